@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — the scan benchmark BASELINE.json names.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--batch B]
+
+A step = one exact top-10 search of a batch of queries over the whole synthetic corpus (the hot
+path of perceive-core: lib.rs:63-77 similarity + search.rs:157-182 selection), corpus resident in
+HBM.  N=1 default workload: BASELINE configs[2] "100M x 384-d, batch=64 queries, top-10, 1 MI355X"
+(the configuration the >=70 %-of-HBM-roofline target is quoted on; it fits one 288 GB GPU).
+N>1 (launched by torch.distributed.run, one rank per GPU): the same 100M rows row-sharded over the
+ranks, per-shard exact top-k, RCCL all-gather of the [B][k] hit lists, merge — strong scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HIT_BYTES = 24          # sizeof(pcv_hit)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=int(os.environ.get("PCV_BENCH_ROWS", 100_000_000)))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PCV_BENCH_BATCH", 64)))
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wave", "mfma"])
+    ap.add_argument("--cpu-rows", type=int, default=int(os.environ.get("PCV_BENCH_CPU_ROWS", 1_000_000)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--normalized", action="store_true", help="store unit-norm rows (MiniLM-like)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Reference-shaped CPU leg: the oracle's multithreaded C port of lib.rs:67-77 + top-k on the
+    host cores of this node, bounded sample (reported, not a target)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi
+
+    orc = oracle_ffi.load()
+    threads = orc.hardware_threads()
+    n = max(10_000, args.cpu_rows)
+    rows = orc.synth_rows(0x5EED, 0, n, args.dim, args.normalized)
+    q = orc.synth_rows(0x5EED + 1, 0, args.batch, args.dim)
+    secs, _, _ = orc.baseline_scan(q, rows[: max(10_000, n // 20)], args.k, threads)  # calibration slice
+    rate = max(10_000, n // 20) / max(secs, 1e-9)
+    reps = int(min(50, max(1, round(12.0 * rate / n))))  # ~12 s of CPU work
+    total = 0.0
+    for _ in range(reps):
+        secs, _, _ = orc.baseline_scan(q, rows, args.k, threads)
+        total += secs
+    return {
+        "value": n * reps / total,
+        "unit": "vectors/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{reps} x fused f32 cosine+top-{args.k} scan of {n} x {args.dim} synthetic rows, batch={args.batch}, "
+                  f"{total:.1f} s on {threads} threads (oracle/baseline.c)",
+        "queries_per_s": args.batch * reps / total,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    dist = torch = None
+    if world > 1:
+        # torch first: its bundled HIP runtime must be the one both it and libperceive_hip.so bind
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import perceive_amd as pa
+
+    ctx = pa.Context(local_rank if world > 1 else 0)
+    lo = args.rows * rank // world
+    hi = args.rows * (rank + 1) // world
+    searcher = pa.Searcher(ctx, args.dim, "cosine")
+    t0 = time.time()
+    searcher.add_synthetic(1, hi - lo, 0x5EED, first_row=lo, normalize=args.normalized)
+    searcher.finalize()
+    searcher.set_shard_offset(lo)
+    searcher.set_kernel(args.kernel)
+    t_build = time.time() - t0
+
+    # same query stream on every rank (device-side generator twin lives in the oracle; queries are
+    # tiny, so they are generated with numpy from a fixed seed instead)
+    rng = np.random.default_rng(0x5EED + 1)
+    queries = rng.standard_normal((args.warmup + args.steps, args.batch, args.dim)).astype(np.float32)
+
+    B, k = args.batch, args.k
+    if world > 1:
+        local = torch.empty(B * k * HIT_BYTES, dtype=torch.uint8, device="cuda")
+        gathered = torch.empty(world * B * k * HIT_BYTES, dtype=torch.uint8, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    scan_ms, scan_bytes, cands, reruns = [], [], [], 0
+    last = None
+
+    def step(i, timed):
+        nonlocal last, reruns
+        q = queries[i]
+        if world == 1:
+            last = searcher.search_vectors(None, k, q)
+        else:
+            searcher.search_device(None, k, q, local.data_ptr())  # returns after the stream drained
+            dist.all_gather_into_tensor(gathered, local)
+            torch.cuda.current_stream().synchronize()
+            last = pa.merge_topk(ctx, "cosine", args.dim, gathered.data_ptr(), world, B, k)
+        if timed:
+            st = searcher.last_stats()
+            scan_ms.append(st["scan_ms"])
+            scan_bytes.append(st["bytes_algorithmic"])
+            cands.append(st["candidates"])
+            reruns += st["overflow_reruns"]
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the dominant kernel's duration: slowest rank per step decides
+        sm = torch.tensor([float(np.mean(scan_ms))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(sm, op=dist.ReduceOp.MAX)
+        mean_scan_ms = float(sm.item())
+    else:
+        mean_scan_ms = float(np.mean(scan_ms))
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        vectors_per_s = args.rows * args.steps / elapsed
+        per_launch_bytes = float(np.mean(scan_bytes))  # this rank's shard: rows * dim * 4
+        achieved = per_launch_bytes / (mean_scan_ms * 1e-3) / 1e9
+        ids, scores, counts = last
+        out = {
+            "metric": f"vectors scanned/sec (exact cosine top-{k}, {args.dim}-d f32, batch={B})",
+            "value": vectors_per_s,
+            "unit": "vectors/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.rows} x {args.dim} f32 synthetic corpus, batch={B} queries, top-{k}, "
+                            f"{world} MI355X" + (" (rows sharded, RCCL all-gather of per-shard top-k)" if world > 1 else ""),
+                "rows": args.rows, "dim": args.dim, "batch": B, "k": k,
+                "kernel": {1: "wave", 2: "mfma"}[searcher.last_stats()["kernel_used"]],
+                "rows_normalized": bool(args.normalized),
+            },
+            "queries_per_s": B * args.steps / elapsed,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "kernel": "scan_mfma_kernel" if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel",
+                "bytes_per_launch": per_launch_bytes,
+                "kernel_ms": mean_scan_ms,
+            },
+            "candidates_per_query": float(np.mean(cands)) / B,
+            "overflow_reruns": reruns,
+            "build_s": t_build,
+            "sample_result": {"ids": [int(x) for x in ids[0][:3]], "scores": [float(x) for x in scores[0][:3]]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+
+    searcher.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,247 @@
+/*
+ * perceive_hip.h — C ABI of the MI355X-native replacement for perceive-core's hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: the path
+ * sits behind ordinary Rust `pub` items of crate `perceive-core`.  Each entry point below names
+ * the reference item it replaces (paths relative to the reference checkout).  A Rust shim
+ * (`extern "C"` block + `Model`/`Searcher` wrappers) binds exactly these symbols.
+ *
+ * Conventions
+ *   - every function returns a pcv_status (0 = ok); no C++ exception or abort crosses the boundary;
+ *   - pcv_last_error() returns a thread-local, NUL-terminated description of the last failure;
+ *   - all handles are opaque; outputs are caller-allocated; the library never frees caller memory;
+ *   - host pointers unless a parameter is documented as a device pointer;
+ *   - a searcher handle may be searched from several host threads (calls serialise on an internal
+ *     mutex, like the reference's model worker channel `model.rs:161,187`).
+ */
+#ifndef PERCEIVE_HIP_H
+#define PERCEIVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int pcv_status;
+enum {
+    PCV_OK = 0,
+    PCV_ERR_INVALID = 1,      /* bad argument / bad handle state                                */
+    PCV_ERR_DEVICE = 2,       /* a HIP call failed (no GPU, out of memory, launch failure)      */
+    PCV_ERR_UNSUPPORTED = 3,  /* shape outside what the kernels implement                       */
+    PCV_ERR_IO = 4,           /* weight / vocab file problems                                   */
+    PCV_ERR_INTERNAL = 5
+};
+
+/* Ranking metric of a searcher.
+ * PCV_METRIC_COSINE : score = cos(q, x), the brute-force path `lib.rs:67-77`
+ *                     (cosine_similarity_single_query / _multi_query); results best-first.
+ * PCV_METRIC_DOT    : ranks by the raw dot product and reports the reference Searcher's distance
+ *                     `max(0, 1 - dot/len)` (`search.rs:266-279`), ascending like `search.rs:179`. */
+enum { PCV_METRIC_COSINE = 0, PCV_METRIC_DOT = 1 };
+
+typedef struct pcv_ctx pcv_ctx;
+typedef struct pcv_searcher pcv_searcher;
+typedef struct pcv_model pcv_model;
+
+/* ---- library / device context ------------------------------------------------------------- */
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* pcv_last_error(void);
+
+/* Library version string, e.g. "perceive-hip 0.1 (gfx950)". */
+const char* pcv_version(void);
+
+/* Number of visible HIP devices (0 when there is no GPU; never fails). */
+int pcv_device_count(void);
+
+/* Bind a context to one GPU.  One process drives one GPU (one rank per device); the context owns
+ * the HIP stream every kernel of its handles is launched on.
+ * Replaces: `tch::Device::cuda_if_available()` at model.rs:117 / configs.rs:117. */
+pcv_status pcv_init(int device_index, pcv_ctx** out_ctx);
+pcv_status pcv_shutdown(pcv_ctx* ctx);
+/* Block until everything queued on the context's stream has finished. */
+pcv_status pcv_synchronize(pcv_ctx* ctx);
+/* The context's hipStream_t (as void*), for callers that order their own work against it. */
+void* pcv_stream(pcv_ctx* ctx);
+
+/* Plain device buffers for hosts that have no HIP binding of their own (the per-shard hit lists that
+ * an RCCL all-gather exchanges live in such buffers). */
+pcv_status pcv_device_alloc(pcv_ctx* ctx, size_t n_bytes, void** out_dptr);
+pcv_status pcv_device_free(pcv_ctx* ctx, void* dptr);
+pcv_status pcv_copy_to_host(pcv_ctx* ctx, void* dst_host, const void* src_dev, size_t n_bytes);
+pcv_status pcv_copy_to_device(pcv_ctx* ctx, void* dst_dev, const void* src_host, size_t n_bytes);
+
+/* ---- embedding blob codec (search.rs:281-294) ---------------------------------------------- */
+
+/* deserialize_embedding: `n_bytes/4` little-endian f32 (trailing bytes that do not fill a chunk
+ * are an error here; the reference would panic on the short chunk). */
+pcv_status pcv_deserialize_embedding(const uint8_t* blob, size_t n_bytes, float* out, size_t out_cap,
+                                     size_t* out_len);
+/* serialize_embedding: writes 4*n bytes, little-endian. */
+pcv_status pcv_serialize_embedding(const float* v, size_t n, uint8_t* out, size_t out_cap);
+
+/* ---- Searcher (search.rs:29-260) ------------------------------------------------------------ */
+
+/* Searcher::build, part 1 (search.rs:38-56): an empty index for `dim`-wide f32 embeddings. */
+pcv_status pcv_searcher_create(pcv_ctx* ctx, int dim, int metric, pcv_searcher** out);
+pcv_status pcv_searcher_destroy(pcv_searcher* s);
+
+/* build_sources row insert (search.rs:87-113,146-148): append `n` rows (row-major [n][dim] f32,
+ * host memory) with their item ids to source `source_id`.  Rows become searchable after
+ * pcv_searcher_finalize.  `ids` may be NULL: ids are then the row's running index in the source. */
+pcv_status pcv_searcher_add_rows(pcv_searcher* s, int64_t source_id, const int64_t* ids,
+                                 const float* rows, int64_t n);
+/* Same, from the on-disk form: `n` blobs of dim*4 bytes each, back to back (search.rs:99,281). */
+pcv_status pcv_searcher_add_blobs(pcv_searcher* s, int64_t source_id, const int64_t* ids,
+                                  const uint8_t* blobs, int64_t n);
+/* Synthetic rows generated on the device (never cross PCIe): row r (0-based within this call) of
+ * the source is synth_row(seed, first_row + r); ids are first_row + r.  See DESIGN.md §synthetic
+ * data; oracle/synth.c is the CPU twin.  normalize != 0 stores x/|x| instead of x. */
+pcv_status pcv_searcher_add_synthetic(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
+                                      int64_t first_row, int normalize);
+/* Searcher::rebuild_source (search.rs:58-79): drop every row of `source_id`; follow with
+ * add_* + finalize to install the replacement.  Unknown source: no-op. */
+pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id);
+/* Pack pending rows into the HBM layout, compute row norms (set_searching_mode, search.rs:150). */
+pcv_status pcv_searcher_finalize(pcv_searcher* s);
+
+pcv_status pcv_searcher_num_rows(pcv_searcher* s, int64_t* out_rows);
+pcv_status pcv_searcher_num_sources(pcv_searcher* s, int* out_n);
+pcv_status pcv_searcher_source_ids(pcv_searcher* s, int64_t* out_ids, int cap);
+/* Read rows back (row-major) by global position (sources in insertion order, rows in insertion
+ * order inside a source).  Test/diagnostic path. */
+pcv_status pcv_searcher_get_rows(pcv_searcher* s, const int64_t* positions, int64_t n, float* out_rows,
+                                 int64_t* out_ids);
+
+/* Which scan kernel pcv_searcher_search uses. AUTO: wave-reduction kernel for n_queries <= 4,
+ * MFMA tile kernel otherwise. */
+enum { PCV_KERNEL_AUTO = 0, PCV_KERNEL_WAVE = 1, PCV_KERNEL_MFMA = 2 };
+pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel);
+
+/* Searcher::search_vector (search.rs:157-182), batched over `n_queries` query vectors.
+ *   queries      [n_queries][dim] f32
+ *   source_ids   sources to search (search.rs:166 filter); NULL/0 = all sources
+ *   k            num_results
+ *   out_ids      [n_queries][k] item ids, best first
+ *   out_scores   [n_queries][k] cosine (COSINE) or reference distance (DOT)
+ *   out_counts   [n_queries] entries actually filled (< k when fewer valid rows exist)
+ * Result order: COSINE descending cosine, DOT ascending distance; ties -> lower global position.
+ * Rows whose norm is 0 or not finite (cosine undefined; the reference would yield NaN and panic at
+ * search.rs:179) are never returned.  Exactness: the returned set is the exact top-k under the
+ * canonical f64 score (DESIGN.md §canonical ranking), not an approximation. */
+pcv_status pcv_searcher_search(pcv_searcher* s, const float* queries, int n_queries,
+                               const int64_t* source_ids, int n_sources, int k, int64_t* out_ids,
+                               float* out_scores, int* out_counts);
+
+/* One entry of a per-shard result list, the unit exchanged between GPUs (all-gather payload). */
+typedef struct pcv_hit {
+    double score;  /* canonical f64 score (cosine or dot)                 */
+    int64_t pos;   /* global row position (shard offset already applied)  */
+    int64_t id;    /* item id                                             */
+} pcv_hit;
+
+/* Row position offset of this searcher's shard inside the whole (multi-GPU) corpus. */
+pcv_status pcv_searcher_set_shard_offset(pcv_searcher* s, int64_t first_global_pos);
+
+/* Local (per-shard) exact top-k, results left on the device: `d_out` is a DEVICE pointer to
+ * [n_queries][k] pcv_hit; unfilled entries have pos = -1.  Queued on the context stream; the
+ * call returns after the stream has drained unless `async` != 0. */
+pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int n_queries,
+                                      const int64_t* source_ids, int n_sources, int k, void* d_out,
+                                      int async);
+
+/* Cross-shard merge (replaces the rayon flat_map + sort + truncate of search.rs:163-181):
+ * `d_lists` is a DEVICE pointer to [n_shards][n_queries][k] pcv_hit (the all-gather result),
+ * written to host arrays shaped like pcv_searcher_search's outputs. */
+pcv_status pcv_merge_topk(pcv_ctx* ctx, int metric, int dim, const void* d_lists, int n_shards, int n_queries,
+                          int k, int64_t* out_ids, float* out_scores, int* out_counts);
+
+/* Brute-force similarity matrices of lib.rs:63-77 for small inputs (tests, highlight.rs:109):
+ *   out[b][n] = dot(a_b, m_n)                       pcv_dot_product            (lib.rs:63-65)
+ *   out[b][n] = cos(a_b, m_n)                       pcv_cosine_similarity      (lib.rs:67-77)
+ * a: [B][dim], m: [N][dim], out: [B][N], all host f32.  Computed on the GPU in f32. */
+pcv_status pcv_dot_product(pcv_ctx* ctx, const float* a, int B, const float* m, int64_t N, int dim,
+                           float* out);
+pcv_status pcv_cosine_similarity(pcv_ctx* ctx, const float* a, int B, const float* m, int64_t N, int dim,
+                                 float* out);
+
+/* Counters of the most recent search on this handle (diagnostics + bench roofline). */
+typedef struct pcv_scan_stats {
+    int64_t rows_scanned;        /* rows streamed by the scan kernel(s), padding excluded        */
+    int64_t bytes_algorithmic;   /* rows_scanned * dim * 4                                       */
+    float scan_ms;               /* hipEvent time of the scan kernel launches only               */
+    float total_ms;              /* hipEvent time of the whole device pipeline                   */
+    int64_t candidates;          /* rows rescored exactly, summed over queries                   */
+    int32_t scan_launches;       /* scan kernel launches (reruns after overflow included)        */
+    int32_t overflow_reruns;     /* passes repeated because a candidate list overflowed          */
+    int32_t kernel_used;         /* PCV_KERNEL_WAVE or PCV_KERNEL_MFMA                           */
+    int32_t reserved;
+} pcv_scan_stats;
+pcv_status pcv_searcher_last_stats(pcv_searcher* s, pcv_scan_stats* out);
+
+/* ---- Model (model.rs:56-191, model/worker.rs:78-106) ---------------------------------------- */
+
+/* Transformer description: what rust-bert reads from config.json / modules.json /
+ * 1_Pooling/config.json (model.rs:84-151). */
+typedef struct pcv_model_desc {
+    int32_t vocab_size;          /* 30522 for all-MiniLM-L6-v2                                  */
+    int32_t hidden;              /* 384                                                         */
+    int32_t layers;              /* 6                                                           */
+    int32_t heads;               /* 12                                                          */
+    int32_t intermediate;        /* 1536                                                        */
+    int32_t max_positions;       /* 512                                                         */
+    int32_t type_vocab;          /* 2                                                           */
+    float layer_norm_eps;        /* 1e-12                                                       */
+    int32_t pooling;             /* PCV_POOL_*                                                  */
+    int32_t normalize;           /* modules.has_normalization(), model.rs:151                   */
+    int32_t dense_out;           /* 0 = no Dense module; else output width (model.rs:139-149)   */
+    int32_t dense_activation;    /* PCV_ACT_* of the Dense module                               */
+    int32_t max_seq_length;      /* sentence_bert_config.max_seq_length (tokenize.rs:66)        */
+    int32_t compute;             /* PCV_COMPUTE_*                                               */
+} pcv_model_desc;
+enum { PCV_POOL_MEAN = 0, PCV_POOL_CLS = 1, PCV_POOL_MAX = 2, PCV_POOL_MEAN_SQRT_LEN = 3 };
+enum { PCV_ACT_IDENTITY = 0, PCV_ACT_TANH = 1 };
+/* F32: every GEMM on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), the reference's dtype.
+ * BF16: GEMM operands rounded to bf16, f32 accumulate (faster, ~1e-2 relative on activations). */
+enum { PCV_COMPUTE_F32 = 0, PCV_COMPUTE_BF16 = 1 };
+
+/* Fill `d` with the all-MiniLM-L6-v2 shape. */
+void pcv_model_desc_minilm_l6(pcv_model_desc* d);
+
+/* Model::new_pretrained, transformer part (model.rs:117-151).  `weights_path` is a flat weight
+ * file in this library's own format; NULL = seeded synthetic weights
+ * (synth_weight(seed, tensor, index)), the only form available offline. */
+pcv_status pcv_model_create(pcv_ctx* ctx, const pcv_model_desc* desc, const char* weights_path,
+                            uint64_t synthetic_seed, pcv_model** out);
+pcv_status pcv_model_destroy(pcv_model* m);
+pcv_status pcv_model_output_dim(pcv_model* m, int* out_dim);
+/* Overwrite one named tensor from host f32 data (tests load oracle weights through this). */
+pcv_status pcv_model_set_tensor(pcv_model* m, const char* name, const float* data, int64_t n);
+/* Copy one named tensor to the host (for oracles that must share the synthetic weights). */
+pcv_status pcv_model_get_tensor(pcv_model* m, const char* name, float* out, int64_t cap, int64_t* out_n);
+
+/* WorkerData::encode_tokens (worker.rs:78-106): ids/mask are [B][L] int64 row-major exactly as
+ * generate_token_tensors lays them out (tokenize.rs:13-51: right-padded, mask = id != pad).
+ * out: [B][output_dim] f32. */
+pcv_status pcv_model_encode_tokens(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L,
+                                   float* out);
+/* Same with the output left on the device (DEVICE pointer d_out, [B][output_dim] f32). */
+pcv_status pcv_model_encode_tokens_device(pcv_model* m, const int64_t* ids, const int64_t* mask, int B,
+                                          int L, void* d_out, int async);
+/* Per-layer hidden states of the last encode (test hook): layer 0 = embedding output,
+ * 1..layers = encoder layer outputs, [B][L][hidden] f32. */
+pcv_status pcv_model_debug_hidden(pcv_model* m, int layer, float* out, int64_t cap);
+
+typedef struct pcv_encode_stats {
+    float total_ms;      /* hipEvent time of the whole forward                                  */
+    double flops;        /* algorithmic FLOPs of the forward (SURVEY.md §8 row D formula)       */
+    int32_t batch, seq_len;
+} pcv_encode_stats;
+pcv_status pcv_model_last_stats(pcv_model* m, pcv_encode_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERCEIVE_HIP_H */

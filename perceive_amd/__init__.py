@@ -1,0 +1,16 @@
+"""perceive_amd — MI355X-native embedding encode + exact similarity scan behind perceive-core's
+Model / Searcher API (dimfeld/perceive).  Product code: HIP kernels + C ABI in csrc/, this package
+is the thin host mirror.  Nothing here imports oracle/ (test infrastructure)."""
+from ._ffi import PcvError, LIB_PATH  # noqa: F401
+from .context import Context, device_count  # noqa: F401
+from .search import (  # noqa: F401
+    SearchItem,
+    Searcher,
+    cosine_similarity_multi_query,
+    cosine_similarity_single_query,
+    deserialize_embedding,
+    dot_product,
+    encode_query,
+    merge_topk,
+    serialize_embedding,
+)

@@ -1,0 +1,65 @@
+// common.h — shared host-side helpers of libperceive_hip (error plumbing, HIP checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/perceive_hip.h"
+
+namespace pcv {
+
+// thread-local last-error text behind pcv_last_error()
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+struct Error {
+    pcv_status status;
+};
+
+#define PCV_FAIL(status, ...)            \
+    do {                                 \
+        ::pcv::set_error(__VA_ARGS__);   \
+        throw ::pcv::Error{(status)};    \
+    } while (0)
+
+#define PCV_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            PCV_FAIL(PCV_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),   \
+                     __FILE__, __LINE__);                                                      \
+    } while (0)
+
+#define PCV_REQUIRE(cond, ...)                              \
+    do {                                                    \
+        if (!(cond)) PCV_FAIL(PCV_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+// Wrap a C-ABI entry point: nothing may escape as an exception.
+template <class F>
+static inline pcv_status guarded(F&& f) {
+    try {
+        f();
+        return PCV_OK;
+    } catch (const Error& e) {
+        return e.status;
+    } catch (const std::exception& e) {
+        set_error("internal error: %s", e.what());
+        return PCV_ERR_INTERNAL;
+    } catch (...) {
+        set_error("internal error: unknown exception");
+        return PCV_ERR_INTERNAL;
+    }
+}
+
+}  // namespace pcv
+
+struct pcv_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t props;
+    int num_cus = 0;
+};

@@ -1,0 +1,793 @@
+// scan_kernels.hip — gfx950 kernels of the exact similarity scan (replaces lib.rs:63-77 +
+// search.rs:157-182 of the reference).
+//
+// Pipeline of one search (all on the context stream, no host round trip in between):
+//   prep_queries -> seed -> scan (wave | mfma) -> rescore -> select
+// The scan is a *screening* pass: it streams the corpus once, computes an approximate score s per
+// (query,row) with |s - c| <= eps of the canonical f64 score c, and emits every row that could
+// still be in the top-k:   emit iff !(s < tau_q - 2*eps),   tau_q = running k-th best s.
+// tau only grows, so the emitted set is a superset of the exact top-k; rescore+select then rank
+// the few hundred survivors per query in exact f64.  HBM traffic = one pass over the rows.
+#include "scan.h"
+#include "synth.h"
+
+namespace pcv {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int find_seg(const ScanParams& p, uint32_t gb) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxSeg; ++i)
+        if (i < p.nseg && gb >= p.seg[i].blk0) s = i;
+    return s;
+}
+
+// A surviving (query,row) pair: append to the query's candidate list and, unless the row was
+// already ranked by the seed kernel, try to raise the running k-th best.
+// slots[q][0..k) always hold approximate scores of k DISTINCT rows (or -inf), each slot only ever
+// grows, so min(slots) is a valid lower bound of the final k-th best approximate score.
+__device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint32_t row, float s,
+                                      bool feeds_slots) {
+    uint32_t idx = atomicAdd(&p.cand_cnt[q], 1u);
+    if (idx < p.cand_cap) p.cand[(size_t)q * p.cand_cap + idx] = ((uint64_t)(uint32_t)seg << 32) | row;
+    if (!feeds_slots || !isfinite(s)) return;
+    const uint32_t key = f32_key(s);
+    uint32_t* sl = p.slots + (size_t)q * kMaxK;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        uint32_t mn = 0xffffffffu;
+        int mi = 0;
+        for (int i = 0; i < p.k; ++i) {
+            uint32_t v = ld_relaxed(&sl[i]);
+            if (v < mn) {
+                mn = v;
+                mi = i;
+            }
+        }
+        if (key <= mn) return;
+        if (atomicCAS(&sl[mi], mn, key) == mn) {
+            uint32_t nm = 0xffffffffu;
+            for (int i = 0; i < p.k; ++i) nm = min(nm, ld_relaxed(&sl[i]));
+            atomicMax(&p.tau[q], nm);
+            return;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize-time kernels
+// ------------------------------------------------------------------------------------------------
+
+// row-major staging [n][D] -> blocked layout, rows row0.. of the segment (buffer pre-zeroed)
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ rows, int64_t n, int D, int D4,
+                                                        float4* __restrict__ blk, uint32_t row0) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(t & 31);
+    const int64_t u = t >> 5;
+    const int f4 = (int)(u % D4);
+    const int64_t lb = u / D4;  // block relative to the first touched block
+    const uint32_t first_blk = row0 >> 5;
+    const int64_t row = (lb + first_blk) * 32 + r;  // row inside the segment
+    const int64_t src = row - row0;
+    if (src < 0 || src >= n) return;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int f = f4 * 4 + j;
+        v[j] = f < D ? rows[src * D + f] : 0.0f;
+    }
+    blk[((lb + first_blk) * D4 + f4) * 32 + r] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// per-row scale = 1/|x| (cosine) or 1 (dot); 0 marks rows that can never be a result
+// (padding, zero / non-finite norm).  |x|^2 accumulated in f64 in feature order.
+__global__ __launch_bounds__(256) void row_scales_kernel(const float4* __restrict__ blk, uint32_t nblocks,
+                                                         uint32_t nrows, int D4, int metric,
+                                                         float* __restrict__ scale, uint32_t* max_norm_bits) {
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= nblocks * 32) return;
+    float out = 0.0f;
+    if (row < nrows) {
+        const float4* base = blk + (size_t)(row >> 5) * D4 * 32 + (row & 31);
+        double nx = 0.0;
+        for (int f4 = 0; f4 < D4; ++f4) {
+            float4 v = base[(size_t)f4 * 32];
+            nx += (double)v.x * (double)v.x;
+            nx += (double)v.y * (double)v.y;
+            nx += (double)v.z * (double)v.z;
+            nx += (double)v.w * (double)v.w;
+        }
+        const bool finite = nx < __builtin_inf();  // false for inf and NaN
+        if (metric == PCV_METRIC_DOT) {
+            out = finite ? 1.0f : 0.0f;
+        } else {
+            out = (finite && nx >= 0x1p-126) ? (float)(1.0 / sqrt(nx)) : 0.0f;
+        }
+        if (out != 0.0f) {
+            float nrm = (float)sqrt(nx) * 1.000001f;
+            atomicMax(max_norm_bits, __builtin_bit_cast(uint32_t, nrm));
+        }
+    }
+    scale[row] = out;
+}
+
+__global__ __launch_bounds__(256) void synth_inv_kernel(uint32_t nrows, int D4src, uint64_t seed, int64_t first_row,
+                                                        float* __restrict__ inv) {
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= nrows) return;
+    double nx = 0.0;
+    for (int f4 = 0; f4 < D4src; ++f4) {
+        float4 v = synth_piece(seed, first_row + row, (uint32_t)f4);
+        nx += (double)v.x * (double)v.x;
+        nx += (double)v.y * (double)v.y;
+        nx += (double)v.z * (double)v.z;
+        nx += (double)v.w * (double)v.w;
+    }
+    inv[row] = (float)(1.0 / sqrt(nx));
+}
+
+// thread per (block, piece, row-in-block): segment rows row0..row0+nrows get synth rows
+// first_row.. ; pieces beyond D stay zero
+__global__ __launch_bounds__(256) void synth_fill_kernel(float4* __restrict__ blk, uint32_t nrows, uint32_t row0,
+                                                         int D4src, int D4, uint64_t seed, int64_t first_row,
+                                                         const float* __restrict__ inv) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(t & 31);
+    const int64_t u = t >> 5;
+    const int f4 = (int)(u % D4src);
+    const int64_t lb = u / D4src;
+    const uint32_t first_blk = row0 >> 5;
+    const int64_t row = (lb + first_blk) * 32 + r;
+    const int64_t src = row - row0;
+    if (src < 0 || src >= nrows) return;
+    float4 v = synth_piece(seed, first_row + src, (uint32_t)f4);
+    if (inv) {
+        float s = inv[src];
+        v.x *= s;
+        v.y *= s;
+        v.z *= s;
+        v.w *= s;
+    }
+    blk[((lb + first_blk) * D4 + f4) * 32 + r] = v;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const SegDesc* __restrict__ segs, int nseg,
+                                                          const int64_t* __restrict__ pos, int64_t n, int D, int D4,
+                                                          float* __restrict__ out_rows,
+                                                          int64_t* __restrict__ out_ids) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int D4src = (D + 3) / 4;
+    const int64_t i = t / D4src;
+    const int f4 = (int)(t % D4src);
+    if (i >= n) return;
+    const int64_t gp = pos[i];
+    int s = -1;
+    for (int j = 0; j < nseg; ++j)
+        if (gp >= segs[j].pos0 && gp < segs[j].pos0 + (int64_t)segs[j].nrows) s = j;
+    float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+    int64_t id = -1;
+    if (s >= 0) {
+        const uint32_t row = (uint32_t)(gp - segs[s].pos0);
+        v = segs[s].blk[((size_t)(row >> 5) * D4 + f4) * 32 + (row & 31)];
+        id = segs[s].ids ? segs[s].ids[row] : segs[s].id0 + row;
+    }
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int j = 0; j < 4; ++j)
+        if (f4 * 4 + j < D) out_rows[i * D + f4 * 4 + j] = vv[j];
+    if (f4 == 0 && out_ids) out_ids[i] = id;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-search kernels
+// ------------------------------------------------------------------------------------------------
+
+// one workgroup per query slot (64 slots always, so the bf16 tile rows >= B are zeroed)
+__global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restrict__ queries, int B, int D, int Dp,
+                                                          int metric, float eps_rel, float max_norm, int k,
+                                                          float* __restrict__ qf32, uint16_t* __restrict__ qbf16,
+                                                          float* __restrict__ qraw, double* __restrict__ qnorm2,
+                                                          float* __restrict__ margin, uint32_t* __restrict__ tau,
+                                                          uint32_t* __restrict__ slots,
+                                                          uint32_t* __restrict__ cand_cnt) {
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (q >= B) {
+        if (q < kMfmaQueries)
+            for (int i = tid; i < Dp; i += 64) qbf16[(size_t)q * Dp + i] = 0;
+        return;
+    }
+    __shared__ double s_nq;
+    const float* src = queries + (size_t)q * D;
+    if (tid == 0) {
+        double nq = 0.0;
+        for (int i = 0; i < D; ++i) nq += (double)src[i] * (double)src[i];
+        s_nq = nq;
+    }
+    __syncthreads();
+    const double nq = s_nq;
+    const bool ok = (nq < __builtin_inf()) && (metric == PCV_METRIC_DOT || nq >= 0x1p-126);
+    const float inv = (metric == PCV_METRIC_DOT) ? 1.0f : (ok ? (float)(1.0 / sqrt(nq)) : 0.0f);
+    for (int i = tid; i < Dp; i += 64) {
+        const float raw = i < D ? src[i] : 0.0f;
+        const float qh = ok ? raw * inv : 0.0f;
+        qraw[(size_t)q * Dp + i] = raw;
+        qf32[(size_t)q * Dp + i] = qh;
+        const __bf16 hb = (__bf16)qh;
+        qbf16[(size_t)q * Dp + i] = __builtin_bit_cast(uint16_t, hb);
+    }
+    for (int i = tid; i < kMaxK; i += 64) slots[(size_t)q * kMaxK + i] = kKeyNegInf;
+    if (tid == 0) {
+        qnorm2[q] = ok ? nq : __builtin_nan("");
+        // cosine: scores are O(1); dot: |s - c| <= eps_rel * |q| * max|x|
+        float m = 2.0f * eps_rel;
+        if (metric == PCV_METRIC_DOT) m *= (float)sqrt(nq) * max_norm * 1.0001f;
+        margin[q] = m;
+        tau[q] = kKeyNegInf;
+        cand_cnt[q] = 0;
+    }
+}
+
+// Seed: rank the first rows of segment 0 per query (f32 FMA chain) and install the k best as the
+// initial slots / threshold, so the streaming kernels start with a useful filter.
+__global__ __launch_bounds__(256) void seed_kernel(ScanParams p) {
+    extern __shared__ float smem[];
+    const int Dp = p.D4 * 4;
+    float* sq = smem;                             // [Dp]
+    uint32_t* keys = (uint32_t*)(smem + Dp);      // [kSeedRows]
+    __shared__ unsigned long long red[256];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const SegDesc& sg = p.seg[0];
+    const uint32_t nseed = min(sg.nrows, p.seed_blocks * 32u);
+    for (int i = tid; i < Dp; i += 256) sq[i] = p.qf32[(size_t)q * Dp + i];
+    __syncthreads();
+    for (uint32_t row = tid; row < (uint32_t)kSeedRows; row += 256) {
+        uint32_t key = 0;  // 0 = absent (below every real key)
+        if (row < nseed) {
+            const float4* base = sg.blk + (size_t)(row >> 5) * p.D4 * 32 + (row & 31);
+            float acc = 0.0f;
+            for (int f4 = 0; f4 < p.D4; ++f4) {
+                const float4 v = base[(size_t)f4 * 32];
+                const float4 qv = *(const float4*)&sq[f4 * 4];
+                acc = fmaf(qv.x, v.x, acc);
+                acc = fmaf(qv.y, v.y, acc);
+                acc = fmaf(qv.z, v.z, acc);
+                acc = fmaf(qv.w, v.w, acc);
+            }
+            const float sc = sg.scale[row];
+            const float s = acc * sc;
+            if (sc != 0.0f && isfinite(s)) key = f32_key(s);
+        }
+        keys[row] = key;
+    }
+    __syncthreads();
+    uint32_t last = kKeyNegInf;
+    for (int j = 0; j < p.k; ++j) {
+        unsigned long long best = 0;
+        for (uint32_t row = tid; row < (uint32_t)kSeedRows; row += 256) {
+            unsigned long long c = ((unsigned long long)keys[row] << 32) | (0xffffffffu - row);
+            best = c > best ? c : best;
+        }
+        red[tid] = best;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) red[tid] = red[tid] > red[tid + off] ? red[tid] : red[tid + off];
+            __syncthreads();
+        }
+        const unsigned long long w = red[0];
+        __syncthreads();
+        const uint32_t wkey = (uint32_t)(w >> 32);
+        if (tid == 0) {
+            last = wkey ? wkey : kKeyNegInf;
+            p.slots[(size_t)q * kMaxK + j] = last;
+            if (wkey) keys[0xffffffffu - (uint32_t)w] = 0;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) p.tau[q] = last;  // k-th best of the seed rows (or -inf when fewer than k)
+}
+
+// Wave-reduction scan for 1..4 queries (BASELINE config "10M x 384, batch=1"): pure HBM streaming.
+// Lane (r = lane&31, h = lane>>5) owns row r of the block and the pieces f4 = 2j+h; the two halves
+// of a row are combined with one cross-lane add.  f32 FMA chain -> eps ~ Dp * 2^-24.
+template <int NB>
+__global__ __launch_bounds__(256) void scan_wave_kernel(ScanParams p) {
+    extern __shared__ float sq[];  // [NB][Dp]
+    const int Dp = p.D4 * 4;
+    for (int i = threadIdx.x; i < NB * Dp; i += 256) sq[i] = p.qf32[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    float mrg[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) mrg[b] = p.margin[b];
+    const uint32_t total_waves = gridDim.x * 4;
+    const int half = p.D4 >> 1;
+    for (uint32_t gb = blockIdx.x * 4 + wave; gb < p.total_blocks; gb += total_waves) {
+        const int si = find_seg(p, gb);
+        const SegDesc& sg = p.seg[si];
+        const uint32_t lb = gb - sg.blk0;
+        const float4* base = sg.blk + (size_t)lb * p.D4 * 32 + h * 32 + r;
+        const float* qb = sq + h * 4;
+        float acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < half; ++j) {
+            const float4 v = base[(size_t)j * 64];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float4 qv = *(const float4*)&qb[b * Dp + j * 8];
+                acc[b] = fmaf(qv.x, v.x, acc[b]);
+                acc[b] = fmaf(qv.y, v.y, acc[b]);
+                acc[b] = fmaf(qv.z, v.z, acc[b]);
+                acc[b] = fmaf(qv.w, v.w, acc[b]);
+            }
+        }
+        const uint32_t row = lb * 32 + r;
+        const float sc = sg.scale[row];
+        bool any = false;
+        float s[NB], thr[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            acc[b] += __shfl_xor(acc[b], 32);
+            s[b] = acc[b] * sc;
+            thr[b] = key_f32(ld_relaxed(&p.tau[b])) - mrg[b];
+            any |= (h == 0) && (sc != 0.0f) && !(s[b] < thr[b]);
+        }
+        if (__any(any)) {
+            const bool feeds = !(si == 0 && lb < p.seed_blocks);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if ((h == 0) && (sc != 0.0f) && !(s[b] < thr[b])) emit_hit(p, b, si, row, s[b], feeds);
+        }
+    }
+}
+
+// MFMA tile scan for up to 64 queries (BASELINE config "100M x 384, batch=64").
+// D[row][query] = sum_k A[row][k] * B[k][query] on v_mfma_f32_32x32x16_bf16: A = 32 corpus rows of a
+// block (f32 from HBM, rounded to bf16 in registers), B = the query tile (bf16, LDS, XOR-swizzled so
+// the 16-lane ds_read_b128 groups are conflict-free).  One bf16 product term -> eps = 2^-8: ~2.4x
+// more survivors than an f32 screen on random data, for 1/16 of the f32 matrix cost; survivors are
+// re-ranked exactly anyway.  Each wave streams its own blocks straight into registers: the blocked
+// HBM layout makes every load two contiguous 512 B runs, so there is no LDS round trip for the corpus.
+template <int NT>
+__global__ __launch_bounds__(256) void scan_mfma_kernel(ScanParams p) {
+    extern __shared__ uint4 lq[];  // [NT*32][Dp/8] 16-byte pieces of 8 bf16, swizzled
+    const int D4 = p.D4;
+    const int P8 = D4 >> 1;   // 16-B pieces per query row
+    const int NCH = D4 >> 4;  // chunks of 64 features
+    for (int i = threadIdx.x; i < NT * 32 * P8; i += 256) {
+        const int q = i / P8, pc = i - q * P8;
+        lq[q * P8 + ((pc & ~15) | ((pc ^ q) & 15))] = ((const uint4*)p.qbf16)[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    float mrg[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mrg[t] = (32 * t + c < p.B) ? p.margin[32 * t + c] : 0.0f;
+
+    const uint32_t total_waves = gridDim.x * 4;
+    uint32_t gb = blockIdx.x * 4 + wave;
+    if (gb >= p.total_blocks) return;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    int si = find_seg(p, gb);
+    uint32_t lb = gb - p.seg[si].blk0;
+    const float4* base = p.seg[si].blk + (size_t)lb * D4 * 32 + h * 64 + c;
+    int ch = 0;
+
+    float4 buf0[8], buf1[8];
+#define PCV_LOAD(buf, bptr, chunk)                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)(buf)[i_] =                         \
+        (bptr)[(size_t)((chunk)*16 + (i_ >> 1) * 4 + (i_ & 1)) * 32];
+    // lane's pieces of k-step ks of the chunk: f4 = chunk*16 + ks*4 + 2h + e  (2h folded into base)
+
+#define PCV_COMPUTE(buf, chunk)                                                                        \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                              \
+        f32x8 v_ = {(buf)[2 * ks_].x,     (buf)[2 * ks_].y,     (buf)[2 * ks_].z,     (buf)[2 * ks_].w,  \
+                    (buf)[2 * ks_ + 1].x, (buf)[2 * ks_ + 1].y, (buf)[2 * ks_ + 1].z, (buf)[2 * ks_ + 1].w}; \
+        const bf16x8 a_ = __builtin_convertvector(v_, bf16x8);                                         \
+        const int pc_ = 2 * ((chunk)*4 + ks_) + h;                                                     \
+        const int ph_ = (pc_ & ~15) | ((pc_ ^ c) & 15);                                                \
+        _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) {                                            \
+            const bf16x8 b_ = *(const bf16x8*)&lq[(32 * t_ + c) * P8 + ph_];                           \
+            acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, acc[t_], 0, 0, 0);               \
+        }                                                                                              \
+    }
+
+    auto epilogue = [&](int esi, uint32_t elb) {
+        const SegDesc& sg = p.seg[esi];
+        const float* scp = sg.scale + (size_t)elb * 32 + 4 * h;
+        float4 s4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s4[g] = *(const float4*)(scp + 8 * g);
+        float thr[NT];
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int q = 32 * t + c;
+            thr[t] = (q < p.B) ? key_f32(ld_relaxed(&p.tau[q])) - mrg[t] : __builtin_inff();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 sv = s4[i >> 2];
+                const float scv = (i & 3) == 0 ? sv.x : (i & 3) == 1 ? sv.y : (i & 3) == 2 ? sv.z : sv.w;
+                any |= !(acc[t][i] * scv < thr[t]);
+            }
+        }
+        if (__any(any)) {
+            const bool feeds = !(esi == 0 && elb < p.seed_blocks);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int q = 32 * t + c;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float4 sv = s4[i >> 2];
+                    const float scv = (i & 3) == 0 ? sv.x : (i & 3) == 1 ? sv.y : (i & 3) == 2 ? sv.z : sv.w;
+                    const float s = acc[t][i] * scv;
+                    if (!(s < thr[t]) && q < p.B && scv != 0.0f) {
+                        const uint32_t row = elb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        emit_hit(p, q, esi, row, s, feeds);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    };
+
+    // flat (block, chunk) stream with two register buffers: the loads of step g+1 are in flight
+    // while step g feeds the matrix cores
+    PCV_LOAD(buf0, base, 0);
+    while (true) {
+        // ---- even step: consume buf0, prefetch into buf1
+        int nch = ch + 1;
+        uint32_t ngb = gb;
+        int nsi = si;
+        uint32_t nlb = lb;
+        const float4* nbase = base;
+        if (nch == NCH) {
+            nch = 0;
+            ngb = gb + total_waves;
+            if (ngb < p.total_blocks) {
+                nsi = find_seg(p, ngb);
+                nlb = ngb - p.seg[nsi].blk0;
+                nbase = p.seg[nsi].blk + (size_t)nlb * D4 * 32 + h * 64 + c;
+            }
+        }
+        bool more = ngb < p.total_blocks;
+        if (more) { PCV_LOAD(buf1, nbase, nch); }
+        PCV_COMPUTE(buf0, ch);
+        if (ch == NCH - 1) epilogue(si, lb);
+        if (!more) break;
+        ch = nch; gb = ngb; si = nsi; lb = nlb; base = nbase;
+        // ---- odd step: consume buf1, prefetch into buf0
+        nch = ch + 1;
+        ngb = gb;
+        nsi = si;
+        nlb = lb;
+        nbase = base;
+        if (nch == NCH) {
+            nch = 0;
+            ngb = gb + total_waves;
+            if (ngb < p.total_blocks) {
+                nsi = find_seg(p, ngb);
+                nlb = ngb - p.seg[nsi].blk0;
+                nbase = p.seg[nsi].blk + (size_t)nlb * D4 * 32 + h * 64 + c;
+            }
+        }
+        more = ngb < p.total_blocks;
+        if (more) { PCV_LOAD(buf0, nbase, nch); }
+        PCV_COMPUTE(buf1, ch);
+        if (ch == NCH - 1) epilogue(si, lb);
+        if (!more) break;
+        ch = nch; gb = ngb; si = nsi; lb = nlb; base = nbase;
+    }
+#undef PCV_LOAD
+#undef PCV_COMPUTE
+}
+
+// Exact canonical score of every surviving (query,row) pair: f64, products exact, sums in feature
+// order — the same definition as oracle/scan.c:orc_canonical_score.
+__global__ __launch_bounds__(256) void rescore_kernel(ScanParams p) {
+    extern __shared__ float sqr[];  // [Dp] raw query
+    const int q = blockIdx.y;
+    const int Dp = p.D4 * 4;
+    const uint32_t cnt = min(p.cand_cnt[q], p.cand_cap);
+    if (blockIdx.x * 256u >= cnt) return;
+    for (int i = threadIdx.x; i < Dp; i += 256) sqr[i] = p.qraw[(size_t)q * Dp + i];
+    __syncthreads();
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cnt) return;
+    const uint64_t e = p.cand[(size_t)q * p.cand_cap + j];
+    const SegDesc& sg = p.seg[(int)(e >> 32)];
+    const uint32_t row = (uint32_t)e;
+    const float4* base = sg.blk + (size_t)(row >> 5) * p.D4 * 32 + (row & 31);
+    double dot = 0.0, nx = 0.0;
+#pragma unroll 8
+    for (int f4 = 0; f4 < p.D4; ++f4) {
+        const float4 v = base[(size_t)f4 * 32];
+        const float4 qv = *(const float4*)&sqr[f4 * 4];
+        dot += (double)qv.x * (double)v.x;
+        nx += (double)v.x * (double)v.x;
+        dot += (double)qv.y * (double)v.y;
+        nx += (double)v.y * (double)v.y;
+        dot += (double)qv.z * (double)v.z;
+        nx += (double)v.z * (double)v.z;
+        dot += (double)qv.w * (double)v.w;
+        nx += (double)v.w * (double)v.w;
+    }
+    const double nq = p.qnorm2[q];
+    const double inf = __builtin_inf();
+    double score = __builtin_nan("");
+    if (p.metric == PCV_METRIC_DOT) {
+        if (dot < inf && dot > -inf && nq == nq) score = dot;
+    } else if (nq >= 0x1p-126 && nq < inf && nx >= 0x1p-126 && nx < inf) {
+        const double cc = dot / (sqrt(nq) * sqrt(nx));
+        if (cc < inf && cc > -inf) score = cc;
+    }
+    p.cand_score[(size_t)q * p.cand_cap + j] = score;
+}
+
+struct Best {
+    double score;
+    int64_t pos;
+    uint32_t idx;
+};
+__device__ __forceinline__ bool better(double sa, int64_t pa, double sb, int64_t pb) {
+    return sa > sb || (sa == sb && pa < pb);
+}
+
+// k rounds of block-wide argmax over the rescored survivors: descending score, ties -> lower
+// global position.  One workgroup per query.
+__global__ __launch_bounds__(256) void select_kernel(ScanParams p, pcv_hit_dev* __restrict__ out) {
+    __shared__ double r_s[256];
+    __shared__ int64_t r_p[256];
+    __shared__ uint32_t r_i[256];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t cnt = min(p.cand_cnt[q], p.cand_cap);
+    const uint64_t* cand = p.cand + (size_t)q * p.cand_cap;
+    double* sc = p.cand_score + (size_t)q * p.cand_cap;
+    for (int j = 0; j < p.k; ++j) {
+        double bs = -__builtin_inf();
+        int64_t bp = INT64_MAX;
+        uint32_t bi = 0xffffffffu;
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const double s = sc[i];
+            if (!(s == s)) continue;  // NaN: undefined score or already taken
+            const uint64_t e = cand[i];
+            const int64_t pos = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
+            if (bi == 0xffffffffu || better(s, pos, bs, bp)) {
+                bs = s;
+                bp = pos;
+                bi = i;
+            }
+        }
+        r_s[tid] = bs;
+        r_p[tid] = bp;
+        r_i[tid] = bi;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) {
+                const bool take = r_i[tid + off] != 0xffffffffu &&
+                                  (r_i[tid] == 0xffffffffu || better(r_s[tid + off], r_p[tid + off], r_s[tid], r_p[tid]));
+                if (take) {
+                    r_s[tid] = r_s[tid + off];
+                    r_p[tid] = r_p[tid + off];
+                    r_i[tid] = r_i[tid + off];
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t wi = r_i[0];
+        if (tid == 0) {
+            pcv_hit_dev hit;
+            if (wi != 0xffffffffu) {
+                const uint64_t e = cand[wi];
+                const SegDesc& sg = p.seg[(int)(e >> 32)];
+                const uint32_t row = (uint32_t)e;
+                hit.score = r_s[0];
+                hit.pos = r_p[0];
+                hit.id = sg.ids ? sg.ids[row] : sg.id0 + (int64_t)row;
+                sc[wi] = __builtin_nan("");
+            } else {
+                hit.score = __builtin_nan("");
+                hit.pos = -1;
+                hit.id = -1;
+            }
+            out[(size_t)q * p.k + j] = hit;
+        }
+        __syncthreads();
+    }
+}
+
+// merge of per-shard top-k lists after the all-gather: [n_shards][B][k] -> [B][k]
+__global__ __launch_bounds__(64) void merge_kernel(const pcv_hit_dev* __restrict__ lists, int n_shards, int B, int k,
+                                                   pcv_hit_dev* __restrict__ out) {
+    extern __shared__ unsigned char taken[];  // [n_shards*k]
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int total = n_shards * k;
+    for (int i = lane; i < total; i += 64) taken[i] = 0;
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        double bs = 0;
+        int64_t bp = 0;
+        int bi = -1;
+        for (int i = lane; i < total; i += 64) {
+            if (taken[i]) continue;
+            const pcv_hit_dev& e = lists[((size_t)(i / k) * B + q) * k + (i % k)];
+            if (e.pos < 0 || !(e.score == e.score)) continue;
+            if (bi < 0 || better(e.score, e.pos, bs, bp)) {
+                bs = e.score;
+                bp = e.pos;
+                bi = i;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double os = __shfl_xor(bs, off);
+            const int64_t op = __shfl_xor(bp, off);
+            const int oi = __shfl_xor(bi, off);
+            if (oi >= 0 && (bi < 0 || better(os, op, bs, bp))) {
+                bs = os;
+                bp = op;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            pcv_hit_dev hit;
+            if (bi >= 0) {
+                hit = lists[((size_t)(bi / k) * B + q) * k + (bi % k)];
+                taken[bi] = 1;
+            } else {
+                hit.score = __builtin_nan("");
+                hit.pos = -1;
+                hit.id = -1;
+            }
+            out[(size_t)q * k + j] = hit;
+        }
+        __syncthreads();
+    }
+}
+
+// lib.rs:63-77 as a plain [B][N] matrix for small inputs (highlight.rs:109, tests): f32.
+__global__ __launch_bounds__(256) void similarity_matrix_kernel(const float* __restrict__ a, int B,
+                                                                const float* __restrict__ m, int64_t N, int D,
+                                                                int cosine, float* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= N) return;
+    const float* q = a + (size_t)b * D;
+    const float* x = m + (size_t)n * D;
+    float dot = 0.0f, nq = 0.0f, nx = 0.0f;
+    for (int i = 0; i < D; ++i) {
+        dot = fmaf(q[i], x[i], dot);
+        nq = fmaf(q[i], q[i], nq);
+        nx = fmaf(x[i], x[i], nx);
+    }
+    out[(size_t)b * N + n] = cosine ? dot / (sqrtf(nq) * sqrtf(nx)) : dot;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+
+static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+void launch_pack_rows(hipStream_t st, const float* rows, int64_t n, int D, int D4, float4* blk, uint32_t nblocks,
+                      uint32_t row0) {
+    if (n <= 0) return;
+    const uint32_t first_blk = row0 >> 5;
+    const uint32_t last_blk = (uint32_t)((row0 + n - 1) >> 5);
+    const int64_t threads = (int64_t)(last_blk - first_blk + 1) * D4 * 32;
+    pack_rows_kernel<<<cdiv64(threads, 256), 256, 0, st>>>(rows, n, D, D4, blk, row0);
+}
+
+void launch_row_scales(hipStream_t st, const float4* blk, uint32_t nblocks, uint32_t nrows, int D4, int metric,
+                       float* scale, uint32_t* max_norm_bits) {
+    if (nblocks == 0) return;
+    row_scales_kernel<<<cdiv64((int64_t)nblocks * 32, 256), 256, 0, st>>>(blk, nblocks, nrows, D4, metric, scale,
+                                                                           max_norm_bits);
+}
+
+void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nblocks, uint32_t nrows, uint32_t row0, int D, int D4,
+                       uint64_t seed, int64_t first_row, int normalize) {
+    if (nrows == 0) return;
+    const int D4src = D / 4;
+    float* inv = nullptr;
+    if (normalize) {
+        hipMallocAsync((void**)&inv, (size_t)nrows * sizeof(float), st);
+        synth_inv_kernel<<<cdiv64(nrows, 256), 256, 0, st>>>(nrows, D4src, seed, first_row, inv);
+    }
+    const uint32_t first_blk = row0 >> 5;
+    const uint32_t last_blk = (uint32_t)(((uint64_t)row0 + nrows - 1) >> 5);
+    const int64_t threads = (int64_t)(last_blk - first_blk + 1) * D4src * 32;
+    synth_fill_kernel<<<cdiv64(threads, 256), 256, 0, st>>>(blk, nrows, row0, D4src, D4, seed, first_row, inv);
+    if (inv) hipFreeAsync(inv, st);
+}
+
+void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const int64_t* d_pos, int64_t n, int D,
+                        int D4, float* out_rows, int64_t* out_ids) {
+    if (n <= 0) return;
+    const int64_t threads = n * ((D + 3) / 4);
+    gather_rows_kernel<<<cdiv64(threads, 256), 256, 0, st>>>(d_segs, nseg, d_pos, n, D, D4, out_rows, out_ids);
+}
+
+void launch_prep_queries(hipStream_t st, const float* d_queries, int B, int D, int Dp, int metric, float eps_rel,
+                         float max_norm, int k, float* qf32, uint16_t* qbf16, float* qraw, double* qnorm2,
+                         float* margin, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt) {
+    const int grid = B > kMfmaQueries ? B : kMfmaQueries;
+    prep_queries_kernel<<<grid, 64, 0, st>>>(d_queries, B, D, Dp, metric, eps_rel, max_norm, k, qf32, qbf16, qraw,
+                                             qnorm2, margin, tau, slots, cand_cnt);
+}
+
+void launch_seed(hipStream_t st, const ScanParams& p) {
+    if (p.seed_blocks == 0 || p.nseg == 0) return;
+    const size_t lds = (size_t)p.D4 * 4 * sizeof(float) + kSeedRows * sizeof(uint32_t);
+    seed_kernel<<<p.B, 256, lds, st>>>(p);
+}
+
+void launch_scan_wave(hipStream_t st, const ScanParams& p, int num_cus) {
+    if (p.total_blocks == 0) return;
+    const size_t lds = (size_t)p.B * p.D4 * 4 * sizeof(float);
+    unsigned grid = (unsigned)num_cus * 8;
+    const unsigned need = (p.total_blocks + 3) / 4;
+    if (grid > need) grid = need;
+    switch (p.B) {
+        case 1: scan_wave_kernel<1><<<grid, 256, lds, st>>>(p); break;
+        case 2: scan_wave_kernel<2><<<grid, 256, lds, st>>>(p); break;
+        case 3: scan_wave_kernel<3><<<grid, 256, lds, st>>>(p); break;
+        default: scan_wave_kernel<4><<<grid, 256, lds, st>>>(p); break;
+    }
+}
+
+void launch_scan_mfma(hipStream_t st, const ScanParams& p, int num_cus) {
+    if (p.total_blocks == 0) return;
+    const int NT = p.B <= 32 ? 1 : 2;
+    const size_t lds = (size_t)NT * 32 * p.D4 * 4 * sizeof(uint16_t);
+    unsigned grid = (unsigned)num_cus * 3;
+    const unsigned need = (p.total_blocks + 3) / 4;
+    if (grid > need) grid = need;
+    if (NT == 1)
+        scan_mfma_kernel<1><<<grid, 256, lds, st>>>(p);
+    else
+        scan_mfma_kernel<2><<<grid, 256, lds, st>>>(p);
+}
+
+void launch_rescore(hipStream_t st, const ScanParams& p) {
+    const size_t lds = (size_t)p.D4 * 4 * sizeof(float);
+    dim3 grid((p.cand_cap + 255) / 256, p.B);
+    rescore_kernel<<<grid, 256, lds, st>>>(p);
+}
+
+void launch_select(hipStream_t st, const ScanParams& p, pcv_hit_dev* out) {
+    select_kernel<<<p.B, 256, 0, st>>>(p, out);
+}
+
+void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out) {
+    merge_kernel<<<B, 64, (size_t)n_shards * k, st>>>(lists, n_shards, B, k, out);
+}
+
+void launch_similarity_matrix(hipStream_t st, const float* a, int B, const float* m, int64_t N, int D, int cosine,
+                              float* out) {
+    if (N <= 0 || B <= 0) return;
+    dim3 grid(cdiv64(N, 256), B);
+    similarity_matrix_kernel<<<grid, 256, 0, st>>>(a, B, m, N, D, cosine, out);
+}
+
+}  // namespace pcv

@@ -1,0 +1,748 @@
+// searcher.cpp — host side of the Searcher C ABI (replaces search.rs:29-260 of the reference).
+//
+// A searcher owns, per source, a list of device-resident corpus segments in the blocked HBM layout
+// (scan.h).  Searching streams the selected segments once; see scan_kernels.hip for the pipeline.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "scan.h"
+
+using namespace pcv;
+
+namespace {
+
+struct Segment {
+    float4* blk = nullptr;
+    float* scale = nullptr;
+    int64_t* ids = nullptr;  // nullptr -> implicit ids id0 + row
+    int64_t id0 = 0;
+    int64_t pos0 = 0;
+    uint32_t nrows = 0, nblocks = 0;
+};
+
+struct SynthSpec {
+    int64_t n;
+    uint64_t seed;
+    int64_t first_row;
+    int normalize;
+};
+
+struct Source {
+    int64_t id = 0;
+    std::vector<Segment> segs;
+    // rows waiting for finalize
+    std::vector<float> pend_rows;
+    std::vector<int64_t> pend_ids;
+    bool pend_ids_explicit = false;
+    int64_t pend_n = 0;
+    int64_t next_implicit_id = 0;
+    std::vector<SynthSpec> pend_synth;
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void ensure(size_t want) {
+        if (want <= n) return;
+        if (p) PCV_HIP(hipFree(p));
+        p = nullptr;
+        n = 0;
+        PCV_HIP(hipMalloc((void**)&p, want * sizeof(T)));
+        n = want;
+    }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct pcv_searcher {
+    pcv_ctx* ctx = nullptr;
+    int D = 0, Dp = 0, D4 = 0;
+    int metric = PCV_METRIC_COSINE;
+    int kernel = PCV_KERNEL_AUTO;
+    int64_t shard_offset = 0;
+    std::vector<Source> sources;
+    uint32_t* d_max_norm_bits = nullptr;
+    float max_norm = 0.0f;
+    bool dirty = false;
+    std::mutex mu;
+    pcv_scan_stats stats{};
+
+    // per-search workspace (sized for one pass of <= 64 queries)
+    DevBuf<float> d_queries, d_qf32, d_qraw, d_margin;
+    DevBuf<uint16_t> d_qbf16;
+    DevBuf<double> d_qnorm2, d_cand_score;
+    DevBuf<uint32_t> d_tau, d_slots, d_cnt;
+    DevBuf<uint64_t> d_cand;
+    DevBuf<pcv_hit_dev> d_hits;
+    uint32_t cand_cap = 8192;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    Source* find_source(int64_t id) {
+        for (auto& s : sources)
+            if (s.id == id) return &s;
+        return nullptr;
+    }
+    Source& get_or_add_source(int64_t id) {
+        if (Source* s = find_source(id)) return *s;
+        sources.emplace_back();
+        sources.back().id = id;
+        return sources.back();
+    }
+};
+
+namespace {
+
+void free_segment(Segment& g) {
+    if (g.blk) hipFree(g.blk);
+    if (g.scale) hipFree(g.scale);
+    if (g.ids) hipFree(g.ids);
+    g = Segment();
+}
+
+// Allocate a segment for `nrows` rows; zero-filled so padding rows / features are exact zeros.
+Segment alloc_segment(pcv_searcher* s, int64_t nrows, bool with_ids) {
+    PCV_REQUIRE(nrows > 0 && nrows < (int64_t)0xffffffe0u, "segment of %lld rows is out of range", (long long)nrows);
+    Segment g;
+    g.nrows = (uint32_t)nrows;
+    g.nblocks = (uint32_t)((nrows + kBlockRows - 1) / kBlockRows);
+    const size_t bytes = (size_t)g.nblocks * s->D4 * 32 * sizeof(float4);
+    hipError_t e = hipMalloc((void**)&g.blk, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        PCV_FAIL(PCV_ERR_DEVICE, "hipMalloc of %.2f GB for %lld corpus rows failed: %s", bytes / 1e9,
+                 (long long)nrows, hipGetErrorString(e));
+    }
+    try {
+        PCV_HIP(hipMalloc((void**)&g.scale, (size_t)g.nblocks * 32 * sizeof(float)));
+        if (with_ids) PCV_HIP(hipMalloc((void**)&g.ids, (size_t)g.nblocks * 32 * sizeof(int64_t)));
+        PCV_HIP(hipMemsetAsync(g.blk, 0, bytes, s->ctx->stream));
+        if (with_ids) PCV_HIP(hipMemsetAsync(g.ids, 0xff, (size_t)g.nblocks * 32 * sizeof(int64_t), s->ctx->stream));
+    } catch (...) {
+        free_segment(g);
+        throw;
+    }
+    return g;
+}
+
+void finish_segment(pcv_searcher* s, Segment& g) {
+    launch_row_scales(s->ctx->stream, g.blk, g.nblocks, g.nrows, s->D4, s->metric, g.scale, s->d_max_norm_bits);
+}
+
+void assign_positions(pcv_searcher* s) {
+    int64_t pos = s->shard_offset;
+    for (auto& src : s->sources)
+        for (auto& g : src.segs) {
+            g.pos0 = pos;
+            pos += g.nrows;
+        }
+}
+
+void do_finalize(pcv_searcher* s) {
+    hipStream_t st = s->ctx->stream;
+    constexpr int64_t kStageRows = 1 << 18;  // rows per H2D staging step (384-d: 400 MB)
+    for (auto& src : s->sources) {
+        if (src.pend_n > 0) {
+            Segment g = alloc_segment(s, src.pend_n, src.pend_ids_explicit);
+            g.id0 = src.pend_ids_explicit ? 0 : src.pend_ids.empty() ? 0 : src.pend_ids[0];
+            float* d_stage = nullptr;
+            try {
+                const int64_t stage_rows = std::min<int64_t>(kStageRows, src.pend_n);
+                PCV_HIP(hipMalloc((void**)&d_stage, (size_t)stage_rows * s->D * sizeof(float)));
+                for (int64_t r0 = 0; r0 < src.pend_n; r0 += stage_rows) {
+                    const int64_t n = std::min(stage_rows, src.pend_n - r0);
+                    PCV_HIP(hipMemcpyAsync(d_stage, src.pend_rows.data() + (size_t)r0 * s->D,
+                                           (size_t)n * s->D * sizeof(float), hipMemcpyHostToDevice, st));
+                    launch_pack_rows(st, d_stage, n, s->D, s->D4, g.blk, g.nblocks, (uint32_t)r0);
+                    PCV_HIP(hipStreamSynchronize(st));  // d_stage is reused
+                }
+                if (src.pend_ids_explicit)
+                    PCV_HIP(hipMemcpyAsync(g.ids, src.pend_ids.data(), (size_t)src.pend_n * sizeof(int64_t),
+                                           hipMemcpyHostToDevice, st));
+                finish_segment(s, g);
+                PCV_HIP(hipStreamSynchronize(st));
+            } catch (...) {
+                if (d_stage) hipFree(d_stage);
+                free_segment(g);
+                throw;
+            }
+            hipFree(d_stage);
+            src.segs.push_back(g);
+            std::vector<float>().swap(src.pend_rows);
+            std::vector<int64_t>().swap(src.pend_ids);
+            src.pend_n = 0;
+            src.pend_ids_explicit = false;
+        }
+        for (const SynthSpec& sp : src.pend_synth) {
+            Segment g = alloc_segment(s, sp.n, false);
+            g.id0 = sp.first_row;
+            try {
+                launch_synth_fill(st, g.blk, g.nblocks, g.nrows, 0, s->D, s->D4, sp.seed, sp.first_row, sp.normalize);
+                finish_segment(s, g);
+                PCV_HIP(hipStreamSynchronize(st));
+                PCV_HIP(hipGetLastError());
+            } catch (...) {
+                free_segment(g);
+                throw;
+            }
+            src.segs.push_back(g);
+        }
+        src.pend_synth.clear();
+    }
+    // sources emptied by clear_source and never refilled disappear (rebuild_source, search.rs:67-69)
+    s->sources.erase(std::remove_if(s->sources.begin(), s->sources.end(),
+                                    [](const Source& x) { return x.segs.empty(); }),
+                     s->sources.end());
+    assign_positions(s);
+    uint32_t bits = 0;
+    PCV_HIP(hipMemcpy(&bits, s->d_max_norm_bits, 4, hipMemcpyDeviceToHost));
+    std::memcpy(&s->max_norm, &bits, 4);
+    s->dirty = false;
+}
+
+struct SelSeg {
+    const Segment* g;
+};
+
+std::vector<SelSeg> select_segments(pcv_searcher* s, const int64_t* source_ids, int n_sources) {
+    std::vector<SelSeg> out;
+    for (const auto& src : s->sources) {
+        bool sel = (n_sources <= 0 || source_ids == nullptr);
+        for (int i = 0; i < n_sources && !sel; ++i) sel = (source_ids[i] == src.id);  // search.rs:166
+        if (!sel) continue;
+        for (const auto& g : src.segs) out.push_back({&g});
+    }
+    return out;
+}
+
+void ensure_workspace(pcv_searcher* s) {
+    const size_t Q = kMfmaQueries;
+    s->d_queries.ensure(Q * s->D);
+    s->d_qf32.ensure(Q * s->Dp);
+    s->d_qraw.ensure(Q * s->Dp);
+    s->d_qbf16.ensure(Q * s->Dp);
+    s->d_margin.ensure(Q);
+    s->d_qnorm2.ensure(Q);
+    s->d_tau.ensure(Q);
+    s->d_slots.ensure(Q * kMaxK);
+    s->d_cnt.ensure(Q);
+    s->d_cand.ensure(Q * s->cand_cap);
+    s->d_cand_score.ensure(Q * s->cand_cap);
+    s->d_hits.ensure(Q * kMaxK);
+    for (auto& e : s->ev)
+        if (!e) PCV_HIP(hipEventCreate(&e));
+}
+
+// One pass: <= 64 queries over <= kMaxSeg segments.  Leaves [B][k] hits in s->d_hits.
+void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel) {
+    hipStream_t st = s->ctx->stream;
+    ensure_workspace(s);
+    PCV_HIP(hipMemcpyAsync(s->d_queries.p, queries_host, (size_t)B * s->D * sizeof(float), hipMemcpyHostToDevice, st));
+
+    for (int attempt = 0;; ++attempt) {
+        ScanParams p{};
+        uint32_t blk0 = 0;
+        int64_t rows = 0;
+        for (int i = 0; i < nseg; ++i) {
+            const Segment& g = *segs[i].g;
+            p.seg[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks, blk0, 0};
+            blk0 += g.nblocks;
+            rows += g.nrows;
+        }
+        p.nseg = nseg;
+        p.total_blocks = blk0;
+        p.D4 = s->D4;
+        p.B = B;
+        p.k = k;
+        p.metric = s->metric;
+        p.qf32 = s->d_qf32.p;
+        p.qbf16 = s->d_qbf16.p;
+        p.qraw = s->d_qraw.p;
+        p.qnorm2 = s->d_qnorm2.p;
+        p.margin = s->d_margin.p;
+        p.tau = s->d_tau.p;
+        p.slots = s->d_slots.p;
+        p.cand_cnt = s->d_cnt.p;
+        p.cand = s->d_cand.p;
+        p.cand_score = s->d_cand_score.p;
+        p.cand_cap = s->cand_cap;
+        p.seed_blocks = nseg > 0 ? std::min<uint32_t>(kSeedRows / kBlockRows, segs[0].g->nblocks) : 0;
+
+        // |s - c| bound of the screening score, relative to |q||x| (DESIGN.md §screening error)
+        const float eps_f32 = (float)(s->Dp + 16) * 1.2e-7f;
+        const float eps_rel = (kernel == PCV_KERNEL_MFMA) ? 0.0039101f + 2.0f * eps_f32 : eps_f32;
+
+        PCV_HIP(hipEventRecord(s->ev[0], st));
+        launch_prep_queries(st, s->d_queries.p, B, s->D, s->Dp, s->metric, eps_rel, s->max_norm, k, s->d_qf32.p,
+                            s->d_qbf16.p, s->d_qraw.p, s->d_qnorm2.p, s->d_margin.p, s->d_tau.p, s->d_slots.p,
+                            s->d_cnt.p);
+        launch_seed(st, p);
+        PCV_HIP(hipEventRecord(s->ev[1], st));
+        if (kernel == PCV_KERNEL_MFMA)
+            launch_scan_mfma(st, p, s->ctx->num_cus);
+        else
+            launch_scan_wave(st, p, s->ctx->num_cus);
+        PCV_HIP(hipEventRecord(s->ev[2], st));
+        launch_rescore(st, p);
+        launch_select(st, p, s->d_hits.p);
+        PCV_HIP(hipEventRecord(s->ev[3], st));
+        uint32_t cnt[kMfmaQueries];
+        PCV_HIP(hipMemcpyAsync(cnt, s->d_cnt.p, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PCV_HIP(hipStreamSynchronize(st));
+        PCV_HIP(hipGetLastError());
+
+        float ms_scan = 0, ms_total = 0;
+        hipEventElapsedTime(&ms_scan, s->ev[1], s->ev[2]);
+        hipEventElapsedTime(&ms_total, s->ev[0], s->ev[3]);
+        s->stats.scan_ms += ms_scan;
+        s->stats.total_ms += ms_total;
+        s->stats.scan_launches += 1;
+        s->stats.rows_scanned += rows;
+        s->stats.bytes_algorithmic += rows * (int64_t)s->D * 4;
+
+        uint32_t mx = 0;
+        int64_t sum = 0;
+        for (int b = 0; b < B; ++b) {
+            mx = std::max(mx, cnt[b]);
+            sum += cnt[b];
+        }
+        if (mx <= s->cand_cap) {
+            s->stats.candidates += sum;
+            return;
+        }
+        // a candidate list overflowed: nothing was lost but the stored prefix is incomplete.
+        // Grow the lists to what this pass needed and repeat it (tau restarts, so the need can
+        // only be met or shrink on data that is not adversarially ordered; bounded by the row count).
+        PCV_REQUIRE(attempt < 6, "candidate lists still overflow after %d reruns (need %u)", attempt, mx);
+        s->stats.overflow_reruns += 1;
+        uint64_t want = (uint64_t)mx + mx / 4 + 1024;
+        want = std::min<uint64_t>(want, (uint64_t)rows + 1024);
+        s->cand_cap = (uint32_t)std::max<uint64_t>(want, s->cand_cap * 2ull);
+        s->d_cand.ensure((size_t)kMfmaQueries * s->cand_cap);
+        s->d_cand_score.ensure((size_t)kMfmaQueries * s->cand_cap);
+    }
+}
+
+bool hit_better(const pcv_hit_dev& a, const pcv_hit_dev& b) {
+    if (a.score != b.score) return a.score > b.score;
+    return a.pos < b.pos;
+}
+
+int pick_kernel(const pcv_searcher* s, int B) {
+    if (s->kernel == PCV_KERNEL_WAVE || s->kernel == PCV_KERNEL_MFMA) return s->kernel;
+    return B <= kMaxWaveQueries ? PCV_KERNEL_WAVE : PCV_KERNEL_MFMA;
+}
+
+// Full search: any number of queries / segments; result [n_queries][k] hits on the host.
+void search_hits(pcv_searcher* s, const float* queries, int n_queries, const int64_t* source_ids, int n_sources,
+                 int k, std::vector<pcv_hit_dev>& out) {
+    PCV_REQUIRE(!s->dirty, "search: rows were added or cleared without pcv_searcher_finalize");
+    PCV_REQUIRE(queries != nullptr && n_queries > 0, "search: no queries");
+    PCV_REQUIRE(k > 0 && k <= kMaxK, "search: num_results %d outside [1,%d]", k, kMaxK);
+    PCV_HIP(hipSetDevice(s->ctx->device));
+    std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
+    const pcv_hit_dev none{NAN, -1, -1};
+    out.assign((size_t)n_queries * k, none);
+    s->stats = pcv_scan_stats{};
+    const int kernel = pick_kernel(s, n_queries);
+    s->stats.kernel_used = kernel;
+    if (segs.empty()) return;
+    const int qstep = (kernel == PCV_KERNEL_WAVE) ? kMaxWaveQueries : kMfmaQueries;
+    std::vector<pcv_hit_dev> tmp((size_t)qstep * k);
+    for (int q0 = 0; q0 < n_queries; q0 += qstep) {
+        const int B = std::min(qstep, n_queries - q0);
+        for (size_t g0 = 0; g0 < segs.size(); g0 += kMaxSeg) {
+            const int nseg = (int)std::min<size_t>(kMaxSeg, segs.size() - g0);
+            run_pass(s, queries + (size_t)q0 * s->D, B, segs.data() + g0, nseg, k, kernel);
+            PCV_HIP(hipMemcpy(tmp.data(), s->d_hits.p, (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost));
+            for (int b = 0; b < B; ++b) {
+                pcv_hit_dev* dst = out.data() + (size_t)(q0 + b) * k;
+                if (g0 == 0) {
+                    std::copy(tmp.begin() + (size_t)b * k, tmp.begin() + (size_t)(b + 1) * k, dst);
+                } else {  // more than kMaxSeg segments: merge this group's list into the running one
+                    std::vector<pcv_hit_dev> m;
+                    for (int j = 0; j < k; ++j) {
+                        if (dst[j].pos >= 0) m.push_back(dst[j]);
+                        if (tmp[(size_t)b * k + j].pos >= 0) m.push_back(tmp[(size_t)b * k + j]);
+                    }
+                    std::sort(m.begin(), m.end(), hit_better);
+                    for (int j = 0; j < k; ++j) dst[j] = j < (int)m.size() ? m[j] : none;
+                }
+            }
+        }
+    }
+}
+
+// hits -> the reference's result convention
+void hits_to_outputs(int metric, int D, const pcv_hit_dev* hits, int n_queries, int k, int64_t* out_ids,
+                     float* out_scores, int* out_counts) {
+    for (int q = 0; q < n_queries; ++q) {
+        int cnt = 0;
+        for (int j = 0; j < k; ++j) {
+            const pcv_hit_dev& h = hits[(size_t)q * k + j];
+            const bool ok = h.pos >= 0;
+            if (ok) ++cnt;
+            if (out_ids) out_ids[(size_t)q * k + j] = ok ? h.id : -1;
+            if (out_scores) {
+                float v = NAN;
+                if (ok) {
+                    if (metric == PCV_METRIC_DOT) {
+                        const double d = 1.0 - h.score / (double)D;  // search.rs:275
+                        v = (float)(d > 0.0 ? d : 0.0);              // search.rs:277
+                    } else {
+                        v = (float)h.score;
+                    }
+                }
+                out_scores[(size_t)q * k + j] = v;
+            }
+        }
+        if (out_counts) out_counts[q] = cnt;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+pcv_status pcv_searcher_create(pcv_ctx* ctx, int dim, int metric, pcv_searcher** out) {
+    return guarded([&] {
+        PCV_REQUIRE(ctx != nullptr && out != nullptr, "searcher_create: NULL argument");
+        *out = nullptr;
+        PCV_REQUIRE(dim > 0 && dim <= 8192, "searcher_create: dim %d outside [1,8192]", dim);
+        PCV_REQUIRE(metric == PCV_METRIC_COSINE || metric == PCV_METRIC_DOT, "searcher_create: unknown metric %d",
+                    metric);
+        PCV_HIP(hipSetDevice(ctx->device));
+        auto* s = new pcv_searcher();
+        s->ctx = ctx;
+        s->D = dim;
+        s->Dp = (dim + 63) / 64 * 64;
+        s->D4 = s->Dp / 4;
+        s->metric = metric;
+        hipError_t e = hipMalloc((void**)&s->d_max_norm_bits, 4);
+        if (e != hipSuccess) {
+            delete s;
+            PCV_FAIL(PCV_ERR_DEVICE, "searcher_create: hipMalloc failed: %s", hipGetErrorString(e));
+        }
+        hipMemset(s->d_max_norm_bits, 0, 4);
+        *out = s;
+    });
+}
+
+pcv_status pcv_searcher_destroy(pcv_searcher* s) {
+    return guarded([&] {
+        if (!s) return;
+        hipSetDevice(s->ctx->device);
+        hipStreamSynchronize(s->ctx->stream);
+        for (auto& src : s->sources)
+            for (auto& g : src.segs) free_segment(g);
+        s->d_queries.release();
+        s->d_qf32.release();
+        s->d_qraw.release();
+        s->d_margin.release();
+        s->d_qbf16.release();
+        s->d_qnorm2.release();
+        s->d_cand_score.release();
+        s->d_tau.release();
+        s->d_slots.release();
+        s->d_cnt.release();
+        s->d_cand.release();
+        s->d_hits.release();
+        if (s->d_max_norm_bits) hipFree(s->d_max_norm_bits);
+        for (auto& e : s->ev)
+            if (e) hipEventDestroy(e);
+        delete s;
+    });
+}
+
+pcv_status pcv_searcher_add_rows(pcv_searcher* s, int64_t source_id, const int64_t* ids, const float* rows,
+                                 int64_t n) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "add_rows: searcher is NULL");
+        PCV_REQUIRE(n >= 0 && (rows != nullptr || n == 0), "add_rows: bad rows/n");
+        std::lock_guard<std::mutex> lk(s->mu);
+        Source& src = s->get_or_add_source(source_id);
+        if (n == 0) return;
+        if (ids && !src.pend_ids_explicit) {
+            // earlier implicit ids of this pending batch become explicit
+            src.pend_ids_explicit = true;
+        }
+        src.pend_rows.insert(src.pend_rows.end(), rows, rows + (size_t)n * s->D);
+        for (int64_t i = 0; i < n; ++i) src.pend_ids.push_back(ids ? ids[i] : src.next_implicit_id + i);
+        src.next_implicit_id += n;
+        src.pend_n += n;
+        s->dirty = true;
+    });
+}
+
+pcv_status pcv_searcher_add_blobs(pcv_searcher* s, int64_t source_id, const int64_t* ids, const uint8_t* blobs,
+                                  int64_t n) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "add_blobs: searcher is NULL");
+        PCV_REQUIRE(n >= 0 && (blobs != nullptr || n == 0), "add_blobs: bad blobs/n");
+        std::vector<float> rows((size_t)n * s->D);
+        for (size_t i = 0; i < rows.size(); ++i) {  // deserialize_embedding, search.rs:281-286
+            const uint8_t* b = blobs + 4 * i;
+            const uint32_t u = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+            std::memcpy(&rows[i], &u, 4);
+        }
+        pcv_status st = pcv_searcher_add_rows(s, source_id, ids, rows.data(), n);
+        if (st != PCV_OK) throw Error{st};
+    });
+}
+
+pcv_status pcv_searcher_add_synthetic(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
+                                      int64_t first_row, int normalize) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "add_synthetic: searcher is NULL");
+        PCV_REQUIRE(n >= 0, "add_synthetic: negative row count");
+        PCV_REQUIRE(s->D % 4 == 0, "add_synthetic: dim %d is not a multiple of 4", s->D);
+        std::lock_guard<std::mutex> lk(s->mu);
+        Source& src = s->get_or_add_source(source_id);
+        // one segment per <= 2^31 rows
+        const int64_t kMaxRows = (int64_t)1 << 31;
+        for (int64_t r0 = 0; r0 < n; r0 += kMaxRows)
+            src.pend_synth.push_back({std::min(kMaxRows, n - r0), seed, first_row + r0, normalize});
+        if (n > 0) s->dirty = true;
+    });
+}
+
+pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "clear_source: searcher is NULL");
+        std::lock_guard<std::mutex> lk(s->mu);
+        Source* src = s->find_source(source_id);
+        if (!src) return;
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+        for (auto& g : src->segs) free_segment(g);
+        src->segs.clear();
+        std::vector<float>().swap(src->pend_rows);
+        std::vector<int64_t>().swap(src->pend_ids);
+        src->pend_synth.clear();
+        src->pend_n = 0;
+        src->pend_ids_explicit = false;
+        src->next_implicit_id = 0;
+        s->dirty = true;
+    });
+}
+
+pcv_status pcv_searcher_finalize(pcv_searcher* s) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "finalize: searcher is NULL");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        do_finalize(s);
+    });
+}
+
+pcv_status pcv_searcher_num_rows(pcv_searcher* s, int64_t* out_rows) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && out_rows != nullptr, "num_rows: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        int64_t n = 0;
+        for (auto& src : s->sources)
+            for (auto& g : src.segs) n += g.nrows;
+        *out_rows = n;
+    });
+}
+
+pcv_status pcv_searcher_num_sources(pcv_searcher* s, int* out_n) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && out_n != nullptr, "num_sources: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        *out_n = (int)s->sources.size();
+    });
+}
+
+pcv_status pcv_searcher_source_ids(pcv_searcher* s, int64_t* out_ids, int cap) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && out_ids != nullptr, "source_ids: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(cap >= (int)s->sources.size(), "source_ids: capacity %d < %zu sources", cap, s->sources.size());
+        for (size_t i = 0; i < s->sources.size(); ++i) out_ids[i] = s->sources[i].id;
+    });
+}
+
+pcv_status pcv_searcher_get_rows(pcv_searcher* s, const int64_t* positions, int64_t n, float* out_rows,
+                                 int64_t* out_ids) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && positions != nullptr && out_rows != nullptr && n >= 0, "get_rows: bad argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->dirty, "get_rows: pending rows; call pcv_searcher_finalize first");
+        if (n == 0) return;
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        hipStream_t st = s->ctx->stream;
+        std::vector<SegDesc> segs;
+        for (auto& src : s->sources)
+            for (auto& g : src.segs)
+                segs.push_back(SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks, 0, 0});
+        DevBuf<SegDesc> d_segs;
+        DevBuf<int64_t> d_pos, d_ids;
+        DevBuf<float> d_rows;
+        try {
+            d_segs.ensure(segs.size() + 1);
+            d_pos.ensure(n);
+            d_ids.ensure(n);
+            d_rows.ensure((size_t)n * s->D);
+            PCV_HIP(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+            PCV_HIP(hipMemcpyAsync(d_pos.p, positions, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            launch_gather_rows(st, d_segs.p, (int)segs.size(), d_pos.p, n, s->D, s->D4, d_rows.p, d_ids.p);
+            PCV_HIP(hipMemcpyAsync(out_rows, d_rows.p, (size_t)n * s->D * sizeof(float), hipMemcpyDeviceToHost, st));
+            if (out_ids)
+                PCV_HIP(hipMemcpyAsync(out_ids, d_ids.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+            PCV_HIP(hipStreamSynchronize(st));
+        } catch (...) {
+            d_segs.release();
+            d_pos.release();
+            d_ids.release();
+            d_rows.release();
+            throw;
+        }
+        d_segs.release();
+        d_pos.release();
+        d_ids.release();
+        d_rows.release();
+    });
+}
+
+pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "set_kernel: searcher is NULL");
+        PCV_REQUIRE(kernel >= PCV_KERNEL_AUTO && kernel <= PCV_KERNEL_MFMA, "set_kernel: unknown kernel %d", kernel);
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->kernel = kernel;
+    });
+}
+
+pcv_status pcv_searcher_set_shard_offset(pcv_searcher* s, int64_t first_global_pos) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "set_shard_offset: searcher is NULL");
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->shard_offset = first_global_pos;
+        assign_positions(s);
+    });
+}
+
+pcv_status pcv_searcher_search(pcv_searcher* s, const float* queries, int n_queries, const int64_t* source_ids,
+                               int n_sources, int k, int64_t* out_ids, float* out_scores, int* out_counts) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "search: searcher is NULL");
+        std::lock_guard<std::mutex> lk(s->mu);
+        std::vector<pcv_hit_dev> hits;
+        search_hits(s, queries, n_queries, source_ids, n_sources, k, hits);
+        hits_to_outputs(s->metric, s->D, hits.data(), n_queries, k, out_ids, out_scores, out_counts);
+    });
+}
+
+pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int n_queries,
+                                      const int64_t* source_ids, int n_sources, int k, void* d_out, int async) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && d_out != nullptr, "search_device: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->dirty, "search_device: rows were added or cleared without pcv_searcher_finalize");
+        PCV_REQUIRE(queries != nullptr && n_queries > 0, "search_device: no queries");
+        PCV_REQUIRE(k > 0 && k <= kMaxK, "search_device: num_results %d outside [1,%d]", k, kMaxK);
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
+        const int kernel = pick_kernel(s, n_queries);
+        const int qstep = (kernel == PCV_KERNEL_WAVE) ? kMaxWaveQueries : kMfmaQueries;
+        s->stats = pcv_scan_stats{};
+        s->stats.kernel_used = kernel;
+        if (segs.size() <= (size_t)kMaxSeg && !segs.empty()) {
+            // fast path: results stay on the device
+            for (int q0 = 0; q0 < n_queries; q0 += qstep) {
+                const int B = std::min(qstep, n_queries - q0);
+                run_pass(s, queries + (size_t)q0 * s->D, B, segs.data(), (int)segs.size(), k, kernel);
+                PCV_HIP(hipMemcpyAsync((pcv_hit_dev*)d_out + (size_t)q0 * k, s->d_hits.p,
+                                       (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToDevice, s->ctx->stream));
+            }
+        } else {
+            std::vector<pcv_hit_dev> hits;
+            search_hits(s, queries, n_queries, source_ids, n_sources, k, hits);
+            PCV_HIP(hipMemcpyAsync(d_out, hits.data(), hits.size() * sizeof(pcv_hit_dev), hipMemcpyHostToDevice,
+                                   s->ctx->stream));
+            async = 0;  // `hits` dies with this scope
+        }
+        if (!async) PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+    });
+}
+
+pcv_status pcv_merge_topk(pcv_ctx* ctx, int metric, int dim, const void* d_lists, int n_shards, int n_queries,
+                          int k, int64_t* out_ids, float* out_scores, int* out_counts) {
+    return guarded([&] {
+        PCV_REQUIRE(ctx != nullptr && d_lists != nullptr, "merge_topk: NULL argument");
+        PCV_REQUIRE(n_shards > 0 && n_queries > 0 && k > 0 && k <= kMaxK, "merge_topk: bad shape");
+        PCV_HIP(hipSetDevice(ctx->device));
+        DevBuf<pcv_hit_dev> d_out;
+        std::vector<pcv_hit_dev> hits((size_t)n_queries * k);
+        try {
+            d_out.ensure(hits.size());
+            launch_merge(ctx->stream, (const pcv_hit_dev*)d_lists, n_shards, n_queries, k, d_out.p);
+            PCV_HIP(hipMemcpyAsync(hits.data(), d_out.p, hits.size() * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+            PCV_HIP(hipStreamSynchronize(ctx->stream));
+            PCV_HIP(hipGetLastError());
+        } catch (...) {
+            d_out.release();
+            throw;
+        }
+        d_out.release();
+        hits_to_outputs(metric, dim, hits.data(), n_queries, k, out_ids, out_scores, out_counts);
+    });
+}
+
+static pcv_status similarity(pcv_ctx* ctx, const float* a, int B, const float* m, int64_t N, int dim, float* out,
+                             int cosine) {
+    return guarded([&] {
+        PCV_REQUIRE(ctx != nullptr && a != nullptr && m != nullptr && out != nullptr, "similarity: NULL argument");
+        PCV_REQUIRE(B > 0 && N > 0 && dim > 0, "similarity: empty input");
+        PCV_HIP(hipSetDevice(ctx->device));
+        DevBuf<float> d_a, d_m, d_o;
+        try {
+            d_a.ensure((size_t)B * dim);
+            d_m.ensure((size_t)N * dim);
+            d_o.ensure((size_t)B * N);
+            PCV_HIP(hipMemcpyAsync(d_a.p, a, (size_t)B * dim * 4, hipMemcpyHostToDevice, ctx->stream));
+            PCV_HIP(hipMemcpyAsync(d_m.p, m, (size_t)N * dim * 4, hipMemcpyHostToDevice, ctx->stream));
+            launch_similarity_matrix(ctx->stream, d_a.p, B, d_m.p, N, dim, cosine, d_o.p);
+            PCV_HIP(hipMemcpyAsync(out, d_o.p, (size_t)B * N * 4, hipMemcpyDeviceToHost, ctx->stream));
+            PCV_HIP(hipStreamSynchronize(ctx->stream));
+            PCV_HIP(hipGetLastError());
+        } catch (...) {
+            d_a.release();
+            d_m.release();
+            d_o.release();
+            throw;
+        }
+        d_a.release();
+        d_m.release();
+        d_o.release();
+    });
+}
+
+pcv_status pcv_dot_product(pcv_ctx* ctx, const float* a, int B, const float* m, int64_t N, int dim, float* out) {
+    return similarity(ctx, a, B, m, N, dim, out, 0);
+}
+pcv_status pcv_cosine_similarity(pcv_ctx* ctx, const float* a, int B, const float* m, int64_t N, int dim,
+                                 float* out) {
+    return similarity(ctx, a, B, m, N, dim, out, 1);
+}
+
+pcv_status pcv_searcher_last_stats(pcv_searcher* s, pcv_scan_stats* out) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && out != nullptr, "last_stats: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        *out = s->stats;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,264 @@
+"""Host-side mirror of perceive-core's search module (crates/perceive-core/search.rs) over the
+C ABI.  Same names and argument meaning as the reference; the SQLite `Database` argument of
+`Searcher::build` / `rebuild_source` is replaced by the row stream its SQL produces
+(search.rs:87-113: `(items.id, source_id, embedding blob)`), because storage is out of scope.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from .context import Context
+
+_METRICS = {"cosine": _ffi.METRIC_COSINE, "dot": _ffi.METRIC_DOT}
+_KERNELS = {"auto": _ffi.KERNEL_AUTO, "wave": _ffi.KERNEL_WAVE, "mfma": _ffi.KERNEL_MFMA}
+
+
+@dataclass(frozen=True)
+class SearchItem:
+    """search.rs:18-22"""
+
+    id: int
+    score: float
+
+
+def serialize_embedding(embedding):
+    """search.rs:288-294 — little-endian f32 bytes, no header."""
+    v = np.ascontiguousarray(embedding, dtype=np.float32)
+    out = np.empty(v.size * 4, dtype=np.uint8)
+    _ffi.check(_ffi.lib().pcv_serialize_embedding(_ffi.f32p(v), v.size, _ffi.u8p(out), out.size))
+    return out.tobytes()
+
+
+def deserialize_embedding(value):
+    """search.rs:281-286"""
+    b = np.frombuffer(bytes(value), dtype=np.uint8)
+    out = np.empty(len(b) // 4, dtype=np.float32)
+    n = C.c_size_t()
+    _ffi.check(_ffi.lib().pcv_deserialize_embedding(_ffi.u8p(b), b.size, _ffi.f32p(out), out.size, C.byref(n)))
+    return out[: n.value]
+
+
+class Searcher:
+    """search.rs:29-35.  One exact, GPU-resident index per process; sources are kept apart so
+    `search_vector(sources=...)` filters like search.rs:166 and `rebuild_source` replaces one.
+
+    metric="dot"    -> the reference Searcher's convention: score = max(0, 1 - dot/len)
+                       (search.rs:269-278), results ascending by score (search.rs:179).
+    metric="cosine" -> lib.rs:67-77 cosine, results best (largest) first.
+    """
+
+    def __init__(self, ctx: Context, dim: int, metric: str = "cosine"):
+        self.ctx = ctx
+        self.dim = int(dim)
+        self.metric = metric
+        self._h = C.c_void_p()
+        _ffi.check(_ffi.lib().pcv_searcher_create(ctx.handle, self.dim, _METRICS[metric], C.byref(self._h)))
+        # search.rs:31-34: ids hidden after the index was built.  Kept, and (like the reference's
+        # search_vector) not consulted when searching.
+        self.hidden = set()
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def build(cls, ctx, rows, dim, metric="cosine"):
+        """Searcher::build (search.rs:38-56).  `rows` yields (item_id, source_id, embedding) with the
+        embedding as a blob (bytes) or a float array — what the query at search.rs:87-113 returns."""
+        s = cls(ctx, dim, metric)
+        s._insert(rows)
+        s.finalize()
+        return s
+
+    def rebuild_source(self, rows, source_id):
+        """Searcher::rebuild_source (search.rs:58-79): rows of other sources are ignored
+        (search.rs:106-109); an empty replacement leaves the source absent."""
+        _ffi.check(_ffi.lib().pcv_searcher_clear_source(self._handle, int(source_id)))
+        self._insert((r for r in rows if int(r[1]) == int(source_id)))
+        self.finalize()
+
+    def _insert(self, rows):
+        by_source = {}
+        for item_id, source_id, emb in rows:
+            v = deserialize_embedding(emb) if isinstance(emb, (bytes, bytearray, memoryview)) else np.asarray(
+                emb, dtype=np.float32
+            )
+            if v.shape != (self.dim,):
+                raise ValueError(f"embedding of item {item_id} has shape {v.shape}, index is {self.dim}-d")
+            ids, vecs = by_source.setdefault(int(source_id), ([], []))
+            ids.append(int(item_id))
+            vecs.append(v)
+        for source_id, (ids, vecs) in by_source.items():
+            self.add_rows(source_id, np.stack(vecs), np.asarray(ids, dtype=np.int64))
+
+    def add_rows(self, source_id, rows, ids=None):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n, {self.dim}]")
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+            if ids.shape != (rows.shape[0],):
+                raise ValueError("ids must be [n]")
+            idp = _ffi.i64p(ids)
+        _ffi.check(_ffi.lib().pcv_searcher_add_rows(self._handle, int(source_id), idp, _ffi.f32p(rows), rows.shape[0]))
+
+    def add_blobs(self, source_id, blobs: bytes, n, ids=None):
+        b = np.frombuffer(blobs, dtype=np.uint8)
+        if b.size != n * self.dim * 4:
+            raise ValueError("blob bytes do not match n*dim*4")
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+            idp = _ffi.i64p(ids)
+        _ffi.check(_ffi.lib().pcv_searcher_add_blobs(self._handle, int(source_id), idp, _ffi.u8p(b), int(n)))
+
+    def add_synthetic(self, source_id, n, seed, first_row=0, normalize=False):
+        _ffi.check(
+            _ffi.lib().pcv_searcher_add_synthetic(
+                self._handle, int(source_id), int(n), int(seed), int(first_row), 1 if normalize else 0
+            )
+        )
+
+    def finalize(self):
+        _ffi.check(_ffi.lib().pcv_searcher_finalize(self._handle))
+
+    # ---- queries ------------------------------------------------------------------------------
+    def search_vector(self, sources, num_results, vector):
+        """Searcher::search_vector (search.rs:157-182)."""
+        ids, scores, counts = self.search_vectors(sources, num_results, np.asarray(vector, dtype=np.float32)[None, :])
+        return [SearchItem(int(ids[0, j]), float(scores[0, j])) for j in range(int(counts[0]))]
+
+    def search_vectors(self, sources, num_results, vectors):
+        """Batched search_vector: vectors [B, dim] -> (ids [B,k] int64, scores [B,k] f32, counts [B])."""
+        q = np.ascontiguousarray(vectors, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"vectors must be [B, {self.dim}]")
+        B, k = q.shape[0], int(num_results)
+        ids = np.full((B, k), -1, dtype=np.int64)
+        scores = np.full((B, k), np.nan, dtype=np.float32)
+        counts = np.zeros(B, dtype=np.int32)
+        src, nsrc = None, 0
+        if sources is not None:
+            sa = np.ascontiguousarray(list(sources), dtype=np.int64)
+            if sa.size == 0:
+                return ids, scores, counts  # search.rs:166 with an empty filter matches nothing
+            src, nsrc = _ffi.i64p(sa), sa.size
+        _ffi.check(
+            _ffi.lib().pcv_searcher_search(
+                self._handle, _ffi.f32p(q), B, src, nsrc, k, _ffi.i64p(ids), _ffi.f32p(scores),
+                counts.ctypes.data_as(C.POINTER(C.c_int)),
+            )
+        )
+        return ids, scores, counts
+
+    def search(self, model, sources, num_results, query):
+        """Searcher::search (search.rs:184-193)."""
+        return self.search_vector(sources, num_results, encode_query(model, query))
+
+    def search_device(self, sources, num_results, vectors, d_out, async_=False):
+        """Per-shard exact top-k left on the device: d_out = device pointer to [B][k] pcv_hit."""
+        q = np.ascontiguousarray(vectors, dtype=np.float32)
+        src, nsrc = None, 0
+        if sources is not None:
+            sa = np.ascontiguousarray(list(sources), dtype=np.int64)
+            src, nsrc = _ffi.i64p(sa), sa.size
+        _ffi.check(
+            _ffi.lib().pcv_searcher_search_device(
+                self._handle, _ffi.f32p(q), q.shape[0], src, nsrc, int(num_results), C.c_void_p(d_out),
+                1 if async_ else 0,
+            )
+        )
+
+    # ---- introspection ------------------------------------------------------------------------
+    def set_kernel(self, kernel="auto"):
+        _ffi.check(_ffi.lib().pcv_searcher_set_kernel(self._handle, _KERNELS[kernel]))
+
+    def set_shard_offset(self, first_global_pos):
+        _ffi.check(_ffi.lib().pcv_searcher_set_shard_offset(self._handle, int(first_global_pos)))
+
+    @property
+    def num_rows(self):
+        n = C.c_int64()
+        _ffi.check(_ffi.lib().pcv_searcher_num_rows(self._handle, C.byref(n)))
+        return n.value
+
+    @property
+    def source_ids(self):
+        n = C.c_int()
+        _ffi.check(_ffi.lib().pcv_searcher_num_sources(self._handle, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int64)
+        _ffi.check(_ffi.lib().pcv_searcher_source_ids(self._handle, _ffi.i64p(out), out.size))
+        return [int(x) for x in out[: n.value]]
+
+    def get_rows(self, positions):
+        pos = np.ascontiguousarray(positions, dtype=np.int64)
+        rows = np.empty((pos.size, self.dim), dtype=np.float32)
+        ids = np.empty(pos.size, dtype=np.int64)
+        _ffi.check(_ffi.lib().pcv_searcher_get_rows(self._handle, _ffi.i64p(pos), pos.size, _ffi.f32p(rows), _ffi.i64p(ids)))
+        return rows, ids
+
+    def last_stats(self):
+        st = _ffi.ScanStats()
+        _ffi.check(_ffi.lib().pcv_searcher_last_stats(self._handle, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in _ffi.ScanStats._fields_ if f != "reserved"}
+
+    @property
+    def _handle(self):
+        if not self._h:
+            raise RuntimeError("searcher already closed")
+        return self._h
+
+    def close(self):
+        if self._h:
+            _ffi.lib().pcv_searcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def encode_query(model, query):
+    """search.rs:262-264"""
+    return np.asarray(model.encode([query]))[0]
+
+
+def merge_topk(ctx, metric, dim, d_lists, n_shards, n_queries, k):
+    """Cross-shard merge of all-gathered per-shard lists (device pointer) -> (ids, scores, counts)."""
+    ids = np.full((n_queries, k), -1, dtype=np.int64)
+    scores = np.full((n_queries, k), np.nan, dtype=np.float32)
+    counts = np.zeros(n_queries, dtype=np.int32)
+    _ffi.check(
+        _ffi.lib().pcv_merge_topk(
+            ctx.handle, _METRICS[metric], int(dim), C.c_void_p(d_lists), int(n_shards), int(n_queries), int(k),
+            _ffi.i64p(ids), _ffi.f32p(scores), counts.ctypes.data_as(C.POINTER(C.c_int)),
+        )
+    )
+    return ids, scores, counts
+
+
+# ---- lib.rs:63-77 -----------------------------------------------------------------------------
+def _sim(ctx, a, m, cosine):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    out = np.empty((a.shape[0], m.shape[0]), dtype=np.float32)
+    fn = _ffi.lib().pcv_cosine_similarity if cosine else _ffi.lib().pcv_dot_product
+    _ffi.check(fn(ctx.handle, _ffi.f32p(a), a.shape[0], _ffi.f32p(m), m.shape[0], a.shape[1], _ffi.f32p(out)))
+    return out
+
+
+def dot_product(ctx, set1, set2):
+    """lib.rs:63-65: set1.matmul(set2.T) -> [len(set1), len(set2)]"""
+    return _sim(ctx, set1, set2, False)
+
+
+def cosine_similarity_single_query(ctx, query, matches):
+    """lib.rs:67-71: query [D], matches [N, D] -> [N]"""
+    return _sim(ctx, np.asarray(query, dtype=np.float32)[None, :], matches, True)[0]
+
+
+def cosine_similarity_multi_query(ctx, set1, set2):
+    """lib.rs:73-77"""
+    return _sim(ctx, set1, set2, True)

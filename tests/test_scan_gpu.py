@@ -1,0 +1,313 @@
+"""GPU parity tests of the similarity scan, through the C ABI (perceive_amd -> libperceive_hip.so),
+against the CPU oracle and the committed PyTorch-CPU vectors.
+
+Bars (BASELINE.json north_star): top-k doc indices bit-exact, cosine scores within 1e-4 (f32).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import perceive_amd as pa
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: "cosine scores within 1e-4 f32"
+
+
+def build(ctx, corpus, metric="cosine", ids=None, source=1, kernel="auto"):
+    s = pa.Searcher(ctx, corpus.shape[1], metric)
+    s.add_rows(source, corpus, ids)
+    s.finalize()
+    s.set_kernel(kernel)
+    return s
+
+
+@pytest.fixture(scope="module")
+def g1000(golden_dir):
+    return np.load(os.path.join(golden_dir, "scan_n1000_d384.npz"))
+
+
+@pytest.fixture(scope="module")
+def g77(golden_dir):
+    return np.load(os.path.join(golden_dir, "scan_n77_d100.npz"))
+
+
+@pytest.mark.parametrize("kernel,B", [("auto", 1), ("auto", 3), ("auto", 64), ("wave", 64), ("mfma", 1), ("mfma", 33)])
+def test_golden_1000(ctx, oracle, g1000, kernel, B):
+    k = int(g1000["k"])
+    s = build(ctx, g1000["corpus"], kernel=kernel)
+    q = g1000["queries"][:B]
+    ids, scores, counts = s.search_vectors(None, k, q)
+    assert (counts == k).all()
+    # indices: bit-exact against the torch-f64 ranking stored in the fixture and the C oracle
+    np.testing.assert_array_equal(ids, g1000["topk_f64"][:B])
+    opos, osc, _ = oracle.topk(q, g1000["corpus"], k)
+    np.testing.assert_array_equal(ids, opos)
+    # scores: within 1e-4 of the reference-shaped f32 torch result (and ~1e-7 of the f64 value)
+    ref32 = np.take_along_axis(g1000["cos_multi_f32"][:B], ids, 1)
+    assert np.abs(scores - ref32).max() < TOL
+    np.testing.assert_allclose(scores, osc.astype(np.float32), rtol=0, atol=1e-7)
+    st = s.last_stats()
+    assert st["kernel_used"] == (2 if (kernel == "mfma" or (kernel == "auto" and B > 4)) else 1)
+    assert st["rows_scanned"] >= 1000 and st["overflow_reruns"] == 0
+    s.close()
+
+
+def test_golden_odd_shape(ctx, oracle, g77):
+    # D=100 (padded to 128 in HBM), N=77 (3 blocks, last one ragged), 3 queries, both kernels
+    k = int(g77["k"])
+    for kernel in ("wave", "mfma"):
+        s = build(ctx, g77["corpus"], kernel=kernel)
+        ids, scores, counts = s.search_vectors(None, k, g77["queries"])
+        np.testing.assert_array_equal(ids, g77["topk_f64"])
+        ref = np.take_along_axis(g77["cos_multi_f32"], ids, 1)
+        assert np.abs(scores - ref).max() < TOL
+        s.close()
+
+
+def test_ties_zero_rows_and_k_larger_than_valid(ctx, oracle, g1000):
+    corpus = g1000["corpus"]
+    s = build(ctx, corpus)
+    # query 5: rows 123 / 777 (exact duplicate) / 778 (3x copy) lead; duplicate resolves to lower position
+    ids, scores, counts = s.search_vectors(None, 3, g1000["queries"][5:6])
+    opos, _, _ = oracle.topk(g1000["queries"][5:6], corpus, 3)
+    np.testing.assert_array_equal(ids, opos)
+    assert list(ids[0]).index(123) < list(ids[0]).index(777)
+    # zero row 500 is never returned, even when k covers the whole corpus (k capped at 128 per call)
+    ids, scores, counts = s.search_vectors(None, 128, g1000["queries"][:2])
+    assert (counts == 128).all() and 500 not in ids
+    opos, _, _ = oracle.topk(g1000["queries"][:2], corpus, 128)
+    np.testing.assert_array_equal(ids, opos)
+    s.close()
+    # fewer valid rows than k
+    m = np.zeros((5, 8), np.float32)
+    m[1, 0] = 1.0
+    m[3, 1] = 2.0
+    s = build(ctx, m)
+    ids, scores, counts = s.search_vectors(None, 4, np.array([[1, 1, 0, 0, 0, 0, 0, 0]], np.float32))
+    assert counts[0] == 2 and list(ids[0]) == [1, 3, -1, -1]
+    np.testing.assert_allclose(scores[0][:2], [2**-0.5, 2**-0.5], atol=1e-7)
+    assert np.isnan(scores[0][2:]).all()
+    # zero query: cosine undefined for every row -> nothing returned (reference: NaN then panic)
+    ids, scores, counts = s.search_vectors(None, 2, np.zeros((1, 8), np.float32))
+    assert counts[0] == 0
+    s.close()
+
+
+def test_nan_and_inf_rows_are_skipped(ctx, oracle):
+    rng = np.random.default_rng(3)
+    m = rng.standard_normal((300, 64)).astype(np.float32)
+    m[10, 3] = np.nan
+    m[20, 5] = np.inf
+    m[30] = 1e30  # huge but finite: |x|^2 overflows f32, fine in f64
+    q = rng.standard_normal((6, 64)).astype(np.float32)
+    for kernel in ("wave", "mfma"):
+        s = build(ctx, m, kernel=kernel)
+        ids, scores, counts = s.search_vectors(None, 7, q)
+        opos, osc, ocnt = oracle.topk(q, m, 7)
+        np.testing.assert_array_equal(ids, opos)
+        np.testing.assert_allclose(scores, osc.astype(np.float32), atol=1e-7)
+        assert 10 not in ids and 20 not in ids
+        s.close()
+
+
+def test_dot_metric_matches_search_vector(ctx, oracle):
+    # the reference Searcher's convention: distance max(0, 1 - dot/len), ascending (search.rs:157-182,266-279)
+    rng = np.random.default_rng(11)
+    m = rng.standard_normal((5000, 384)).astype(np.float32) * rng.uniform(0.2, 3.0, (5000, 1)).astype(np.float32)
+    ids = rng.permutation(100000)[:5000].astype(np.int64)
+    src = np.where(np.arange(5000) < 3000, 7, 9)
+    q = rng.standard_normal((5, 384)).astype(np.float32)
+    for kernel in ("wave", "mfma"):
+        s = pa.Searcher(ctx, 384, "dot")
+        s.add_rows(7, m[src == 7], ids[src == 7])
+        s.add_rows(9, m[src == 9], ids[src == 9])
+        s.finalize()
+        s.set_kernel(kernel)
+        assert s.source_ids == [7, 9] and s.num_rows == 5000
+        for sources in ([7], [9], [7, 9], None):
+            got_ids, got_d, cnt = s.search_vectors(sources, 20, q)
+            for b in range(q.shape[0]):
+                oi, od = oracle.search_vector(q[b], m, ids, src, sources if sources else [], 20)
+                np.testing.assert_array_equal(got_ids[b], oi)
+                np.testing.assert_allclose(got_d[b], od, atol=1e-6)
+                assert (np.diff(got_d[b]) >= 0).all()
+        assert s.search_vectors([], 5, q)[2].sum() == 0  # empty filter matches nothing (search.rs:166)
+        assert s.search_vectors([12345], 5, q)[2].sum() == 0
+        # the single-vector API returns SearchItems like search.rs:171-174
+        items = s.search_vector([9], 3, q[0])
+        oi, od = oracle.search_vector(q[0], m, ids, src, [9], 3)
+        assert [it.id for it in items] == list(oi)
+        s.close()
+    # clamp at distance 0 for dot >= len (search.rs:277): order still follows the dot product
+    m2 = np.eye(8, dtype=np.float32) * np.arange(1, 9, dtype=np.float32)[:, None] * 10
+    s = build(ctx, m2, metric="dot")
+    q2 = np.ones((1, 8), np.float32)
+    got_ids, got_d, _ = s.search_vectors(None, 8, q2)
+    assert list(got_ids[0]) == [7, 6, 5, 4, 3, 2, 1, 0] and (got_d[0] == 0).all()
+    s.close()
+
+
+def test_build_from_row_stream_and_rebuild_source(ctx, oracle):
+    rng = np.random.default_rng(5)
+    m = rng.standard_normal((600, 384)).astype(np.float32)
+    item_ids = np.arange(600) * 3 + 1
+    src = np.where(np.arange(600) % 3 == 0, 1, 2)
+    # rows as Searcher::build reads them: (items.id, source_id, embedding BLOB) search.rs:87-113
+    rows = [(int(item_ids[i]), int(src[i]), pa.serialize_embedding(m[i])) for i in range(600)]
+    s = pa.Searcher.build(ctx, rows, 384, metric="dot")
+    q = rng.standard_normal(384).astype(np.float32)
+    order = np.concatenate([np.nonzero(src == 1)[0], np.nonzero(src == 2)[0]])  # sources kept apart
+    items = s.search_vector([1, 2], 10, q)
+    oi, od = oracle.search_vector(q, m[order], item_ids[order], src[order], [1, 2], 10)
+    assert [it.id for it in items] == list(oi)
+    np.testing.assert_allclose([it.score for it in items], od, atol=1e-6)
+    # rebuild_source (search.rs:58-79): source 2 replaced by new rows, source 1 untouched
+    m_new = rng.standard_normal((50, 384)).astype(np.float32)
+    new_rows = [(9000 + i, 2, m_new[i]) for i in range(50)] + [(777777, 1, m_new[0])]  # other sources ignored
+    s.rebuild_source(new_rows, 2)
+    assert s.num_rows == 200 + 50 and s.source_ids == [1, 2]
+    allm = np.concatenate([m[src == 1], m_new])
+    allids = np.concatenate([item_ids[src == 1], 9000 + np.arange(50)])
+    allsrc = np.concatenate([np.full(200, 1), np.full(50, 2)])
+    for sources in ([2], [1], [1, 2]):
+        items = s.search_vector(sources, 10, q)
+        oi, od = oracle.search_vector(q, allm, allids, allsrc, sources, 10)
+        assert [it.id for it in items] == list(oi)
+    # rebuilding with no rows leaves the source absent (search.rs:67-69)
+    s.rebuild_source([], 2)
+    assert s.source_ids == [1] and s.num_rows == 200
+    s.hidden.add(1)  # pub field kept (search.rs:34); like the reference's search_vector it does not filter
+    assert s.search_vector([1], 1, m[0])[0].id == 1  # row 0 (item id 1, source 1) still found
+    s.close()
+
+
+def test_synthetic_rows_bit_identical_to_oracle(ctx, oracle):
+    for normalize in (False, True):
+        s = pa.Searcher(ctx, 384, "cosine")
+        s.add_synthetic(1, 5000, 0x5EED, first_row=1000, normalize=normalize)
+        s.finalize()
+        pos = np.array([0, 1, 31, 32, 33, 1023, 1024, 4999], np.int64)
+        rows, ids = s.get_rows(pos)
+        ref = oracle.synth_rows(0x5EED, 1000, 5000, 384, normalize)
+        np.testing.assert_array_equal(rows.view(np.uint32), ref[pos].view(np.uint32))
+        np.testing.assert_array_equal(ids, 1000 + pos)
+        # and a search over them agrees with the oracle on the oracle-generated copy
+        q = oracle.synth_rows(0x5EED + 1, 0, 5, 384)
+        got, sc, _ = s.search_vectors(None, 10, q)
+        opos, osc, _ = oracle.topk(q, ref, 10)
+        np.testing.assert_array_equal(got, opos + 1000)
+        np.testing.assert_allclose(sc, osc.astype(np.float32), atol=1e-7)
+        s.close()
+
+
+@pytest.mark.parametrize("B,kernel", [(1, "wave"), (4, "wave"), (8, "mfma"), (64, "mfma")])
+def test_medium_random_vs_oracle(ctx, oracle, B, kernel):
+    N = 200_000 if B <= 8 else 60_000
+    s = pa.Searcher(ctx, 384, "cosine")
+    s.add_synthetic(1, N, 42)
+    s.finalize()
+    s.set_kernel(kernel)
+    q = oracle.synth_rows(43, 0, B, 384)
+    ids, scores, counts = s.search_vectors(None, 10, q)
+    ref = oracle.synth_rows(42, 0, N, 384)
+    opos, osc, _ = oracle.topk(q, ref, 10)
+    np.testing.assert_array_equal(ids, opos)
+    np.testing.assert_allclose(scores, osc.astype(np.float32), atol=1e-7)
+    st = s.last_stats()
+    # the screen must be selective: survivors are a tiny fraction of the B*N pairs
+    assert st["candidates"] < 0.02 * B * N, st
+    s.close()
+
+
+def test_candidate_overflow_reruns_and_stays_exact(ctx, oracle):
+    # adversarial order: similarity grows with the row index, so every row beats the running k-th
+    # best and the candidate lists overflow their initial capacity; the pass must be repeated with
+    # larger lists and still return the exact answer.
+    rng = np.random.default_rng(9)
+    N, D = 40_000, 64
+    q = rng.standard_normal(D).astype(np.float32)
+    noise = rng.standard_normal((N, D)).astype(np.float32)
+    t = np.linspace(-1, 1, N, dtype=np.float32)[:, None]
+    m = (t * q[None, :] + 0.01 * noise).astype(np.float32)
+    for kernel in ("wave", "mfma"):
+        s = build(ctx, m, kernel=kernel)
+        ids, scores, counts = s.search_vectors(None, 10, q[None, :])
+        opos, osc, _ = oracle.topk(q[None, :], m, 10)
+        np.testing.assert_array_equal(ids, opos)
+        st = s.last_stats()
+        assert st["overflow_reruns"] >= 1, st
+        s.close()
+
+
+def test_many_sources_more_than_one_launch_group(ctx, oracle):
+    # 11 sources -> 11 segments > kMaxSeg(8): two scan groups merged on the host
+    rng = np.random.default_rng(21)
+    s = pa.Searcher(ctx, 128, "cosine")
+    parts = []
+    for src in range(11):
+        m = rng.standard_normal((100 + 7 * src, 128)).astype(np.float32)
+        parts.append(m)
+        s.add_rows(src, m, np.arange(m.shape[0]) + 1000 * src)
+    s.finalize()
+    allm = np.concatenate(parts)
+    allids = np.concatenate([np.arange(p.shape[0]) + 1000 * i for i, p in enumerate(parts)])
+    q = rng.standard_normal((3, 128)).astype(np.float32)
+    ids, scores, _ = s.search_vectors(None, 12, q)
+    opos, osc, _ = oracle.topk(q, allm, 12)
+    np.testing.assert_array_equal(ids, allids[opos])
+    s.close()
+
+
+def test_similarity_matrices(ctx, oracle, g77):
+    q, m = g77["queries"], g77["corpus"]
+    np.testing.assert_allclose(pa.dot_product(ctx, q, m), g77["dot_f32"], atol=1e-4)
+    np.testing.assert_allclose(pa.cosine_similarity_multi_query(ctx, q, m), g77["cos_multi_f32"], atol=TOL)
+    np.testing.assert_allclose(pa.cosine_similarity_single_query(ctx, q[0], m), g77["cos_multi_f32"][0], atol=TOL)
+    np.testing.assert_allclose(pa.cosine_similarity_multi_query(ctx, q, m), oracle.cosine_similarity_multi_query(q, m), atol=1e-6)
+
+
+def test_sharded_search_and_merge(ctx, oracle):
+    # two shards of one corpus in one process: per-shard device lists -> merge == unsharded oracle
+    N, B, k = 30_000, 6, 10
+    ref = oracle.synth_rows(77, 0, N, 384)
+    q = oracle.synth_rows(78, 0, B, 384)
+    cut = 17_000
+    hit_bytes = 24
+    d_lists = ctx.alloc(2 * B * k * hit_bytes)
+    shards = []
+    for r, (lo, hi) in enumerate([(0, cut), (cut, N)]):
+        s = pa.Searcher(ctx, 384, "cosine")
+        s.add_synthetic(1, hi - lo, 77, first_row=lo)
+        s.finalize()
+        s.set_shard_offset(lo)
+        s.search_device(None, k, q, d_lists + r * B * k * hit_bytes)
+        shards.append(s)
+    ids, scores, counts = pa.merge_topk(ctx, "cosine", 384, d_lists, 2, B, k)
+    opos, osc, _ = oracle.topk(q, ref, k)
+    np.testing.assert_array_equal(ids, opos)  # synthetic ids = global row index
+    np.testing.assert_allclose(scores, osc.astype(np.float32), atol=1e-7)
+    raw = ctx.to_host(d_lists, 2 * B * k * hit_bytes).view(np.dtype([("score", "<f8"), ("pos", "<i8"), ("id", "<i8")]))
+    assert (raw["pos"][B * k :] >= cut).all() and (raw["pos"][: B * k] < cut).all()
+    ctx.free(d_lists)
+    for s in shards:
+        s.close()
+
+
+def test_error_paths(ctx):
+    s = pa.Searcher(ctx, 16, "cosine")
+    s.add_rows(1, np.ones((4, 16), np.float32))
+    with pytest.raises(pa.PcvError) as e:
+        s.search_vectors(None, 3, np.ones((1, 16), np.float32))
+    assert "finalize" in str(e.value)
+    s.finalize()
+    with pytest.raises(pa.PcvError):
+        s.search_vectors(None, 0, np.ones((1, 16), np.float32))
+    with pytest.raises(pa.PcvError):
+        s.search_vectors(None, 1000, np.ones((1, 16), np.float32))
+    with pytest.raises(ValueError):
+        s.search_vectors(None, 3, np.ones((1, 8), np.float32))
+    s.close()
+    with pytest.raises(pa.PcvError):
+        pa.Searcher(ctx, 0, "cosine")
