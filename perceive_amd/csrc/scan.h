@@ -18,7 +18,8 @@ namespace pcv {
 constexpr int kBlockRows = 32;      // rows per corpus block
 constexpr int kMaxSeg = 8;          // corpus segments one scan launch can walk
 constexpr int kMaxK = 128;          // largest num_results the running top-k slots hold
-constexpr int kSeedRows = 1024;     // rows the seed kernel ranks to initialise the thresholds
+constexpr int kSeedPartRows = 1024;  // rows one seed workgroup ranks
+constexpr int kSeedParts = 16;       // seed workgroups per query -> up to 16384 seed rows
 constexpr int kMaxWaveQueries = 4;  // wave-reduction kernel handles 1..4 queries per pass
 constexpr int kMfmaQueries = 64;    // MFMA kernel handles up to 64 queries per pass
 
@@ -51,9 +52,12 @@ struct ScanParams {
     uint32_t* slots;         // [B][kMaxK] ordered keys of k distinct rows' approximate scores
     uint32_t* cand_cnt;      // [B]
     uint64_t* cand;          // [B][cand_cap]  (segment index << 32) | row
+    float* cand_s;           // [B][cand_cap]  screening score the row was emitted with
     double* cand_score;      // [B][cand_cap]  canonical score, filled by the rescoring kernel
+    uint32_t* seed_part;     // [B][kSeedParts][kMaxK] per-part seed keys
     uint32_t cand_cap;
     uint32_t seed_blocks;    // leading blocks of segment 0 ranked by the seed kernel
+    uint32_t flags;          // bit 0: non-temporal corpus loads; bits 8..: grid multiplier override (tuning)
 };
 
 // float <-> order-preserving uint32 key (for atomicMax / CAS on scores)
@@ -85,7 +89,7 @@ void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const i
 void launch_prep_queries(hipStream_t st, const float* d_queries, int B, int D, int Dp, int metric, float eps_rel,
                          float max_norm, int k, float* qf32, uint16_t* qbf16, float* qraw, double* qnorm2,
                          float* margin, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt);
-void launch_seed(hipStream_t st, const ScanParams& p);
+void launch_seed(hipStream_t st, const ScanParams& p);  // seed_partial + seed_merge
 void launch_scan_wave(hipStream_t st, const ScanParams& p, int num_cus);
 void launch_scan_mfma(hipStream_t st, const ScanParams& p, int num_cus);
 void launch_rescore(hipStream_t st, const ScanParams& p);

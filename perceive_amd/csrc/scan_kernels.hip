@@ -18,6 +18,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// corpus rows are read exactly once per scan: optionally mark the loads non-temporal
+template <bool NTL>
+__device__ __forceinline__ float4 ld_row(const float4* p) {
+    if constexpr (NTL) {
+        const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+
 __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -37,7 +49,10 @@ __device__ __forceinline__ int find_seg(const ScanParams& p, uint32_t gb) {
 __device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint32_t row, float s,
                                       bool feeds_slots) {
     uint32_t idx = atomicAdd(&p.cand_cnt[q], 1u);
-    if (idx < p.cand_cap) p.cand[(size_t)q * p.cand_cap + idx] = ((uint64_t)(uint32_t)seg << 32) | row;
+    if (idx < p.cand_cap) {
+        p.cand[(size_t)q * p.cand_cap + idx] = ((uint64_t)(uint32_t)seg << 32) | row;
+        p.cand_s[(size_t)q * p.cand_cap + idx] = s;
+    }
     if (!feeds_slots || !isfinite(s)) return;
     const uint32_t key = f32_key(s);
     uint32_t* sl = p.slots + (size_t)q * kMaxK;
@@ -196,6 +211,7 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
                                                           float* __restrict__ margin, uint32_t* __restrict__ tau,
                                                           uint32_t* __restrict__ slots,
                                                           uint32_t* __restrict__ cand_cnt) {
+    extern __shared__ float sraw[];  // [Dp]
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     if (q >= B) {
@@ -205,9 +221,11 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
     }
     __shared__ double s_nq;
     const float* src = queries + (size_t)q * D;
-    if (tid == 0) {
+    for (int i = tid; i < Dp; i += 64) sraw[i] = i < D ? src[i] : 0.0f;
+    __syncthreads();
+    if (tid == 0) {  // f64, feature order: the canonical |q|^2 (oracle/scan.c:orc_canonical_score)
         double nq = 0.0;
-        for (int i = 0; i < D; ++i) nq += (double)src[i] * (double)src[i];
+        for (int i = 0; i < D; ++i) nq += (double)sraw[i] * (double)sraw[i];
         s_nq = nq;
     }
     __syncthreads();
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
     const bool ok = (nq < __builtin_inf()) && (metric == PCV_METRIC_DOT || nq >= 0x1p-126);
     const float inv = (metric == PCV_METRIC_DOT) ? 1.0f : (ok ? (float)(1.0 / sqrt(nq)) : 0.0f);
     for (int i = tid; i < Dp; i += 64) {
-        const float raw = i < D ? src[i] : 0.0f;
+        const float raw = sraw[i];
         const float qh = ok ? raw * inv : 0.0f;
         qraw[(size_t)q * Dp + i] = raw;
         qf32[(size_t)q * Dp + i] = qh;
@@ -234,69 +252,105 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
     }
 }
 
-// Seed: rank the first rows of segment 0 per query (f32 FMA chain) and install the k best as the
-// initial slots / threshold, so the streaming kernels start with a useful filter.
-__global__ __launch_bounds__(256) void seed_kernel(ScanParams p) {
-    extern __shared__ float smem[];
-    const int Dp = p.D4 * 4;
-    float* sq = smem;                             // [Dp]
-    uint32_t* keys = (uint32_t*)(smem + Dp);      // [kSeedRows]
-    __shared__ unsigned long long red[256];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const SegDesc& sg = p.seg[0];
-    const uint32_t nseed = min(sg.nrows, p.seed_blocks * 32u);
-    for (int i = tid; i < Dp; i += 256) sq[i] = p.qf32[(size_t)q * Dp + i];
-    __syncthreads();
-    for (uint32_t row = tid; row < (uint32_t)kSeedRows; row += 256) {
-        uint32_t key = 0;  // 0 = absent (below every real key)
-        if (row < nseed) {
-            const float4* base = sg.blk + (size_t)(row >> 5) * p.D4 * 32 + (row & 31);
-            float acc = 0.0f;
-            for (int f4 = 0; f4 < p.D4; ++f4) {
-                const float4 v = base[(size_t)f4 * 32];
-                const float4 qv = *(const float4*)&sq[f4 * 4];
-                acc = fmaf(qv.x, v.x, acc);
-                acc = fmaf(qv.y, v.y, acc);
-                acc = fmaf(qv.z, v.z, acc);
-                acc = fmaf(qv.w, v.w, acc);
-            }
-            const float sc = sg.scale[row];
-            const float s = acc * sc;
-            if (sc != 0.0f && isfinite(s)) key = f32_key(s);
-        }
-        keys[row] = key;
-    }
-    __syncthreads();
-    uint32_t last = kKeyNegInf;
-    for (int j = 0; j < p.k; ++j) {
+// k rounds of workgroup-wide argmax over `n` keys in LDS (0 = absent); round j's winner goes to
+// out[j] (0 when exhausted).  All 256 threads call it.
+__device__ __forceinline__ void topk_keys_lds(uint32_t* keys, uint32_t n, int k, unsigned long long* red4,
+                                              uint32_t* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = 0; j < k; ++j) {
         unsigned long long best = 0;
-        for (uint32_t row = tid; row < (uint32_t)kSeedRows; row += 256) {
-            unsigned long long c = ((unsigned long long)keys[row] << 32) | (0xffffffffu - row);
+        for (uint32_t i = tid; i < n; i += 256) {
+            const unsigned long long c = ((unsigned long long)keys[i] << 32) | (0xffffffffu - i);
             best = c > best ? c : best;
         }
-        red[tid] = best;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) red[tid] = red[tid] > red[tid + off] ? red[tid] : red[tid + off];
-            __syncthreads();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o > best ? o : best;
         }
-        const unsigned long long w = red[0];
+        if (lane == 0) red4[wave] = best;
         __syncthreads();
+        unsigned long long w = red4[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) w = red4[i] > w ? red4[i] : w;
         const uint32_t wkey = (uint32_t)(w >> 32);
         if (tid == 0) {
-            last = wkey ? wkey : kKeyNegInf;
-            p.slots[(size_t)q * kMaxK + j] = last;
+            out[j] = wkey;
             if (wkey) keys[0xffffffffu - (uint32_t)w] = 0;
         }
         __syncthreads();
     }
-    if (tid == 0) p.tau[q] = last;  // k-th best of the seed rows (or -inf when fewer than k)
+}
+
+// Seed, step 1: workgroup (part, query) ranks rows [part*1024, +1024) of segment 0 with an f32 FMA
+// chain and keeps its k best keys.  Gives the streaming kernels a useful threshold from the first
+// block on: with W waves in flight the first round screens 32*W rows against the seed threshold.
+__global__ __launch_bounds__(256) void seed_partial_kernel(ScanParams p) {
+    extern __shared__ float smem[];
+    const int Dp = p.D4 * 4;
+    float* sq = smem;                         // [Dp]
+    uint32_t* keys = (uint32_t*)(smem + Dp);  // [kSeedPartRows]
+    __shared__ unsigned long long red4[4];
+    const int part = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+    const SegDesc& sg = p.seg[0];
+    const uint32_t nseed = min(sg.nrows, p.seed_blocks * 32u);
+    for (int i = tid; i < Dp; i += 256) sq[i] = p.qf32[(size_t)q * Dp + i];
+    __syncthreads();
+    // thread t owns rows base + t + 256*u, u = 0..3: four independent FMA chains per thread
+    const uint32_t row0 = part * kSeedPartRows + tid;
+    const float4* base[4];
+    float acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t row = min(row0 + 256u * u, nseed ? nseed - 1 : 0u);
+        base[u] = sg.blk + (size_t)(row >> 5) * p.D4 * 32 + (row & 31);
+        acc[u] = 0.0f;
+    }
+    for (int f4 = 0; f4 < p.D4; ++f4) {
+        const float4 qv = *(const float4*)&sq[f4 * 4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v = base[u][(size_t)f4 * 32];
+            acc[u] = fmaf(qv.x, v.x, acc[u]);
+            acc[u] = fmaf(qv.y, v.y, acc[u]);
+            acc[u] = fmaf(qv.z, v.z, acc[u]);
+            acc[u] = fmaf(qv.w, v.w, acc[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t row = row0 + 256u * u;
+        uint32_t key = 0;  // 0 = absent (below every real key)
+        if (row < nseed) {
+            const float sc = sg.scale[row];
+            const float s = acc[u] * sc;
+            if (sc != 0.0f && isfinite(s)) key = f32_key(s);
+        }
+        keys[tid + 256 * u] = key;
+    }
+    __syncthreads();
+    topk_keys_lds(keys, kSeedPartRows, p.k, red4, p.seed_part + ((size_t)q * kSeedParts + part) * kMaxK);
+}
+
+// Seed, step 2: merge the per-part lists into the query's slots and threshold.
+__global__ __launch_bounds__(256) void seed_merge_kernel(ScanParams p, int nparts) {
+    __shared__ uint32_t keys[kSeedParts * kMaxK];
+    __shared__ uint32_t outk[kMaxK];
+    __shared__ unsigned long long red4[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = (uint32_t)nparts * p.k;
+    for (uint32_t i = tid; i < n; i += 256)
+        keys[i] = p.seed_part[((size_t)q * kSeedParts + i / p.k) * kMaxK + i % p.k];
+    __syncthreads();
+    topk_keys_lds(keys, n, p.k, red4, outk);
+    for (int j = tid; j < p.k; j += 256) p.slots[(size_t)q * kMaxK + j] = outk[j] ? outk[j] : kKeyNegInf;
+    if (tid == 0) p.tau[q] = outk[p.k - 1] ? outk[p.k - 1] : kKeyNegInf;  // k-th best seed row, -inf if fewer
 }
 
 // Wave-reduction scan for 1..4 queries (BASELINE config "10M x 384, batch=1"): pure HBM streaming.
 // Lane (r = lane&31, h = lane>>5) owns row r of the block and the pieces f4 = 2j+h; the two halves
 // of a row are combined with one cross-lane add.  f32 FMA chain -> eps ~ Dp * 2^-24.
-template <int NB>
+template <int NB, bool NTL>
 __global__ __launch_bounds__(256) void scan_wave_kernel(ScanParams p) {
     extern __shared__ float sq[];  // [NB][Dp]
     const int Dp = p.D4 * 4;
@@ -315,12 +369,18 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(ScanParams p) {
         const uint32_t lb = gb - sg.blk0;
         const float4* base = sg.blk + (size_t)lb * p.D4 * 32 + h * 32 + r;
         const float* qb = sq + h * 4;
+        // issued with the row loads so that their latency overlaps the streaming
+        const uint32_t row = lb * 32 + r;
+        const float sc = sg.scale[row];
+        uint32_t tk[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) tk[b] = ld_relaxed(&p.tau[b]);
         float acc[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
 #pragma unroll 8
         for (int j = 0; j < half; ++j) {
-            const float4 v = base[(size_t)j * 64];
+            const float4 v = ld_row<NTL>(base + (size_t)j * 64);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const float4 qv = *(const float4*)&qb[b * Dp + j * 8];
@@ -330,15 +390,13 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(ScanParams p) {
                 acc[b] = fmaf(qv.w, v.w, acc[b]);
             }
         }
-        const uint32_t row = lb * 32 + r;
-        const float sc = sg.scale[row];
         bool any = false;
         float s[NB], thr[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             acc[b] += __shfl_xor(acc[b], 32);
             s[b] = acc[b] * sc;
-            thr[b] = key_f32(ld_relaxed(&p.tau[b])) - mrg[b];
+            thr[b] = key_f32(tk[b]) - mrg[b];
             any |= (h == 0) && (sc != 0.0f) && !(s[b] < thr[b]);
         }
         if (__any(any)) {
@@ -357,8 +415,8 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(ScanParams p) {
 // more survivors than an f32 screen on random data, for 1/16 of the f32 matrix cost; survivors are
 // re-ranked exactly anyway.  Each wave streams its own blocks straight into registers: the blocked
 // HBM layout makes every load two contiguous 512 B runs, so there is no LDS round trip for the corpus.
-template <int NT>
-__global__ __launch_bounds__(256) void scan_mfma_kernel(ScanParams p) {
+template <int NT, bool NTL>
+__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(ScanParams p) {
     extern __shared__ uint4 lq[];  // [NT*32][Dp/8] 16-byte pieces of 8 bf16, swizzled
     const int D4 = p.D4;
     const int P8 = D4 >> 1;   // 16-B pieces per query row
@@ -388,18 +446,21 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(ScanParams p) {
     uint32_t lb = gb - p.seg[si].blk0;
     const float4* base = p.seg[si].blk + (size_t)lb * D4 * 32 + h * 64 + c;
     int ch = 0;
+    // scale of this lane's row (1/|x|, 1 or 0): multiplied into the A operand before the bf16
+    // rounding, so the accumulators are final screening scores
+    float sc_cur = p.seg[si].scale[(size_t)lb * 32 + c], sc_next = 0.0f;
 
     float4 buf0[8], buf1[8];
 #define PCV_LOAD(buf, bptr, chunk)                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)(buf)[i_] =                         \
-        (bptr)[(size_t)((chunk)*16 + (i_ >> 1) * 4 + (i_ & 1)) * 32];
+        ld_row<NTL>((bptr) + (size_t)((chunk)*16 + (i_ >> 1) * 4 + (i_ & 1)) * 32);
     // lane's pieces of k-step ks of the chunk: f4 = chunk*16 + ks*4 + 2h + e  (2h folded into base)
 
 #define PCV_COMPUTE(buf, chunk)                                                                        \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                              \
         f32x8 v_ = {(buf)[2 * ks_].x,     (buf)[2 * ks_].y,     (buf)[2 * ks_].z,     (buf)[2 * ks_].w,  \
                     (buf)[2 * ks_ + 1].x, (buf)[2 * ks_ + 1].y, (buf)[2 * ks_ + 1].z, (buf)[2 * ks_ + 1].w}; \
-        const bf16x8 a_ = __builtin_convertvector(v_, bf16x8);                                         \
+        const bf16x8 a_ = __builtin_convertvector(v_ * sc_cur, bf16x8);                                         \
         const int pc_ = 2 * ((chunk)*4 + ks_) + h;                                                     \
         const int ph_ = (pc_ & ~15) | ((pc_ ^ c) & 15);                                                \
         _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) {                                            \
@@ -408,38 +469,37 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(ScanParams p) {
         }                                                                                              \
     }
 
-    auto epilogue = [&](int esi, uint32_t elb) {
-        const SegDesc& sg = p.seg[esi];
-        const float* scp = sg.scale + (size_t)elb * 32 + 4 * h;
-        float4 s4[4];
+    // thresholds of the block being finished: issued one step ahead of the epilogue (together with
+    // the prefetch of the block's last chunk) so their latency is not exposed
+    uint32_t tauk[NT];
+    auto ep_prefetch = [&](int, uint32_t) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) s4[g] = *(const float4*)(scp + 8 * g);
+        for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? ld_relaxed(&p.tau[32 * t + c]) : 0u;
+    };
+
+    auto epilogue = [&](int esi, uint32_t elb) {
+        if (NCH < 2) ep_prefetch(esi, elb);
         float thr[NT];
         bool any = false;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int q = 32 * t + c;
-            thr[t] = (q < p.B) ? key_f32(ld_relaxed(&p.tau[q])) - mrg[t] : __builtin_inff();
+            thr[t] = (q < p.B) ? key_f32(tauk[t]) - mrg[t] : __builtin_inff();
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float4 sv = s4[i >> 2];
-                const float scv = (i & 3) == 0 ? sv.x : (i & 3) == 1 ? sv.y : (i & 3) == 2 ? sv.z : sv.w;
-                any |= !(acc[t][i] * scv < thr[t]);
-            }
+            for (int i = 0; i < 16; ++i) any |= !(acc[t][i] < thr[t]);
         }
         if (__any(any)) {
             const bool feeds = !(esi == 0 && elb < p.seed_blocks);
+            const float* scp = p.seg[esi].scale + (size_t)elb * 32;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int q = 32 * t + c;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float4 sv = s4[i >> 2];
-                    const float scv = (i & 3) == 0 ? sv.x : (i & 3) == 1 ? sv.y : (i & 3) == 2 ? sv.z : sv.w;
-                    const float s = acc[t][i] * scv;
-                    if (!(s < thr[t]) && q < p.B && scv != 0.0f) {
-                        const uint32_t row = elb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        emit_hit(p, q, esi, row, s, feeds);
+                    const float s = acc[t][i];  // the row scale is already folded into the A operand
+                    if (!(s < thr[t]) && q < p.B) {
+                        const uint32_t r = (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (scp[r] != 0.0f) emit_hit(p, q, esi, elb * 32 + r, s, feeds);
                     }
                 }
             }
@@ -467,12 +527,17 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(ScanParams p) {
                 nsi = find_seg(p, ngb);
                 nlb = ngb - p.seg[nsi].blk0;
                 nbase = p.seg[nsi].blk + (size_t)nlb * D4 * 32 + h * 64 + c;
+                sc_next = p.seg[nsi].scale[(size_t)nlb * 32 + c];
             }
         }
         bool more = ngb < p.total_blocks;
         if (more) { PCV_LOAD(buf1, nbase, nch); }
+        if (ch == NCH - 2) ep_prefetch(si, lb);
         PCV_COMPUTE(buf0, ch);
-        if (ch == NCH - 1) epilogue(si, lb);
+        if (ch == NCH - 1) {
+            epilogue(si, lb);
+            sc_cur = sc_next;
+        }
         if (!more) break;
         ch = nch; gb = ngb; si = nsi; lb = nlb; base = nbase;
         // ---- odd step: consume buf1, prefetch into buf0
@@ -488,12 +553,17 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(ScanParams p) {
                 nsi = find_seg(p, ngb);
                 nlb = ngb - p.seg[nsi].blk0;
                 nbase = p.seg[nsi].blk + (size_t)nlb * D4 * 32 + h * 64 + c;
+                sc_next = p.seg[nsi].scale[(size_t)nlb * 32 + c];
             }
         }
         more = ngb < p.total_blocks;
         if (more) { PCV_LOAD(buf0, nbase, nch); }
+        if (ch == NCH - 2) ep_prefetch(si, lb);
         PCV_COMPUTE(buf1, ch);
-        if (ch == NCH - 1) epilogue(si, lb);
+        if (ch == NCH - 1) {
+            epilogue(si, lb);
+            sc_cur = sc_next;
+        }
         if (!more) break;
         ch = nch; gb = ngb; si = nsi; lb = nlb; base = nbase;
     }
@@ -513,6 +583,13 @@ __global__ __launch_bounds__(256) void rescore_kernel(ScanParams p) {
     __syncthreads();
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= cnt) return;
+    // rows emitted while tau was still low: the final threshold already excludes most of them
+    // (same rule as the scan: a row with s < tau - 2*eps cannot reach the final k-th best)
+    const float thr_final = key_f32(p.tau[q]) - p.margin[q];
+    if (p.cand_s[(size_t)q * p.cand_cap + j] < thr_final) {
+        p.cand_score[(size_t)q * p.cand_cap + j] = __builtin_nan("");
+        return;
+    }
     const uint64_t e = p.cand[(size_t)q * p.cand_cap + j];
     const SegDesc& sg = p.seg[(int)(e >> 32)];
     const uint32_t row = (uint32_t)e;
@@ -552,58 +629,98 @@ __device__ __forceinline__ bool better(double sa, int64_t pa, double sb, int64_t
     return sa > sb || (sa == sb && pa < pb);
 }
 
-// k rounds of block-wide argmax over the rescored survivors: descending score, ties -> lower
-// global position.  One workgroup per query.
+// Final ranking of the rescored survivors: descending canonical score, ties -> lower global
+// position.  One workgroup per query.  The valid survivors (normally a few dozen) are compacted
+// into LDS, then k rounds of argmax run there; lists that do not fit fall back to global memory.
+constexpr int kSelCap = 1024;
 __global__ __launch_bounds__(256) void select_kernel(ScanParams p, pcv_hit_dev* __restrict__ out) {
-    __shared__ double r_s[256];
-    __shared__ int64_t r_p[256];
-    __shared__ uint32_t r_i[256];
-    const int q = blockIdx.x, tid = threadIdx.x;
+    __shared__ double c_s[kSelCap];
+    __shared__ int64_t c_p[kSelCap];
+    __shared__ uint32_t c_i[kSelCap];
+    __shared__ double r_s[4];
+    __shared__ int64_t r_p[4];
+    __shared__ uint32_t r_i[4];
+    __shared__ uint32_t n_valid;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cnt = min(p.cand_cnt[q], p.cand_cap);
     const uint64_t* cand = p.cand + (size_t)q * p.cand_cap;
     double* sc = p.cand_score + (size_t)q * p.cand_cap;
+    if (tid == 0) n_valid = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < cnt; i += 256) {
+        const double s = sc[i];
+        if (!(s == s)) continue;  // NaN: undefined score or ruled out
+        const uint32_t slot = atomicAdd(&n_valid, 1u);
+        if (slot < (uint32_t)kSelCap) {
+            const uint64_t e = cand[i];
+            c_s[slot] = s;
+            c_p[slot] = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
+            c_i[slot] = i;
+        }
+    }
+    __syncthreads();
+    const uint32_t nv = n_valid;
+    const bool in_lds = nv <= (uint32_t)kSelCap;
+    const uint32_t n = in_lds ? nv : cnt;
     for (int j = 0; j < p.k; ++j) {
         double bs = -__builtin_inf();
         int64_t bp = INT64_MAX;
-        uint32_t bi = 0xffffffffu;
-        for (uint32_t i = tid; i < cnt; i += 256) {
-            const double s = sc[i];
-            if (!(s == s)) continue;  // NaN: undefined score or already taken
-            const uint64_t e = cand[i];
-            const int64_t pos = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
+        uint32_t bi = 0xffffffffu;  // index into the LDS list (in_lds) or the global list
+        for (uint32_t i = tid; i < n; i += 256) {
+            double s;
+            int64_t pos;
+            if (in_lds) {
+                s = c_s[i];
+                pos = c_p[i];
+            } else {
+                s = sc[i];
+                const uint64_t e = cand[i];
+                pos = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
+            }
+            if (!(s == s)) continue;
             if (bi == 0xffffffffu || better(s, pos, bs, bp)) {
                 bs = s;
                 bp = pos;
                 bi = i;
             }
         }
-        r_s[tid] = bs;
-        r_p[tid] = bp;
-        r_i[tid] = bi;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) {
-                const bool take = r_i[tid + off] != 0xffffffffu &&
-                                  (r_i[tid] == 0xffffffffu || better(r_s[tid + off], r_p[tid + off], r_s[tid], r_p[tid]));
-                if (take) {
-                    r_s[tid] = r_s[tid + off];
-                    r_p[tid] = r_p[tid + off];
-                    r_i[tid] = r_i[tid + off];
-                }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double os = __shfl_xor(bs, off);
+            const int64_t op = __shfl_xor(bp, off);
+            const uint32_t oi = __shfl_xor(bi, off);
+            if (oi != 0xffffffffu && (bi == 0xffffffffu || better(os, op, bs, bp))) {
+                bs = os;
+                bp = op;
+                bi = oi;
             }
-            __syncthreads();
         }
-        const uint32_t wi = r_i[0];
+        if (lane == 0) {
+            r_s[wave] = bs;
+            r_p[wave] = bp;
+            r_i[wave] = bi;
+        }
+        __syncthreads();
         if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (r_i[w] != 0xffffffffu && (bi == 0xffffffffu || better(r_s[w], r_p[w], bs, bp))) {
+                    bs = r_s[w];
+                    bp = r_p[w];
+                    bi = r_i[w];
+                }
             pcv_hit_dev hit;
-            if (wi != 0xffffffffu) {
-                const uint64_t e = cand[wi];
+            if (bi != 0xffffffffu) {
+                const uint32_t gi = in_lds ? c_i[bi] : bi;
+                const uint64_t e = cand[gi];
                 const SegDesc& sg = p.seg[(int)(e >> 32)];
                 const uint32_t row = (uint32_t)e;
-                hit.score = r_s[0];
-                hit.pos = r_p[0];
+                hit.score = bs;
+                hit.pos = bp;
                 hit.id = sg.ids ? sg.ids[row] : sg.id0 + (int64_t)row;
-                sc[wi] = __builtin_nan("");
+                if (in_lds)
+                    c_s[bi] = __builtin_nan("");
+                else
+                    sc[bi] = __builtin_nan("");
             } else {
                 hit.score = __builtin_nan("");
                 hit.pos = -1;
@@ -732,41 +849,60 @@ void launch_prep_queries(hipStream_t st, const float* d_queries, int B, int D, i
                          float max_norm, int k, float* qf32, uint16_t* qbf16, float* qraw, double* qnorm2,
                          float* margin, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt) {
     const int grid = B > kMfmaQueries ? B : kMfmaQueries;
-    prep_queries_kernel<<<grid, 64, 0, st>>>(d_queries, B, D, Dp, metric, eps_rel, max_norm, k, qf32, qbf16, qraw,
+    prep_queries_kernel<<<grid, 64, (size_t)Dp * sizeof(float), st>>>(d_queries, B, D, Dp, metric, eps_rel, max_norm, k, qf32, qbf16, qraw,
                                              qnorm2, margin, tau, slots, cand_cnt);
 }
 
 void launch_seed(hipStream_t st, const ScanParams& p) {
     if (p.seed_blocks == 0 || p.nseg == 0) return;
-    const size_t lds = (size_t)p.D4 * 4 * sizeof(float) + kSeedRows * sizeof(uint32_t);
-    seed_kernel<<<p.B, 256, lds, st>>>(p);
+    const int nparts = (int)((p.seed_blocks * 32u + kSeedPartRows - 1) / kSeedPartRows);
+    const size_t lds = (size_t)p.D4 * 4 * sizeof(float) + kSeedPartRows * sizeof(uint32_t);
+    seed_partial_kernel<<<dim3(nparts, p.B), 256, lds, st>>>(p);
+    seed_merge_kernel<<<p.B, 256, 0, st>>>(p, nparts);
 }
 
 void launch_scan_wave(hipStream_t st, const ScanParams& p, int num_cus) {
     if (p.total_blocks == 0) return;
     const size_t lds = (size_t)p.B * p.D4 * 4 * sizeof(float);
-    unsigned grid = (unsigned)num_cus * 8;
+    const unsigned gm = (p.flags >> 8) & 0xff;
+    unsigned grid = (unsigned)num_cus * (gm ? gm : 8);
     const unsigned need = (p.total_blocks + 3) / 4;
     if (grid > need) grid = need;
+    const bool ntl = (p.flags & 1) != 0;
+#define PCV_WAVE(NB)                                                   \
+    if (ntl)                                                           \
+        scan_wave_kernel<NB, true><<<grid, 256, lds, st>>>(p);         \
+    else                                                               \
+        scan_wave_kernel<NB, false><<<grid, 256, lds, st>>>(p);
     switch (p.B) {
-        case 1: scan_wave_kernel<1><<<grid, 256, lds, st>>>(p); break;
-        case 2: scan_wave_kernel<2><<<grid, 256, lds, st>>>(p); break;
-        case 3: scan_wave_kernel<3><<<grid, 256, lds, st>>>(p); break;
-        default: scan_wave_kernel<4><<<grid, 256, lds, st>>>(p); break;
+        case 1: PCV_WAVE(1); break;
+        case 2: PCV_WAVE(2); break;
+        case 3: PCV_WAVE(3); break;
+        default: PCV_WAVE(4); break;
     }
+#undef PCV_WAVE
 }
 
 void launch_scan_mfma(hipStream_t st, const ScanParams& p, int num_cus) {
     if (p.total_blocks == 0) return;
     const int NT = p.B <= 32 ? 1 : 2;
     const size_t lds = (size_t)NT * 32 * p.D4 * 4 * sizeof(uint16_t);
-    unsigned grid = (unsigned)num_cus * 3;
+    const unsigned gm = (p.flags >> 8) & 0xff;
+    unsigned grid = (unsigned)num_cus * (gm ? gm : 3);
     const unsigned need = (p.total_blocks + 3) / 4;
     if (grid > need) grid = need;
-    if (NT == 1)
-        scan_mfma_kernel<1><<<grid, 256, lds, st>>>(p);
-    else
-        scan_mfma_kernel<2><<<grid, 256, lds, st>>>(p);
+    const bool ntl = (p.flags & 1) != 0;
+    if (NT == 1) {
+        if (ntl)
+            scan_mfma_kernel<1, true><<<grid, 256, lds, st>>>(p);
+        else
+            scan_mfma_kernel<1, false><<<grid, 256, lds, st>>>(p);
+    } else {
+        if (ntl)
+            scan_mfma_kernel<2, true><<<grid, 256, lds, st>>>(p);
+        else
+            scan_mfma_kernel<2, false><<<grid, 256, lds, st>>>(p);
+    }
 }
 
 void launch_rescore(hipStream_t st, const ScanParams& p) {

@@ -4,6 +4,7 @@
 // (scan.h).  Searching streams the selected segments once; see scan_kernels.hip for the pipeline.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -81,10 +82,12 @@ struct pcv_searcher {
     DevBuf<float> d_queries, d_qf32, d_qraw, d_margin;
     DevBuf<uint16_t> d_qbf16;
     DevBuf<double> d_qnorm2, d_cand_score;
-    DevBuf<uint32_t> d_tau, d_slots, d_cnt;
+    DevBuf<float> d_cand_s;
+    DevBuf<uint32_t> d_tau, d_slots, d_cnt, d_seed_part;
     DevBuf<uint64_t> d_cand;
     DevBuf<pcv_hit_dev> d_hits;
     uint32_t cand_cap = 8192;
+    uint32_t scan_flags = 0;  // tuning knobs, PCV_SCAN_FLAGS
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
     Source* find_source(int64_t id) {
@@ -237,6 +240,8 @@ void ensure_workspace(pcv_searcher* s) {
     s->d_cnt.ensure(Q);
     s->d_cand.ensure(Q * s->cand_cap);
     s->d_cand_score.ensure(Q * s->cand_cap);
+    s->d_cand_s.ensure(Q * s->cand_cap);
+    s->d_seed_part.ensure(Q * kSeedParts * kMaxK);
     s->d_hits.ensure(Q * kMaxK);
     for (auto& e : s->ev)
         if (!e) PCV_HIP(hipEventCreate(&e));
@@ -274,8 +279,12 @@ void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* s
         p.cand_cnt = s->d_cnt.p;
         p.cand = s->d_cand.p;
         p.cand_score = s->d_cand_score.p;
+        p.cand_s = s->d_cand_s.p;
+        p.seed_part = s->d_seed_part.p;
         p.cand_cap = s->cand_cap;
-        p.seed_blocks = nseg > 0 ? std::min<uint32_t>(kSeedRows / kBlockRows, segs[0].g->nblocks) : 0;
+        p.flags = s->scan_flags;
+        p.seed_blocks =
+            nseg > 0 ? std::min<uint32_t>(kSeedParts * kSeedPartRows / kBlockRows, segs[0].g->nblocks) : 0;
 
         // |s - c| bound of the screening score, relative to |q||x| (DESIGN.md §screening error)
         const float eps_f32 = (float)(s->Dp + 16) * 1.2e-7f;
@@ -329,6 +338,7 @@ void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* s
         s->cand_cap = (uint32_t)std::max<uint64_t>(want, s->cand_cap * 2ull);
         s->d_cand.ensure((size_t)kMfmaQueries * s->cand_cap);
         s->d_cand_score.ensure((size_t)kMfmaQueries * s->cand_cap);
+        s->d_cand_s.ensure((size_t)kMfmaQueries * s->cand_cap);
     }
 }
 
@@ -427,6 +437,7 @@ pcv_status pcv_searcher_create(pcv_ctx* ctx, int dim, int metric, pcv_searcher**
         s->Dp = (dim + 63) / 64 * 64;
         s->D4 = s->Dp / 4;
         s->metric = metric;
+        if (const char* f = getenv("PCV_SCAN_FLAGS")) s->scan_flags = (uint32_t)strtoul(f, nullptr, 0);
         hipError_t e = hipMalloc((void**)&s->d_max_norm_bits, 4);
         if (e != hipSuccess) {
             delete s;
@@ -451,6 +462,8 @@ pcv_status pcv_searcher_destroy(pcv_searcher* s) {
         s->d_qbf16.release();
         s->d_qnorm2.release();
         s->d_cand_score.release();
+        s->d_cand_s.release();
+        s->d_seed_part.release();
         s->d_tau.release();
         s->d_slots.release();
         s->d_cnt.release();
