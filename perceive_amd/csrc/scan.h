@@ -57,7 +57,7 @@ struct ScanParams {
     uint32_t* seed_part;     // [B][kSeedParts][kMaxK] per-part seed keys
     uint32_t cand_cap;
     uint32_t seed_blocks;    // leading blocks of segment 0 ranked by the seed kernel
-    uint32_t flags;          // bit 0: non-temporal corpus loads; bits 8..: grid multiplier override (tuning)
+    uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bits 8..: grid multiplier override (tuning)
 };
 
 // float <-> order-preserving uint32 key (for atomicMax / CAS on scores)
@@ -89,11 +89,14 @@ void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const i
 void launch_prep_queries(hipStream_t st, const float* d_queries, int B, int D, int Dp, int metric, float eps_rel,
                          float max_norm, int k, float* qf32, uint16_t* qbf16, float* qraw, double* qnorm2,
                          float* margin, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt);
-void launch_seed(hipStream_t st, const ScanParams& p);  // seed_partial + seed_merge
-void launch_scan_wave(hipStream_t st, const ScanParams& p, int num_cus);
-void launch_scan_mfma(hipStream_t st, const ScanParams& p, int num_cus);
-void launch_rescore(hipStream_t st, const ScanParams& p);
-void launch_select(hipStream_t st, const ScanParams& p, pcv_hit_dev* out);
+// `p` is the host copy (shapes for the launch geometry), `dp` the same struct resident in device
+// memory: the kernels index p.seg[] at run time, which a by-value kernel argument would force
+// through scratch memory.
+void launch_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp);  // seed_partial + seed_merge
+void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);
+void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);
+void launch_rescore(hipStream_t st, const ScanParams& p, const ScanParams* dp);
+void launch_select(hipStream_t st, const ScanParams& p, const ScanParams* dp, pcv_hit_dev* out);
 void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out);
 void launch_similarity_matrix(hipStream_t st, const float* a, int B, const float* m, int64_t N, int D, int cosine,
                               float* out);

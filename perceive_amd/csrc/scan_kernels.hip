@@ -8,6 +8,9 @@
 // still be in the top-k:   emit iff !(s < tau_q - 2*eps),   tau_q = running k-th best s.
 // tau only grows, so the emitted set is a superset of the exact top-k; rescore+select then rank
 // the few hundred survivors per query in exact f64.  HBM traffic = one pass over the rows.
+#include <algorithm>
+#include <cstdlib>
+
 #include "scan.h"
 #include "synth.h"
 
@@ -148,29 +151,31 @@ __global__ __launch_bounds__(256) void synth_inv_kernel(uint32_t nrows, int D4sr
     inv[row] = (float)(1.0 / sqrt(nx));
 }
 
-// thread per (block, piece, row-in-block): segment rows row0..row0+nrows get synth rows
+// thread per (block, piece, row-in-block), grid-stride (a 100M-row segment has 9.6e9 work items,
+// more than one launch dimension can carry): segment rows row0..row0+nrows get synth rows
 // first_row.. ; pieces beyond D stay zero
 __global__ __launch_bounds__(256) void synth_fill_kernel(float4* __restrict__ blk, uint32_t nrows, uint32_t row0,
                                                          int D4src, int D4, uint64_t seed, int64_t first_row,
-                                                         const float* __restrict__ inv) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int r = (int)(t & 31);
-    const int64_t u = t >> 5;
-    const int f4 = (int)(u % D4src);
-    const int64_t lb = u / D4src;
+                                                         const float* __restrict__ inv, int64_t total) {
     const uint32_t first_blk = row0 >> 5;
-    const int64_t row = (lb + first_blk) * 32 + r;
-    const int64_t src = row - row0;
-    if (src < 0 || src >= nrows) return;
-    float4 v = synth_piece(seed, first_row + src, (uint32_t)f4);
-    if (inv) {
-        float s = inv[src];
-        v.x *= s;
-        v.y *= s;
-        v.z *= s;
-        v.w *= s;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int r = (int)(t & 31);
+        const int64_t u = t >> 5;
+        const int f4 = (int)(u % D4src);
+        const int64_t lb = u / D4src;
+        const int64_t row = (lb + first_blk) * 32 + r;
+        const int64_t src = row - row0;
+        if (src < 0 || src >= nrows) continue;
+        float4 v = synth_piece(seed, first_row + src, (uint32_t)f4);
+        if (inv) {
+            float s = inv[src];
+            v.x *= s;
+            v.y *= s;
+            v.z *= s;
+            v.w *= s;
+        }
+        blk[((lb + first_blk) * D4 + f4) * 32 + r] = v;
     }
-    blk[((lb + first_blk) * D4 + f4) * 32 + r] = v;
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const SegDesc* __restrict__ segs, int nseg,
@@ -285,7 +290,8 @@ __device__ __forceinline__ void topk_keys_lds(uint32_t* keys, uint32_t n, int k,
 // Seed, step 1: workgroup (part, query) ranks rows [part*1024, +1024) of segment 0 with an f32 FMA
 // chain and keeps its k best keys.  Gives the streaming kernels a useful threshold from the first
 // block on: with W waves in flight the first round screens 32*W rows against the seed threshold.
-__global__ __launch_bounds__(256) void seed_partial_kernel(ScanParams p) {
+__global__ __launch_bounds__(256) void seed_partial_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
     extern __shared__ float smem[];
     const int Dp = p.D4 * 4;
     float* sq = smem;                         // [Dp]
@@ -333,7 +339,8 @@ __global__ __launch_bounds__(256) void seed_partial_kernel(ScanParams p) {
 }
 
 // Seed, step 2: merge the per-part lists into the query's slots and threshold.
-__global__ __launch_bounds__(256) void seed_merge_kernel(ScanParams p, int nparts) {
+__global__ __launch_bounds__(256) void seed_merge_kernel(const ScanParams* __restrict__ pp, int nparts) {
+    const ScanParams& p = *pp;
     __shared__ uint32_t keys[kSeedParts * kMaxK];
     __shared__ uint32_t outk[kMaxK];
     __shared__ unsigned long long red4[4];
@@ -351,7 +358,8 @@ __global__ __launch_bounds__(256) void seed_merge_kernel(ScanParams p, int npart
 // Lane (r = lane&31, h = lane>>5) owns row r of the block and the pieces f4 = 2j+h; the two halves
 // of a row are combined with one cross-lane add.  f32 FMA chain -> eps ~ Dp * 2^-24.
 template <int NB, bool NTL>
-__global__ __launch_bounds__(256) void scan_wave_kernel(ScanParams p) {
+__global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
     extern __shared__ float sq[];  // [NB][Dp]
     const int Dp = p.D4 * 4;
     for (int i = threadIdx.x; i < NB * Dp; i += 256) sq[i] = p.qf32[i];
@@ -416,7 +424,8 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(ScanParams p) {
 // re-ranked exactly anyway.  Each wave streams its own blocks straight into registers: the blocked
 // HBM layout makes every load two contiguous 512 B runs, so there is no LDS round trip for the corpus.
 template <int NT, bool NTL>
-__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(ScanParams p) {
+__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
     extern __shared__ uint4 lq[];  // [NT*32][Dp/8] 16-byte pieces of 8 bf16, swizzled
     const int D4 = p.D4;
     const int P8 = D4 >> 1;   // 16-B pieces per query row
@@ -573,7 +582,8 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(ScanParams p) {
 
 // Exact canonical score of every surviving (query,row) pair: f64, products exact, sums in feature
 // order — the same definition as oracle/scan.c:orc_canonical_score.
-__global__ __launch_bounds__(256) void rescore_kernel(ScanParams p) {
+__global__ __launch_bounds__(256) void rescore_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
     extern __shared__ float sqr[];  // [Dp] raw query
     const int q = blockIdx.y;
     const int Dp = p.D4 * 4;
@@ -633,7 +643,8 @@ __device__ __forceinline__ bool better(double sa, int64_t pa, double sb, int64_t
 // position.  One workgroup per query.  The valid survivors (normally a few dozen) are compacted
 // into LDS, then k rounds of argmax run there; lists that do not fit fall back to global memory.
 constexpr int kSelCap = 1024;
-__global__ __launch_bounds__(256) void select_kernel(ScanParams p, pcv_hit_dev* __restrict__ out) {
+__global__ __launch_bounds__(256) void select_kernel(const ScanParams* __restrict__ pp, pcv_hit_dev* __restrict__ out) {
+    const ScanParams& p = *pp;
     __shared__ double c_s[kSelCap];
     __shared__ int64_t c_p[kSelCap];
     __shared__ uint32_t c_i[kSelCap];
@@ -812,6 +823,7 @@ void launch_pack_rows(hipStream_t st, const float* rows, int64_t n, int D, int D
     const uint32_t first_blk = row0 >> 5;
     const uint32_t last_blk = (uint32_t)((row0 + n - 1) >> 5);
     const int64_t threads = (int64_t)(last_blk - first_blk + 1) * D4 * 32;
+    if (threads > (int64_t)0xffffff00u) abort();  // callers stage <= 2^18 rows per call
     pack_rows_kernel<<<cdiv64(threads, 256), 256, 0, st>>>(rows, n, D, D4, blk, row0);
 }
 
@@ -834,7 +846,8 @@ void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nblocks, uint32_t n
     const uint32_t first_blk = row0 >> 5;
     const uint32_t last_blk = (uint32_t)(((uint64_t)row0 + nrows - 1) >> 5);
     const int64_t threads = (int64_t)(last_blk - first_blk + 1) * D4src * 32;
-    synth_fill_kernel<<<cdiv64(threads, 256), 256, 0, st>>>(blk, nrows, row0, D4src, D4, seed, first_row, inv);
+    const unsigned grid = (unsigned)std::min<int64_t>((threads + 255) / 256, 1 << 20);
+    synth_fill_kernel<<<grid, 256, 0, st>>>(blk, nrows, row0, D4src, D4, seed, first_row, inv, threads);
     if (inv) hipFreeAsync(inv, st);
 }
 
@@ -853,27 +866,27 @@ void launch_prep_queries(hipStream_t st, const float* d_queries, int B, int D, i
                                              qnorm2, margin, tau, slots, cand_cnt);
 }
 
-void launch_seed(hipStream_t st, const ScanParams& p) {
+void launch_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
     if (p.seed_blocks == 0 || p.nseg == 0) return;
     const int nparts = (int)((p.seed_blocks * 32u + kSeedPartRows - 1) / kSeedPartRows);
     const size_t lds = (size_t)p.D4 * 4 * sizeof(float) + kSeedPartRows * sizeof(uint32_t);
-    seed_partial_kernel<<<dim3(nparts, p.B), 256, lds, st>>>(p);
-    seed_merge_kernel<<<p.B, 256, 0, st>>>(p, nparts);
+    seed_partial_kernel<<<dim3(nparts, p.B), 256, lds, st>>>(dp);
+    seed_merge_kernel<<<p.B, 256, 0, st>>>(dp, nparts);
 }
 
-void launch_scan_wave(hipStream_t st, const ScanParams& p, int num_cus) {
+void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
     if (p.total_blocks == 0) return;
     const size_t lds = (size_t)p.B * p.D4 * 4 * sizeof(float);
     const unsigned gm = (p.flags >> 8) & 0xff;
     unsigned grid = (unsigned)num_cus * (gm ? gm : 8);
     const unsigned need = (p.total_blocks + 3) / 4;
     if (grid > need) grid = need;
-    const bool ntl = (p.flags & 1) != 0;
+    const bool ntl = (p.flags & 1) == 0;  // non-temporal corpus loads unless flag bit 0 is set
 #define PCV_WAVE(NB)                                                   \
     if (ntl)                                                           \
-        scan_wave_kernel<NB, true><<<grid, 256, lds, st>>>(p);         \
+        scan_wave_kernel<NB, true><<<grid, 256, lds, st>>>(dp);         \
     else                                                               \
-        scan_wave_kernel<NB, false><<<grid, 256, lds, st>>>(p);
+        scan_wave_kernel<NB, false><<<grid, 256, lds, st>>>(dp);
     switch (p.B) {
         case 1: PCV_WAVE(1); break;
         case 2: PCV_WAVE(2); break;
@@ -883,7 +896,7 @@ void launch_scan_wave(hipStream_t st, const ScanParams& p, int num_cus) {
 #undef PCV_WAVE
 }
 
-void launch_scan_mfma(hipStream_t st, const ScanParams& p, int num_cus) {
+void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
     if (p.total_blocks == 0) return;
     const int NT = p.B <= 32 ? 1 : 2;
     const size_t lds = (size_t)NT * 32 * p.D4 * 4 * sizeof(uint16_t);
@@ -891,28 +904,28 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, int num_cus) {
     unsigned grid = (unsigned)num_cus * (gm ? gm : 3);
     const unsigned need = (p.total_blocks + 3) / 4;
     if (grid > need) grid = need;
-    const bool ntl = (p.flags & 1) != 0;
+    const bool ntl = (p.flags & 1) == 0;  // non-temporal corpus loads unless flag bit 0 is set
     if (NT == 1) {
         if (ntl)
-            scan_mfma_kernel<1, true><<<grid, 256, lds, st>>>(p);
+            scan_mfma_kernel<1, true><<<grid, 256, lds, st>>>(dp);
         else
-            scan_mfma_kernel<1, false><<<grid, 256, lds, st>>>(p);
+            scan_mfma_kernel<1, false><<<grid, 256, lds, st>>>(dp);
     } else {
         if (ntl)
-            scan_mfma_kernel<2, true><<<grid, 256, lds, st>>>(p);
+            scan_mfma_kernel<2, true><<<grid, 256, lds, st>>>(dp);
         else
-            scan_mfma_kernel<2, false><<<grid, 256, lds, st>>>(p);
+            scan_mfma_kernel<2, false><<<grid, 256, lds, st>>>(dp);
     }
 }
 
-void launch_rescore(hipStream_t st, const ScanParams& p) {
+void launch_rescore(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
     const size_t lds = (size_t)p.D4 * 4 * sizeof(float);
     dim3 grid((p.cand_cap + 255) / 256, p.B);
-    rescore_kernel<<<grid, 256, lds, st>>>(p);
+    rescore_kernel<<<grid, 256, lds, st>>>(dp);
 }
 
-void launch_select(hipStream_t st, const ScanParams& p, pcv_hit_dev* out) {
-    select_kernel<<<p.B, 256, 0, st>>>(p, out);
+void launch_select(hipStream_t st, const ScanParams& p, const ScanParams* dp, pcv_hit_dev* out) {
+    select_kernel<<<p.B, 256, 0, st>>>(dp, out);
 }
 
 void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out) {

@@ -86,6 +86,8 @@ struct pcv_searcher {
     DevBuf<uint32_t> d_tau, d_slots, d_cnt, d_seed_part;
     DevBuf<uint64_t> d_cand;
     DevBuf<pcv_hit_dev> d_hits;
+    DevBuf<ScanParams> d_params;
+    ScanParams h_params{};  // stays alive while the async upload of a pass is in flight
     uint32_t cand_cap = 8192;
     uint32_t scan_flags = 0;  // tuning knobs, PCV_SCAN_FLAGS
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -243,6 +245,7 @@ void ensure_workspace(pcv_searcher* s) {
     s->d_cand_s.ensure(Q * s->cand_cap);
     s->d_seed_part.ensure(Q * kSeedParts * kMaxK);
     s->d_hits.ensure(Q * kMaxK);
+    s->d_params.ensure(1);
     for (auto& e : s->ev)
         if (!e) PCV_HIP(hipEventCreate(&e));
 }
@@ -254,7 +257,8 @@ void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* s
     PCV_HIP(hipMemcpyAsync(s->d_queries.p, queries_host, (size_t)B * s->D * sizeof(float), hipMemcpyHostToDevice, st));
 
     for (int attempt = 0;; ++attempt) {
-        ScanParams p{};
+        ScanParams& p = s->h_params;
+        p = ScanParams{};
         uint32_t blk0 = 0;
         int64_t rows = 0;
         for (int i = 0; i < nseg; ++i) {
@@ -290,19 +294,21 @@ void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* s
         const float eps_f32 = (float)(s->Dp + 16) * 1.2e-7f;
         const float eps_rel = (kernel == PCV_KERNEL_MFMA) ? 0.0039101f + 2.0f * eps_f32 : eps_f32;
 
+        const ScanParams* dp = s->d_params.p;
+        PCV_HIP(hipMemcpyAsync(s->d_params.p, &p, sizeof(ScanParams), hipMemcpyHostToDevice, st));
         PCV_HIP(hipEventRecord(s->ev[0], st));
         launch_prep_queries(st, s->d_queries.p, B, s->D, s->Dp, s->metric, eps_rel, s->max_norm, k, s->d_qf32.p,
                             s->d_qbf16.p, s->d_qraw.p, s->d_qnorm2.p, s->d_margin.p, s->d_tau.p, s->d_slots.p,
                             s->d_cnt.p);
-        launch_seed(st, p);
+        launch_seed(st, p, dp);
         PCV_HIP(hipEventRecord(s->ev[1], st));
         if (kernel == PCV_KERNEL_MFMA)
-            launch_scan_mfma(st, p, s->ctx->num_cus);
+            launch_scan_mfma(st, p, dp, s->ctx->num_cus);
         else
-            launch_scan_wave(st, p, s->ctx->num_cus);
+            launch_scan_wave(st, p, dp, s->ctx->num_cus);
         PCV_HIP(hipEventRecord(s->ev[2], st));
-        launch_rescore(st, p);
-        launch_select(st, p, s->d_hits.p);
+        launch_rescore(st, p, dp);
+        launch_select(st, p, dp, s->d_hits.p);
         PCV_HIP(hipEventRecord(s->ev[3], st));
         uint32_t cnt[kMfmaQueries];
         PCV_HIP(hipMemcpyAsync(cnt, s->d_cnt.p, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -469,6 +475,7 @@ pcv_status pcv_searcher_destroy(pcv_searcher* s) {
         s->d_cnt.release();
         s->d_cand.release();
         s->d_hits.release();
+        s->d_params.release();
         if (s->d_max_norm_bits) hipFree(s->d_max_norm_bits);
         for (auto& e : s->ev)
             if (e) hipEventDestroy(e);

@@ -202,6 +202,26 @@ def test_synthetic_rows_bit_identical_to_oracle(ctx, oracle):
         s.close()
 
 
+def test_synthetic_fill_beyond_2_pow_32_work_items(ctx, oracle):
+    # 12M x 384 rows = 1.15e9 float4 pieces per 32-row block column... the fill kernel covers
+    # 12M*96 = 1.15e9 (x32 lanes -> 3.7e10 work items): a launch sized in work items would wrap at 2^32
+    N = 12_000_000
+    s = pa.Searcher(ctx, 384, "cosine")
+    s.add_synthetic(1, N, 99)
+    s.finalize()
+    pos = np.array([0, 10_485_759, 10_485_760, 10_500_000, N - 33, N - 1], np.int64)
+    rows, ids = s.get_rows(pos)
+    for i, p_ in enumerate(pos):
+        np.testing.assert_array_equal(rows[i].view(np.uint32), oracle.synth_rows(99, int(p_), 1, 384)[0].view(np.uint32))
+    # a row planted by value near the end must be found: query = that row -> cosine 1 at its position
+    q = oracle.synth_rows(99, N - 5, 1, 384)
+    got, sc, _ = s.search_vectors(None, 1, q)
+    assert got[0, 0] == N - 5 and abs(sc[0, 0] - 1.0) < 1e-6
+    got64, sc64, _ = s.search_vectors(None, 1, np.repeat(q, 5, 0))
+    assert (got64[:, 0] == N - 5).all()
+    s.close()
+
+
 @pytest.mark.parametrize("B,kernel", [(1, "wave"), (4, "wave"), (8, "mfma"), (64, "mfma")])
 def test_medium_random_vs_oracle(ctx, oracle, B, kernel):
     N = 200_000 if B <= 8 else 60_000
