@@ -54,11 +54,11 @@ def cpu_baseline(args):
     n = max(10_000, args.cpu_rows)
     rows = orc.synth_rows(0x5EED, 0, n, args.dim, args.normalized)
     q = orc.synth_rows(0x5EED + 1, 0, args.batch, args.dim)
-    secs, _, _ = orc.baseline_scan(q, rows[: max(10_000, n // 20)], args.k, threads)  # calibration slice
-    rate = max(10_000, n // 20) / max(secs, 1e-9)
-    reps = int(min(50, max(1, round(12.0 * rate / n))))  # ~12 s of CPU work
-    total = 0.0
-    for _ in range(reps):
+    orc.baseline_scan(q, rows[: max(10_000, n // 10)], args.k, threads)  # warm the thread pool / caches
+    first, _, _ = orc.baseline_scan(q, rows, args.k, threads)
+    reps = int(min(400, max(1, round(12.0 / max(first, 1e-6)))))  # ~12 s of CPU work in all
+    total = first
+    for _ in range(reps - 1):
         secs, _, _ = orc.baseline_scan(q, rows, args.k, threads)
         total += secs
     return {
@@ -70,6 +70,19 @@ def cpu_baseline(args):
                   f"{total:.1f} s on {threads} threads (oracle/baseline.c)",
         "queries_per_s": args.batch * reps / total,
     }
+
+
+def measured_traffic(kernel, rows, dim):
+    """HBM bytes per launch from the committed PMC pass of this command (profiles/traffic.json,
+    written by tools/summarize_profiles.py; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 guide), scaled by
+    rows.  bench.py cannot collect PMC counters on itself; None when no pass covers this kernel."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
+        if t["dim"] != dim or not t["bytes_per_row"]:
+            return None, None
+        return t["bytes_per_row"] * rows, t["source"]
+    except Exception:
+        return None, None
 
 
 def main():
@@ -164,6 +177,8 @@ def main():
         per_launch_bytes = float(np.mean(scan_bytes))  # this rank's shard: rows * dim * 4
         achieved = per_launch_bytes / (mean_scan_ms * 1e-3) / 1e9
         ids, scores, counts = last
+        kname = "scan_mfma_kernel" if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel"
+        traffic, traffic_src = measured_traffic(kname, (hi - lo), args.dim)
         out = {
             "metric": f"vectors scanned/sec (exact cosine top-{k}, {args.dim}-d f32, batch={B})",
             "value": vectors_per_s,
@@ -191,8 +206,9 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
-                "kernel": "scan_mfma_kernel" if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel",
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "kernel": kname,
                 "bytes_per_launch": per_launch_bytes,
                 "kernel_ms": mean_scan_ms,
             },

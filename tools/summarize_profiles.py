@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of one round (gpurun_out/...) into the committed summaries under
+profiles/: kernel-stats CSVs are copied as they are; PMC passes are reduced to per-launch HBM
+traffic, corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes for gfx950
+(FETCH_SIZE counts 64 B per 128 B request on wide coalesced streaming reads: x2; WRITE_SIZE exact;
+both in KiB).
+
+    python tools/summarize_profiles.py r01
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "profiles")
+GO = os.path.join(ROOT, "gpurun_out")
+
+
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: keep only the latest run of a directory."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+def pmc_mean(dirname, counter, kernel_substr):
+    vals = []
+    for f in newest(os.path.join(GO, dirname, "*", "*_counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+                vals.append(float(row["Counter_Value"]))
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def kernel_avg_ms(dirname, kernel_substr):
+    for f in newest(os.path.join(GO, dirname, "*", "*_kernel_stats.csv")):
+        for row in csv.DictReader(open(f)):
+            if kernel_substr in row["Name"]:
+                return float(row["AverageNs"]) / 1e6, int(row["Calls"])
+    return None, 0
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    os.makedirs(OUT, exist_ok=True)
+    summary = {}
+    cases = [
+        # (label, stats dir, fetch dir, write dir, kernel, rows, dim)
+        ("100m_b64_mfma", "prof_default", "pmc_fetch", "pmc_write", "scan_mfma_kernel", 100_000_000, 384),
+        ("10m_b1_wave", "prof_10m_b1", "pmc_fetch_10m_b1", None, "scan_wave_kernel", 10_000_000, 384),
+    ]
+    for label, sdir, fdir, wdir, kern, rows, dim in cases:
+        for f in newest(os.path.join(GO, sdir, "*", "*_kernel_stats.csv")):
+            shutil.copy(f, os.path.join(OUT, f"{tag}_{label}_kernel_stats.csv"))
+        ms, calls = kernel_avg_ms(sdir, kern)
+        fetch_kib, nf = pmc_mean(fdir, "FETCH_SIZE", kern) if fdir else (None, 0)
+        write_kib, nw = pmc_mean(wdir, "WRITE_SIZE", kern) if wdir else (None, 0)
+        alg = rows * dim * 4
+        entry = {
+            "kernel": kern, "rows": rows, "dim": dim, "algorithmic_bytes_per_launch": alg,
+            "rocprof_avg_kernel_ms": ms, "rocprof_calls": calls,
+            "achieved_GBps_from_rocprof": alg / (ms * 1e-3) / 1e9 if ms else None,
+            "FETCH_SIZE_KiB_raw": fetch_kib, "FETCH_launches": nf,
+            "WRITE_SIZE_KiB_raw": write_kib, "WRITE_launches": nw,
+        }
+        if fetch_kib is not None:
+            read_b = fetch_kib * 1024 * 2.0  # gfx950 correction for 16 B/lane streaming reads
+            write_b = (write_kib or 0.0) * 1024
+            entry["hbm_read_bytes_per_launch"] = read_b
+            entry["hbm_write_bytes_per_launch"] = write_b
+            entry["traffic_bytes_per_launch"] = read_b + write_b
+            entry["traffic_over_algorithmic"] = (read_b + write_b) / alg
+            entry["traffic_bytes_per_row"] = (read_b + write_b) / rows
+        summary[label] = entry
+    with open(os.path.join(OUT, f"{tag}_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    # what bench.py reads to fill roofline.traffic (per-row figure of the newest round)
+    with open(os.path.join(OUT, "traffic.json"), "w") as f:
+        json.dump({e["kernel"]: {"bytes_per_row": e.get("traffic_bytes_per_row"), "dim": e["dim"],
+                                 "source": f"profiles/{tag}_summary.json:{k}"}
+                   for k, e in summary.items() if e.get("traffic_bytes_per_row")}, f, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
