@@ -24,7 +24,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-HIT_BYTES = 24          # sizeof(pcv_hit)
 
 
 def parse():
@@ -94,7 +93,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     dist = torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PCV_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal
+    if use_dist:
         # torch first: its bundled HIP runtime must be the one both it and libperceive_hip.so bind
         import torch
         import torch.distributed as dist
@@ -104,7 +104,7 @@ def main():
 
     import perceive_amd as pa
 
-    ctx = pa.Context(local_rank if world > 1 else 0)
+    ctx = pa.Context(local_rank if use_dist else 0)
     lo = args.rows * rank // world
     hi = args.rows * (rank + 1) // world
     searcher = pa.Searcher(ctx, args.dim, "cosine")
@@ -121,12 +121,11 @@ def main():
     queries = rng.standard_normal((args.warmup + args.steps, args.batch, args.dim)).astype(np.float32)
 
     B, k = args.batch, args.k
-    if world > 1:
-        local = torch.empty(B * k * HIT_BYTES, dtype=torch.uint8, device="cuda")
-        gathered = torch.empty(world * B * k * HIT_BYTES, dtype=torch.uint8, device="cuda")
+    if use_dist:
+        sharded = pa.ShardedSearcher(dist, "cosine", args.dim, searcher=searcher, ctx=ctx, device=True)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         ctx.synchronize()
@@ -137,13 +136,10 @@ def main():
     def step(i, timed):
         nonlocal last, reruns
         q = queries[i]
-        if world == 1:
+        if not use_dist:
             last = searcher.search_vectors(None, k, q)
-        else:
-            searcher.search_device(None, k, q, local.data_ptr())  # returns after the stream drained
-            dist.all_gather_into_tensor(gathered, local)
-            torch.cuda.current_stream().synchronize()
-            last = pa.merge_topk(ctx, "cosine", args.dim, gathered.data_ptr(), world, B, k)
+        else:  # local exact top-k -> RCCL all-gather of [B][k] hits -> merge (perceive_amd/sharded.py)
+            last = sharded.search_vectors(None, k, q)
         if timed:
             st = searcher.last_stats()
             scan_ms.append(st["scan_ms"])
@@ -160,7 +156,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -223,7 +219,7 @@ def main():
 
     searcher.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -158,6 +158,12 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
 pcv_status pcv_merge_topk(pcv_ctx* ctx, int metric, int dim, const void* d_lists, int n_shards, int n_queries,
                           int k, int64_t* out_ids, float* out_scores, int* out_counts);
 
+/* The same merge on host memory (`lists` = host pointer, same shape): the reference's own merge is
+ * host code (search.rs:179-180 sort + truncate); used when the lists were gathered on the host and
+ * by the CPU-side (gloo) tests of the multi-GPU protocol.  Needs no GPU. */
+pcv_status pcv_merge_topk_host(int metric, int dim, const pcv_hit* lists, int n_shards, int n_queries, int k,
+                               int64_t* out_ids, float* out_scores, int* out_counts);
+
 /* Brute-force similarity matrices of lib.rs:63-77 for small inputs (tests, highlight.rs:109):
  *   out[b][n] = dot(a_b, m_n)                       pcv_dot_product            (lib.rs:63-65)
  *   out[b][n] = cos(a_b, m_n)                       pcv_cosine_similarity      (lib.rs:67-77)

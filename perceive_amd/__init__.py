@@ -14,3 +14,4 @@ from .search import (  # noqa: F401
     merge_topk,
     serialize_embedding,
 )
+from .sharded import HIT_DTYPE, ShardedSearcher, merge_topk_host, shard_bounds  # noqa: F401,E402

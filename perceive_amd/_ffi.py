@@ -100,6 +100,7 @@ SYMBOLS = {
     "pcv_searcher_set_shard_offset": (C.c_int, [_P, C.c_int64]),
     "pcv_searcher_search_device": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _P, C.c_int]),
     "pcv_merge_topk": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
+    "pcv_merge_topk_host": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
     "pcv_dot_product": (C.c_int, [_P, _F32P, C.c_int, _F32P, C.c_int64, C.c_int, _F32P]),
     "pcv_cosine_similarity": (C.c_int, [_P, _F32P, C.c_int, _F32P, C.c_int64, C.c_int, _F32P]),
     "pcv_searcher_last_stats": (C.c_int, [_P, C.POINTER(ScanStats)]),

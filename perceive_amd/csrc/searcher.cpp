@@ -720,6 +720,29 @@ pcv_status pcv_merge_topk(pcv_ctx* ctx, int metric, int dim, const void* d_lists
     });
 }
 
+pcv_status pcv_merge_topk_host(int metric, int dim, const pcv_hit* lists, int n_shards, int n_queries, int k,
+                               int64_t* out_ids, float* out_scores, int* out_counts) {
+    return guarded([&] {
+        PCV_REQUIRE(lists != nullptr, "merge_topk_host: lists is NULL");
+        PCV_REQUIRE(n_shards > 0 && n_queries > 0 && k > 0 && k <= kMaxK, "merge_topk_host: bad shape");
+        static_assert(sizeof(pcv_hit) == sizeof(pcv_hit_dev), "hit layout");
+        const pcv_hit_dev* L = reinterpret_cast<const pcv_hit_dev*>(lists);
+        const pcv_hit_dev none{NAN, -1, -1};
+        std::vector<pcv_hit_dev> out((size_t)n_queries * k, none), m;
+        for (int q = 0; q < n_queries; ++q) {
+            m.clear();
+            for (int r = 0; r < n_shards; ++r)
+                for (int j = 0; j < k; ++j) {
+                    const pcv_hit_dev& e = L[((size_t)r * n_queries + q) * k + j];
+                    if (e.pos >= 0 && e.score == e.score) m.push_back(e);
+                }
+            std::sort(m.begin(), m.end(), hit_better);  // search.rs:179, canonical order
+            for (int j = 0; j < k && j < (int)m.size(); ++j) out[(size_t)q * k + j] = m[j];  // search.rs:180
+        }
+        hits_to_outputs(metric, dim, out.data(), n_queries, k, out_ids, out_scores, out_counts);
+    });
+}
+
 static pcv_status similarity(pcv_ctx* ctx, const float* a, int B, const float* m, int64_t N, int dim, float* out,
                              int cosine) {
     return guarded([&] {
