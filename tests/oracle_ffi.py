@@ -153,3 +153,72 @@ def load():
             build()
         _cached = Oracle(C.CDLL(LIB))
     return _cached
+
+
+# ---- encoder oracle (oracle/encoder.c) -----------------------------------------------------------
+class _Desc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("vocab", "hidden", "layers", "heads", "inter", "max_pos", "type_vocab")] + [
+        ("eps", C.c_float)] + [(n, C.c_int) for n in ("pooling", "normalize", "dense_out", "dense_act")]
+
+
+_PP = C.POINTER(_F)
+
+
+class _Weights(C.Structure):
+    _fields_ = [(n, _F) for n in ("word", "pos", "type", "emb_ln_w", "emb_ln_b")] + [
+        (n, _PP) for n in ("qw", "qb", "kw", "kb", "vw", "vb", "ow", "ob", "ln1w", "ln1b", "iw", "ib", "fw", "fb",
+                           "ln2w", "ln2b")] + [("dense_w", _F), ("dense_b", _F)]
+
+
+_LAYER_KEYS = {
+    "qw": "attention.self.query.weight", "qb": "attention.self.query.bias",
+    "kw": "attention.self.key.weight", "kb": "attention.self.key.bias",
+    "vw": "attention.self.value.weight", "vb": "attention.self.value.bias",
+    "ow": "attention.output.dense.weight", "ob": "attention.output.dense.bias",
+    "ln1w": "attention.output.LayerNorm.weight", "ln1b": "attention.output.LayerNorm.bias",
+    "iw": "intermediate.dense.weight", "ib": "intermediate.dense.bias",
+    "fw": "output.dense.weight", "fb": "output.dense.bias",
+    "ln2w": "output.LayerNorm.weight", "ln2b": "output.LayerNorm.bias",
+}
+
+
+def encode_tokens(self, desc, weights, ids, mask, want_hidden=False):
+    """desc: dict(vocab, hidden, layers, heads, inter, max_pos, eps, pooling, normalize, dense_out,
+    dense_act); weights: dict of HF-named f32 arrays.  Returns (out [B,OD], hidden [(layers+1),B,L,H] | None)."""
+    keep = []
+
+    def arr(name):
+        a = np.ascontiguousarray(weights[name], np.float32)
+        keep.append(a)
+        return _fp(a)
+
+    d = _Desc(desc["vocab"], desc["hidden"], desc["layers"], desc["heads"], desc["inter"], desc["max_pos"],
+              desc.get("type_vocab", 2), desc.get("eps", 1e-12), desc.get("pooling", 0), desc.get("normalize", 1),
+              desc.get("dense_out", 0), desc.get("dense_act", 0))
+    w = _Weights()
+    w.word = arr("embeddings.word_embeddings.weight")
+    w.pos = arr("embeddings.position_embeddings.weight")
+    w.type = arr("embeddings.token_type_embeddings.weight")
+    w.emb_ln_w = arr("embeddings.LayerNorm.weight")
+    w.emb_ln_b = arr("embeddings.LayerNorm.bias")
+    for field, key in _LAYER_KEYS.items():
+        ptrs = (_F * desc["layers"])(*[arr(f"encoder.layer.{i}.{key}") for i in range(desc["layers"])])
+        keep.append(ptrs)
+        setattr(w, field, C.cast(ptrs, _PP))
+    if desc.get("dense_out", 0) > 0:
+        w.dense_w = arr("dense.linear.weight")
+        w.dense_b = arr("dense.linear.bias")
+    ids = np.ascontiguousarray(ids, np.int64)
+    mask = np.ascontiguousarray(mask, np.int64)
+    B, L = ids.shape
+    od = desc.get("dense_out", 0) or desc["hidden"]
+    out = np.empty((B, od), np.float32)
+    hidden = np.empty((desc["layers"] + 1, B, L, desc["hidden"]), np.float32) if want_hidden else None
+    self.lib.orc_encode_tokens.argtypes = [C.POINTER(_Desc), C.POINTER(_Weights), _I, _I, C.c_int, C.c_int, _F, _F]
+    self.lib.orc_encode_tokens.restype = None
+    self.lib.orc_encode_tokens(C.byref(d), C.byref(w), _ip(ids), _ip(mask), B, L, _fp(hidden) if want_hidden else None,
+                               _fp(out))
+    return out, hidden
+
+
+Oracle.encode_tokens = encode_tokens
