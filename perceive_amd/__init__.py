@@ -15,3 +15,11 @@ from .search import (  # noqa: F401
     serialize_embedding,
 )
 from .sharded import HIT_DTYPE, ShardedSearcher, merge_topk_host, shard_bounds  # noqa: F401,E402
+from .model import (  # noqa: F401,E402
+    Model,
+    ModelError,
+    SentenceEmbeddingsModelType,
+    make_desc,
+    minilm_l6_desc,
+    save_weights,
+)

@@ -1,0 +1,41 @@
+// encoder.h — launcher interface of the sentence-embedding encoder kernels (encoder_kernels.hip).
+// Replaces the libtorch forward behind crates/perceive-core/model/worker.rs:78-106.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/perceive_hip.h"
+
+namespace pcv {
+
+enum GemmEpilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
+
+// C[M][N] = A[M][K] * W[N][K]^T + bias (+ GELU | + resid).  N % 128 == 0, K % 32 == 0.
+// exact f32 on v_mfma_f32_32x32x2_f32.
+void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float* bias, const float* resid, float* C,
+                     int M, int N, int K, int epilogue);
+
+// tokens -> embeddings + LayerNorm; also converts the int64 mask to the additive float mask
+// (1-m)*-10000 used by the attention kernel and to a float 0/1 mask for pooling.
+void launch_embed_ln(hipStream_t st, const int64_t* ids, const int64_t* mask, int B, int L, int H, int vocab,
+                     const float* word, const float* pos, const float* type, const float* ln_w, const float* ln_b,
+                     float eps, float* hidden, float* mask_add, float* mask01);
+
+// in-place LayerNorm over rows of x[T][H]
+void launch_layer_norm(hipStream_t st, float* x, int T, int H, const float* w, const float* b, float eps);
+
+// softmax(QK^T/sqrt(hd) + mask) V for every (batch, head): qkv[T][3H] -> ctx[T][H]; head_dim 32 or 64
+void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int H,
+                      int heads);
+
+// pooling (mean | cls | max | mean_sqrt_len) + optional L2 normalisation (worker.rs:88-103)
+void launch_pool(hipStream_t st, const float* hidden, const float* mask01, int B, int L, int H, int mode,
+                 int normalize, float* out);
+// optional Dense module: y = act(W x + b), then optional normalisation
+void launch_dense(hipStream_t st, const float* x, const float* W, const float* b, int B, int in, int out, int act,
+                  int normalize, float* y);
+
+void launch_synth_weights(hipStream_t st, float* dst, int64_t n, uint64_t seed, uint32_t tensor_index, float scale,
+                          float offset);
+
+}  // namespace pcv

@@ -1,0 +1,473 @@
+// encoder_kernels.hip — gfx950 kernels of the sentence-embedding forward pass (replaces the
+// libtorch forward behind model/worker.rs:78-106: BERT-family encoder, pooling, normalisation).
+//
+// Numerics: f32 end to end like the reference (tch default dtype, no autocast).  Every contraction
+// runs on the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain in k
+// order), so the result differs from a CPU f32 evaluation only by summation order.
+#include "encoder.h"
+#include "synth.h"
+
+namespace pcv {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D-layout of a 32x32 accumulator: register r of lane (c = lane&31, h = lane>>5) is element
+// [row = (r&3) + 8*(r>>2) + 4*h][col = c].
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM: C[M][N] = A[M][K] W[N][K]^T + bias (+GELU | +residual)
+// 128x128 output tile per 256-thread workgroup, K in steps of 32 through LDS (rows padded to 36
+// floats: the 16-lane ds_read_b128 groups then cover all 64 banks), 4 waves as 2x2, each wave
+// 2x2 MFMA tiles of 32x32.  The k index inside a 32-wide step is assigned as k = 16*(lane>>5) + s
+// for both operands, so a lane's 16 operand values are 64 contiguous bytes (4 x ds_read_b128).
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, float* __restrict__ C, int M,
+                                                       int N, int K) {
+    __shared__ float As[BM * LDT];
+    __shared__ float Ws[BN * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // staging: thread t moves float4 (row = (t>>3) + 32*u, 16-byte column c4 = t&7), u = 0..3
+    const int srow = tid >> 3, c4 = tid & 7;
+    const float* ag[4];
+    const float* wg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ar = min(m0 + srow + 32 * u, M - 1);
+        ag[u] = A + (size_t)ar * K + c4 * 4;
+        wg[u] = W + (size_t)(n0 + srow + 32 * u) * K + c4 * 4;
+    }
+    f32x4 ra[4], rw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        ra[u] = *(const f32x4*)(ag[u]);
+        rw[u] = *(const f32x4*)(wg[u]);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *(f32x4*)&As[(srow + 32 * u) * LDT + c4 * 4] = ra[u];
+            *(f32x4*)&Ws[(srow + 32 * u) * LDT + c4 * 4] = rw[u];
+        }
+        __syncthreads();
+        {  // next step's global loads fly under this step's MFMAs (the last step re-reads its own
+           // tile instead of branching: a conditional load made the compiler park the staging
+           // registers in scratch)
+            const size_t koff = (size_t)min(kt + 1, nk - 1) * BK;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ra[u] = *(const f32x4*)(ag[u] + koff);
+                rw[u] = *(const f32x4*)(wg[u] + koff);
+            }
+        }
+        float af[2][16], bf[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* ap = &As[(wr * 64 + t * 32 + i) * LDT + 16 * kk];
+            const float* bp = &Ws[(wc * 64 + t * 32 + i) * LDT + 16 * kk];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 x = *(const f32x4*)(ap + 4 * v);
+                const f32x4 y = *(const f32x4*)(bp + 4 * v);
+                af[t][4 * v + 0] = x.x; af[t][4 * v + 1] = x.y; af[t][4 * v + 2] = x.z; af[t][4 * v + 3] = x.w;
+                bf[t][4 * v + 0] = y.x; bf[t][4 * v + 1] = y.y; bf[t][4 * v + 2] = y.z; bf[t][4 * v + 3] = y.w;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
+    }
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wc * 64 + b * 32 + i;
+            const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + a * 32 + acc_row(r, kk);
+                if (row < M) {
+                    float v = acc[a][b][r] + bv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
+                    C[(size_t)row * N + col] = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm helpers: one wave per token row, H/64 values per lane (H <= 1024)
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxPerLane = 16;
+
+__device__ __forceinline__ void ln_row(float (&v)[kMaxPerLane], int n_per_lane, int H, int lane,
+                                       const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                       float* __restrict__ dst) {
+    float s = 0.0f;
+    for (int j = 0; j < n_per_lane; ++j) s += v[j];
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.0f;
+    for (int j = 0; j < n_per_lane; ++j) {
+        const int c = lane + 64 * j;
+        const float d = c < H ? v[j] - mean : 0.0f;
+        q += d * d;
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+    for (int j = 0; j < n_per_lane; ++j) {
+        const int c = lane + 64 * j;
+        if (c < H) dst[c] = (v[j] - mean) * inv * w[c] + b[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict__ ids,
+                                                       const int64_t* __restrict__ mask, int B, int L, int Lp, int H,
+                                                       int vocab, const float* __restrict__ word,
+                                                       const float* __restrict__ pos, const float* __restrict__ type,
+                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                       float eps, float* __restrict__ hidden,
+                                                       float* __restrict__ mask_add, float* __restrict__ mask01) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);  // token slot in the padded [B][Lp] grid
+    if (t >= B * Lp) return;
+    const int b = t / Lp, l = t - b * Lp;
+    if (l >= L) {  // padding keys of the last 32-key tile: excluded from every softmax
+        if (lane == 0) mask_add[t] = -__builtin_inff();
+        return;
+    }
+    const int tok = b * L + l;
+    if (lane == 0) {
+        const float m = (float)mask[tok];
+        mask_add[t] = (1.0f - m) * -10000.0f;  // rust-bert BertModel: additive attention mask
+        mask01[tok] = m;
+    }
+    int64_t id = ids[tok];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* we = word + (size_t)id * H;
+    const float* pe = pos + (size_t)l * H;
+    float v[kMaxPerLane];
+    const int npl = (H + 63) / 64;
+    for (int j = 0; j < npl; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = c < H ? we[c] + pe[c] + type[c] : 0.0f;
+    }
+    ln_row(v, npl, H, lane, ln_w, ln_b, eps, hidden + (size_t)tok * H);
+}
+
+__global__ __launch_bounds__(256) void layer_norm_kernel(float* __restrict__ x, int T, int H,
+                                                         const float* __restrict__ w, const float* __restrict__ b,
+                                                         float eps) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    float* row = x + (size_t)t * H;
+    float v[kMaxPerLane];
+    const int npl = (H + 63) / 64;
+    for (int j = 0; j < npl; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = c < H ? row[c] : 0.0f;
+    }
+    ln_row(v, npl, H, lane, w, b, eps, row);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention: one wave per (batch, head, 32-query block), online softmax over chunks of 128 keys.
+// S^T = K Q^T is computed so that the query sits on the lane and the keys in the accumulator
+// registers: row max / sum are in-register reductions plus one cross-half exchange, and the
+// probabilities are, as they stand, the A operand of the P V product (k index = key).
+// ------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
+                                                        const float* __restrict__ mask_add, float* __restrict__ ctx,
+                                                        int B, int L, int Lp, int H) {
+    constexpr int KS = HD / 2;   // k-steps of the QK^T product; also floats of a row held per lane
+    constexpr int CT = HD / 32;  // 32-wide column tiles of the output
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int qb = blockIdx.x * 4 + wave, head = blockIdx.y, b = blockIdx.z;
+    if (qb * 32 >= L) return;
+    const int H3 = 3 * H;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const float ninf = -__builtin_inff();
+
+    const int qrow = min(qb * 32 + i, L - 1);
+    const float* qp = qkv + (size_t)(b * L + qrow) * H3 + head * HD + KS * h;
+    float qf[KS];
+#pragma unroll
+    for (int v = 0; v < KS / 4; ++v) {
+        const float4 x = *(const float4*)(qp + 4 * v);
+        qf[4 * v] = x.x; qf[4 * v + 1] = x.y; qf[4 * v + 2] = x.z; qf[4 * v + 3] = x.w;
+    }
+
+    float m_run = ninf, l_run = 0.0f;
+    f32x16 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.0f;
+
+    for (int k0 = 0; k0 < L; k0 += 128) {
+        f32x16 s[4];
+        float mc = ninf;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kt = k0 + 32 * t;
+            if (kt >= L) {  // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = ninf;
+                continue;
+            }
+            const int krow = min(kt + i, L - 1);
+            const float* kp = qkv + (size_t)(b * L + krow) * H3 + H + head * HD + KS * h;
+            float kf[KS];
+#pragma unroll
+            for (int v = 0; v < KS / 4; ++v) {
+                const float4 x = *(const float4*)(kp + 4 * v);
+                kf[4 * v] = x.x; kf[4 * v + 1] = x.y; kf[4 * v + 2] = x.z; kf[4 * v + 3] = x.w;
+            }
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+#pragma unroll
+            for (int e = 0; e < KS; ++e) a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[e], a, 0, 0, 0);
+            const float* mp = mask_add + (size_t)b * Lp + kt + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 ma = *(const float4*)(mp + 8 * g);  // keys kt + 8g + 4h + 0..3 (-inf beyond L)
+                s[t][4 * g + 0] = a[4 * g + 0] * scale + ma.x;
+                s[t][4 * g + 1] = a[4 * g + 1] * scale + ma.y;
+                s[t][4 * g + 2] = a[4 * g + 2] * scale + ma.z;
+                s[t][4 * g + 3] = a[4 * g + 3] * scale + ma.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mc = fmaxf(mc, s[t][r]);
+        }
+        mc = fmaxf(mc, __shfl_xor(mc, 32));
+        const float m_new = fmaxf(m_run, mc);
+        const float factor = (m_run == ninf) ? 0.0f : expf(m_run - m_new);
+        float lc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = (s[t][r] == ninf) ? 0.0f : expf(s[t][r] - m_new);
+                s[t][r] = p;
+                lc += p;
+            }
+        lc += __shfl_xor(lc, 32);
+        l_run = l_run * factor + lc;
+        m_run = m_new;
+        // rescale the running output: its rows are queries acc_row(r,h), whose factor sits on that lane
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float fr = __shfl(factor, acc_row(r, h));
+#pragma unroll
+            for (int c = 0; c < CT; ++c) o[c][r] *= fr;
+        }
+        // O += P V : k index = key acc_row(r,h) of tile t; B operand = V[key][32c + i]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kt = k0 + 32 * t;
+            if (kt >= L) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = min(kt + acc_row(r, h), L - 1);  // clamped keys carry p = 0
+                const float* vp = qkv + (size_t)(b * L + key) * H3 + 2 * H + head * HD + i;
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[t][r], vp[32 * c], o[c], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = acc_row(r, h);
+        const float linv = 1.0f / __shfl(l_run, q);
+        const int row = qb * 32 + q;
+        if (row < L) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) ctx[(size_t)(b * L + row) * H + head * HD + 32 * c + i] = o[c][r] * linv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling + normalisation (worker.rs:88-103), one workgroup per sequence
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hidden, const float* __restrict__ mask01,
+                                                   int L, int H, int mode, int normalize, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* hb = hidden + (size_t)b * L * H;
+    const float* mb = mask01 + (size_t)b * L;
+    float msum = 0.0f;
+    for (int l = tid; l < L; l += 256) msum += mb[l];
+    msum = block_sum(msum, red);
+    const float den = fmaxf(msum, 1e-9f);  // clamp_min(1e-9) of rust-bert's mean pooling
+    float vals[4];                         // H <= 1024
+    float ss = 0.0f;
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid + 256 * j;
+        float v = 0.0f;
+        if (c < H) {
+            if (mode == PCV_POOL_CLS) {
+                v = hb[c];
+            } else if (mode == PCV_POOL_MAX) {
+                v = -__builtin_inff();
+                for (int l = 0; l < L; ++l) v = fmaxf(v, mb[l] != 0.0f ? hb[(size_t)l * H + c] : -1e9f);
+            } else {
+                float s = 0.0f;
+                for (int l = 0; l < L; ++l) s += hb[(size_t)l * H + c] * mb[l];
+                v = mode == PCV_POOL_MEAN_SQRT_LEN ? s / sqrtf(den) : s / den;
+            }
+        }
+        vals[j] = v;
+        ss += c < H ? v * v : 0.0f;
+    }
+    float inv = 1.0f;
+    if (normalize) {  // x / clamp_min(||x||, 1e-12), worker.rs:95-103
+        const float nrm = sqrtf(block_sum(ss, red));
+        inv = 1.0f / fmaxf(nrm, 1e-12f);
+    }
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid + 256 * j;
+        if (c < H) out[(size_t)b * H + c] = normalize ? vals[j] * inv : vals[j];
+    }
+}
+
+// Dense module (worker.rs:90-94): one workgroup per sequence, thread per output feature
+__global__ __launch_bounds__(256) void dense_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                    const float* __restrict__ bvec, int in, int out, int act,
+                                                    int normalize, float* __restrict__ y) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xb = x + (size_t)b * in;
+    float vals[4];
+    float ss = 0.0f;
+    for (int j = 0; j < 4; ++j) {
+        const int o = tid + 256 * j;
+        float v = 0.0f;
+        if (o < out) {
+            const float* wr = W + (size_t)o * in;
+            for (int c = 0; c < in; ++c) v = fmaf(xb[c], wr[c], v);
+            v += bvec ? bvec[o] : 0.0f;
+            if (act == PCV_ACT_TANH) v = tanhf(v);
+            ss += v * v;
+        }
+        vals[j] = v;
+    }
+    float inv = 1.0f;
+    if (normalize) inv = 1.0f / fmaxf(sqrtf(block_sum(ss, red)), 1e-12f);
+    for (int j = 0; j < 4; ++j) {
+        const int o = tid + 256 * j;
+        if (o < out) y[(size_t)b * out + o] = normalize ? vals[j] * inv : vals[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void synth_weights_kernel(float* __restrict__ dst, int64_t n, uint64_t seed,
+                                                            uint32_t tensor_index, float scale, float offset) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one float4 piece per thread
+    if (p * 4 >= n) return;
+    const float4 v = synth_piece(seed, (int64_t)tensor_index, (uint32_t)p);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int j = 0; j < 4; ++j)
+        if (p * 4 + j < n) dst[p * 4 + j] = offset + scale * vv[j];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float* bias, const float* resid, float* C,
+                     int M, int N, int K, int epilogue) {
+    if (M <= 0) return;
+    dim3 grid(N / BN, (M + BM - 1) / BM);
+    switch (epilogue) {
+        case EPI_BIAS_GELU: gemm_f32_kernel<EPI_BIAS_GELU><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K); break;
+        case EPI_BIAS_RESIDUAL:
+            gemm_f32_kernel<EPI_BIAS_RESIDUAL><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K);
+            break;
+        default: gemm_f32_kernel<EPI_BIAS><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K); break;
+    }
+}
+
+void launch_embed_ln(hipStream_t st, const int64_t* ids, const int64_t* mask, int B, int L, int H, int vocab,
+                     const float* word, const float* pos, const float* type, const float* ln_w, const float* ln_b,
+                     float eps, float* hidden, float* mask_add, float* mask01) {
+    const int Lp = (L + 31) / 32 * 32;
+    embed_ln_kernel<<<(B * Lp + 3) / 4, 256, 0, st>>>(ids, mask, B, L, Lp, H, vocab, word, pos, type, ln_w, ln_b, eps,
+                                                      hidden, mask_add, mask01);
+}
+
+void launch_layer_norm(hipStream_t st, float* x, int T, int H, const float* w, const float* b, float eps) {
+    layer_norm_kernel<<<(T + 3) / 4, 256, 0, st>>>(x, T, H, w, b, eps);
+}
+
+void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int H,
+                      int heads) {
+    const int Lp = (L + 31) / 32 * 32;
+    dim3 grid((Lp / 32 + 3) / 4, heads, B);
+    if (H / heads == 32)
+        attention_kernel<32><<<grid, 256, 0, st>>>(qkv, mask_add, ctx, B, L, Lp, H);
+    else
+        attention_kernel<64><<<grid, 256, 0, st>>>(qkv, mask_add, ctx, B, L, Lp, H);
+}
+
+void launch_pool(hipStream_t st, const float* hidden, const float* mask01, int B, int L, int H, int mode,
+                 int normalize, float* out) {
+    pool_kernel<<<B, 256, 0, st>>>(hidden, mask01, L, H, mode, normalize, out);
+}
+
+void launch_dense(hipStream_t st, const float* x, const float* W, const float* b, int B, int in, int out, int act,
+                  int normalize, float* y) {
+    dense_kernel<<<B, 256, 0, st>>>(x, W, b, in, out, act, normalize, y);
+}
+
+void launch_synth_weights(hipStream_t st, float* dst, int64_t n, uint64_t seed, uint32_t tensor_index, float scale,
+                          float offset) {
+    if (n <= 0) return;
+    synth_weights_kernel<<<(unsigned)((n / 4 + 256) / 256), 256, 0, st>>>(dst, n, seed, tensor_index, scale, offset);
+}
+
+}  // namespace pcv

@@ -1,7 +1,281 @@
-// model.cpp — Model C ABI (model.rs:56-191, worker.rs:78-106).  Encoder kernels: encoder_kernels.hip.
+// model.cpp — Model C ABI: weights, workspace and the forward pass orchestration
+// (replaces model.rs:56-191 + model/worker.rs:78-106 of the reference; kernels: encoder_kernels.hip).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "common.h"
+#include "encoder.h"
 
 using namespace pcv;
+
+namespace {
+
+struct Tensor {
+    float* p = nullptr;
+    int64_t n = 0;
+};
+
+struct Layer {
+    Tensor qkv_w, qkv_b;  // fused [3H][H], [3H]: rows 0..H = query, H..2H = key, 2H..3H = value
+    Tensor ao_w, ao_b, ln1_w, ln1_b;
+    Tensor i_w, i_b, f_w, f_b, ln2_w, ln2_b;
+};
+
+}  // namespace
+
+struct pcv_model {
+    pcv_ctx* ctx = nullptr;
+    pcv_model_desc d{};
+    Tensor word, pos, type, eln_w, eln_b, dense_w, dense_b;
+    std::vector<Layer> layers;
+    // name -> (device pointer, element count): HF / rust-bert tensor names
+    std::map<std::string, Tensor> table;
+    std::vector<float*> owned;
+    std::mutex mu;
+    pcv_encode_stats stats{};
+
+    // workspace, grown on demand
+    int64_t cap_tokens = 0, cap_batch = 0;
+    int64_t* d_ids = nullptr;
+    int64_t* d_mask = nullptr;
+    float *hidden = nullptr, *qkv = nullptr, *ctxbuf = nullptr, *tmp = nullptr, *ff = nullptr;
+    float *mask_add = nullptr, *mask01 = nullptr, *pooled = nullptr, *out = nullptr;
+    float* dbg = nullptr;  // [(layers+1)][T][H] of the last encode when it is small
+    int64_t dbg_tokens = 0;
+    int last_B = 0, last_L = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+constexpr int64_t kDebugTokenLimit = 16384;
+
+Tensor alloc_tensor(pcv_model* m, int64_t n) {
+    Tensor t;
+    t.n = n;
+    PCV_HIP(hipMalloc((void**)&t.p, (size_t)n * sizeof(float)));
+    m->owned.push_back(t.p);
+    return t;
+}
+
+void reg(pcv_model* m, const std::string& name, float* p, int64_t n) { m->table[name] = Tensor{p, n}; }
+
+void build_tensors(pcv_model* m) {
+    const pcv_model_desc& d = m->d;
+    const int64_t H = d.hidden, F = d.intermediate;
+    m->word = alloc_tensor(m, (int64_t)d.vocab_size * H);
+    m->pos = alloc_tensor(m, (int64_t)d.max_positions * H);
+    m->type = alloc_tensor(m, (int64_t)d.type_vocab * H);
+    m->eln_w = alloc_tensor(m, H);
+    m->eln_b = alloc_tensor(m, H);
+    reg(m, "embeddings.word_embeddings.weight", m->word.p, m->word.n);
+    reg(m, "embeddings.position_embeddings.weight", m->pos.p, m->pos.n);
+    reg(m, "embeddings.token_type_embeddings.weight", m->type.p, m->type.n);
+    reg(m, "embeddings.LayerNorm.weight", m->eln_w.p, H);
+    reg(m, "embeddings.LayerNorm.bias", m->eln_b.p, H);
+    m->layers.resize(d.layers);
+    for (int i = 0; i < d.layers; ++i) {
+        Layer& L = m->layers[i];
+        L.qkv_w = alloc_tensor(m, 3 * H * H);
+        L.qkv_b = alloc_tensor(m, 3 * H);
+        L.ao_w = alloc_tensor(m, H * H);
+        L.ao_b = alloc_tensor(m, H);
+        L.ln1_w = alloc_tensor(m, H);
+        L.ln1_b = alloc_tensor(m, H);
+        L.i_w = alloc_tensor(m, F * H);
+        L.i_b = alloc_tensor(m, F);
+        L.f_w = alloc_tensor(m, H * F);
+        L.f_b = alloc_tensor(m, H);
+        L.ln2_w = alloc_tensor(m, H);
+        L.ln2_b = alloc_tensor(m, H);
+        const std::string p = "encoder.layer." + std::to_string(i) + ".";
+        reg(m, p + "attention.self.query.weight", L.qkv_w.p, H * H);
+        reg(m, p + "attention.self.key.weight", L.qkv_w.p + H * H, H * H);
+        reg(m, p + "attention.self.value.weight", L.qkv_w.p + 2 * H * H, H * H);
+        reg(m, p + "attention.self.query.bias", L.qkv_b.p, H);
+        reg(m, p + "attention.self.key.bias", L.qkv_b.p + H, H);
+        reg(m, p + "attention.self.value.bias", L.qkv_b.p + 2 * H, H);
+        reg(m, p + "attention.output.dense.weight", L.ao_w.p, H * H);
+        reg(m, p + "attention.output.dense.bias", L.ao_b.p, H);
+        reg(m, p + "attention.output.LayerNorm.weight", L.ln1_w.p, H);
+        reg(m, p + "attention.output.LayerNorm.bias", L.ln1_b.p, H);
+        reg(m, p + "intermediate.dense.weight", L.i_w.p, F * H);
+        reg(m, p + "intermediate.dense.bias", L.i_b.p, F);
+        reg(m, p + "output.dense.weight", L.f_w.p, H * F);
+        reg(m, p + "output.dense.bias", L.f_b.p, H);
+        reg(m, p + "output.LayerNorm.weight", L.ln2_w.p, H);
+        reg(m, p + "output.LayerNorm.bias", L.ln2_b.p, H);
+    }
+    if (d.dense_out > 0) {
+        m->dense_w = alloc_tensor(m, (int64_t)d.dense_out * H);
+        m->dense_b = alloc_tensor(m, d.dense_out);
+        reg(m, "dense.linear.weight", m->dense_w.p, m->dense_w.n);
+        reg(m, "dense.linear.bias", m->dense_b.p, m->dense_b.n);
+    }
+}
+
+// Seeded synthetic weights (no checkpoint exists offline): BERT-like scales, non-trivial LayerNorm
+// and biases so that every term of the forward matters.  Tensor order = name order of the table.
+void fill_synthetic(pcv_model* m, uint64_t seed) {
+    uint32_t idx = 0;
+    for (auto& kv : m->table) {
+        const std::string& name = kv.first;
+        float scale = 0.05f, offset = 0.0f;
+        if (name.find("LayerNorm.weight") != std::string::npos) {
+            scale = 0.1f;
+            offset = 1.0f;
+        } else if (name.size() >= 4 && name.compare(name.size() - 4, 4, "bias") == 0) {
+            scale = 0.05f;
+        } else if (name.find("embeddings") != std::string::npos) {
+            scale = 0.5f;
+        }
+        launch_synth_weights(m->ctx->stream, kv.second.p, kv.second.n, seed, idx++, scale, offset);
+    }
+    PCV_HIP(hipStreamSynchronize(m->ctx->stream));
+    PCV_HIP(hipGetLastError());
+}
+
+// flat weight file: "PCVW0001", u32 count, then { u32 name_len, name, u64 numel, f32[numel] } (LE)
+void load_weight_file(pcv_model* m, const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) PCV_FAIL(PCV_ERR_IO, "cannot open weight file %s", path);
+    auto fail = [&](const char* what) {
+        std::fclose(f);
+        PCV_FAIL(PCV_ERR_IO, "weight file %s: %s", path, what);
+    };
+    char magic[8];
+    uint32_t count = 0;
+    if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "PCVW0001", 8) != 0) fail("bad magic");
+    if (std::fread(&count, 4, 1, f) != 1) fail("truncated header");
+    std::vector<float> buf;
+    size_t seen = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        uint32_t nl = 0;
+        uint64_t numel = 0;
+        if (std::fread(&nl, 4, 1, f) != 1 || nl > 4096) fail("bad tensor name length");
+        std::string name(nl, '\0');
+        if (std::fread(&name[0], 1, nl, f) != nl || std::fread(&numel, 8, 1, f) != 1) fail("truncated entry");
+        auto it = m->table.find(name);
+        if (it == m->table.end()) {  // tensors this architecture does not use (e.g. pooler, position_ids)
+            if (std::fseek(f, (long)(numel * 4), SEEK_CUR) != 0) fail("truncated data");
+            continue;
+        }
+        if ((int64_t)numel != it->second.n) {
+            std::fclose(f);
+            PCV_FAIL(PCV_ERR_IO, "weight file %s: tensor %s has %llu elements, model expects %lld", path, name.c_str(),
+                     (unsigned long long)numel, (long long)it->second.n);
+        }
+        buf.resize(numel);
+        if (std::fread(buf.data(), 4, numel, f) != numel) fail("truncated data");
+        PCV_HIP(hipMemcpy(it->second.p, buf.data(), numel * 4, hipMemcpyHostToDevice));
+        ++seen;
+    }
+    std::fclose(f);
+    if (seen != m->table.size())
+        PCV_FAIL(PCV_ERR_IO, "weight file %s provides %zu of the %zu tensors the model needs", path, seen,
+                 m->table.size());
+}
+
+void free_workspace(pcv_model* m) {
+    for (void* p : {(void*)m->d_ids, (void*)m->d_mask, (void*)m->hidden, (void*)m->qkv, (void*)m->ctxbuf, (void*)m->tmp,
+                    (void*)m->ff, (void*)m->mask_add, (void*)m->mask01, (void*)m->pooled, (void*)m->out, (void*)m->dbg})
+        if (p) hipFree(p);
+    m->d_ids = m->d_mask = nullptr;
+    m->hidden = m->qkv = m->ctxbuf = m->tmp = m->ff = m->mask_add = m->mask01 = m->pooled = m->out = m->dbg = nullptr;
+    m->cap_tokens = m->cap_batch = 0;
+}
+
+void ensure_workspace(pcv_model* m, int B, int L) {
+    const int64_t T = (int64_t)B * L;
+    const int64_t Tp = (int64_t)B * ((L + 31) / 32 * 32);
+    if (Tp <= m->cap_tokens && B <= m->cap_batch) return;
+    free_workspace(m);
+    const int64_t H = m->d.hidden, F = m->d.intermediate;
+    const int64_t OD = m->d.dense_out > 0 ? m->d.dense_out : H;
+    PCV_HIP(hipMalloc((void**)&m->d_ids, T * 8));
+    PCV_HIP(hipMalloc((void**)&m->d_mask, T * 8));
+    PCV_HIP(hipMalloc((void**)&m->hidden, T * H * 4));
+    PCV_HIP(hipMalloc((void**)&m->qkv, T * 3 * H * 4));
+    PCV_HIP(hipMalloc((void**)&m->ctxbuf, T * H * 4));
+    PCV_HIP(hipMalloc((void**)&m->tmp, T * H * 4));
+    PCV_HIP(hipMalloc((void**)&m->ff, T * F * 4));
+    PCV_HIP(hipMalloc((void**)&m->mask_add, Tp * 4));
+    PCV_HIP(hipMalloc((void**)&m->mask01, T * 4));
+    PCV_HIP(hipMalloc((void**)&m->pooled, (int64_t)B * H * 4));
+    PCV_HIP(hipMalloc((void**)&m->out, (int64_t)B * OD * 4));
+    if (T <= kDebugTokenLimit) PCV_HIP(hipMalloc((void**)&m->dbg, (int64_t)(m->d.layers + 1) * T * H * 4));
+    m->cap_tokens = Tp;
+    m->cap_batch = B;
+}
+
+// worker.rs:78-106 on the device.  Leaves [B][out_dim] in m->out.
+void forward(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L) {
+    const pcv_model_desc& d = m->d;
+    const int H = d.hidden, F = d.intermediate;
+    const int T = B * L;
+    hipStream_t st = m->ctx->stream;
+    ensure_workspace(m, B, L);
+    // Tensor::stack(ids/masks).to(device), worker.rs:82-83
+    PCV_HIP(hipMemcpyAsync(m->d_ids, ids, (size_t)T * 8, hipMemcpyHostToDevice, st));
+    PCV_HIP(hipMemcpyAsync(m->d_mask, mask, (size_t)T * 8, hipMemcpyHostToDevice, st));
+    PCV_HIP(hipEventRecord(m->ev0, st));
+    launch_embed_ln(st, m->d_ids, m->d_mask, B, L, H, d.vocab_size, m->word.p, m->pos.p, m->type.p, m->eln_w.p,
+                    m->eln_b.p, d.layer_norm_eps, m->hidden, m->mask_add, m->mask01);
+    const bool dbg = m->dbg != nullptr && T <= kDebugTokenLimit;
+    auto snap = [&](int layer) {
+        if (dbg)
+            PCV_HIP(hipMemcpyAsync(m->dbg + (size_t)layer * T * H, m->hidden, (size_t)T * H * 4,
+                                   hipMemcpyDeviceToDevice, st));
+    };
+    snap(0);
+    for (int ly = 0; ly < d.layers; ++ly) {
+        const Layer& W = m->layers[ly];
+        launch_gemm_f32(st, m->hidden, W.qkv_w.p, W.qkv_b.p, nullptr, m->qkv, T, 3 * H, H, EPI_BIAS);
+        launch_attention(st, m->qkv, m->mask_add, m->ctxbuf, B, L, H, d.heads);
+        launch_gemm_f32(st, m->ctxbuf, W.ao_w.p, W.ao_b.p, m->hidden, m->tmp, T, H, H, EPI_BIAS_RESIDUAL);
+        launch_layer_norm(st, m->tmp, T, H, W.ln1_w.p, W.ln1_b.p, d.layer_norm_eps);
+        launch_gemm_f32(st, m->tmp, W.i_w.p, W.i_b.p, nullptr, m->ff, T, F, H, EPI_BIAS_GELU);
+        launch_gemm_f32(st, m->ff, W.f_w.p, W.f_b.p, m->tmp, m->hidden, T, H, F, EPI_BIAS_RESIDUAL);
+        launch_layer_norm(st, m->hidden, T, H, W.ln2_w.p, W.ln2_b.p, d.layer_norm_eps);
+        snap(ly + 1);
+    }
+    if (d.dense_out > 0) {
+        launch_pool(st, m->hidden, m->mask01, B, L, H, d.pooling, 0, m->pooled);
+        launch_dense(st, m->pooled, m->dense_w.p, m->dense_b.p, B, H, d.dense_out, d.dense_activation, d.normalize,
+                     m->out);
+    } else {
+        launch_pool(st, m->hidden, m->mask01, B, L, H, d.pooling, d.normalize, m->out);
+    }
+    PCV_HIP(hipEventRecord(m->ev1, st));
+    m->dbg_tokens = dbg ? T : 0;
+    m->last_B = B;
+    m->last_L = L;
+}
+
+void check_tokens(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L) {
+    PCV_REQUIRE(m != nullptr && ids != nullptr && mask != nullptr, "encode_tokens: NULL argument");
+    PCV_REQUIRE(B > 0 && L > 0, "encode_tokens: empty batch (B=%d, L=%d)", B, L);
+    PCV_REQUIRE(L <= m->d.max_positions, "encode_tokens: sequence length %d exceeds max_position_embeddings %d", L,
+                m->d.max_positions);
+    PCV_REQUIRE((int64_t)B * L < ((int64_t)1 << 31), "encode_tokens: batch of %d x %d tokens is too large", B, L);
+}
+
+void finish_stats(pcv_model* m) {
+    float ms = 0.0f;
+    hipEventElapsedTime(&ms, m->ev0, m->ev1);
+    const double H = m->d.hidden, F = m->d.intermediate, L = m->last_L, T = (double)m->last_B * m->last_L;
+    m->stats.total_ms = ms;
+    m->stats.flops = T * m->d.layers * (8.0 * H * H + 4.0 * H * F + 4.0 * L * H);
+    m->stats.batch = m->last_B;
+    m->stats.seq_len = m->last_L;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -23,17 +297,150 @@ void pcv_model_desc_minilm_l6(pcv_model_desc* d) {
     d->compute = PCV_COMPUTE_F32;
 }
 
-#define PCV_TODO(name)                                                        \
-    return guarded([&] { PCV_FAIL(PCV_ERR_UNSUPPORTED, name ": encoder not built yet"); })
+pcv_status pcv_model_create(pcv_ctx* ctx, const pcv_model_desc* desc, const char* weights_path,
+                            uint64_t synthetic_seed, pcv_model** out) {
+    return guarded([&] {
+        PCV_REQUIRE(ctx != nullptr && desc != nullptr && out != nullptr, "model_create: NULL argument");
+        *out = nullptr;
+        const pcv_model_desc& d = *desc;
+        PCV_REQUIRE(d.hidden > 0 && d.layers > 0 && d.heads > 0 && d.intermediate > 0 && d.vocab_size > 0 &&
+                        d.max_positions > 0 && d.type_vocab > 0,
+                    "model_create: non-positive dimension in the model description");
+        if (d.hidden % 128 != 0 || d.intermediate % 128 != 0 || d.hidden > 1024)
+            PCV_FAIL(PCV_ERR_UNSUPPORTED, "model_create: hidden %d / intermediate %d must be multiples of 128 (hidden <= 1024)",
+                     d.hidden, d.intermediate);
+        if (d.hidden % d.heads != 0 || (d.hidden / d.heads != 32 && d.hidden / d.heads != 64))
+            PCV_FAIL(PCV_ERR_UNSUPPORTED, "model_create: head dimension %d not supported (32 or 64)",
+                     d.heads ? d.hidden / d.heads : 0);
+        PCV_REQUIRE(d.pooling >= PCV_POOL_MEAN && d.pooling <= PCV_POOL_MEAN_SQRT_LEN, "model_create: unknown pooling %d",
+                    d.pooling);
+        PCV_REQUIRE(d.dense_out >= 0 && d.dense_out <= 1024, "model_create: dense_out %d outside [0,1024]", d.dense_out);
+        if (d.compute != PCV_COMPUTE_F32)
+            PCV_FAIL(PCV_ERR_UNSUPPORTED, "model_create: only PCV_COMPUTE_F32 is implemented");
+        PCV_HIP(hipSetDevice(ctx->device));
+        auto* m = new pcv_model();
+        m->ctx = ctx;
+        m->d = d;
+        try {
+            build_tensors(m);
+            PCV_HIP(hipEventCreate(&m->ev0));
+            PCV_HIP(hipEventCreate(&m->ev1));
+            if (weights_path && weights_path[0])
+                load_weight_file(m, weights_path);
+            else
+                fill_synthetic(m, synthetic_seed);
+        } catch (...) {
+            pcv_model_destroy(m);
+            throw;
+        }
+        *out = m;
+    });
+}
 
-pcv_status pcv_model_create(pcv_ctx*, const pcv_model_desc*, const char*, uint64_t, pcv_model**) { PCV_TODO("pcv_model_create"); }
-pcv_status pcv_model_destroy(pcv_model*) { return PCV_OK; }
-pcv_status pcv_model_output_dim(pcv_model*, int*) { PCV_TODO("pcv_model_output_dim"); }
-pcv_status pcv_model_set_tensor(pcv_model*, const char*, const float*, int64_t) { PCV_TODO("pcv_model_set_tensor"); }
-pcv_status pcv_model_get_tensor(pcv_model*, const char*, float*, int64_t, int64_t*) { PCV_TODO("pcv_model_get_tensor"); }
-pcv_status pcv_model_encode_tokens(pcv_model*, const int64_t*, const int64_t*, int, int, float*) { PCV_TODO("pcv_model_encode_tokens"); }
-pcv_status pcv_model_encode_tokens_device(pcv_model*, const int64_t*, const int64_t*, int, int, void*, int) { PCV_TODO("pcv_model_encode_tokens_device"); }
-pcv_status pcv_model_debug_hidden(pcv_model*, int, float*, int64_t) { PCV_TODO("pcv_model_debug_hidden"); }
-pcv_status pcv_model_last_stats(pcv_model*, pcv_encode_stats*) { PCV_TODO("pcv_model_last_stats"); }
+pcv_status pcv_model_destroy(pcv_model* m) {
+    return guarded([&] {
+        if (!m) return;
+        hipSetDevice(m->ctx->device);
+        hipStreamSynchronize(m->ctx->stream);
+        free_workspace(m);
+        for (float* p : m->owned) hipFree(p);
+        if (m->ev0) hipEventDestroy(m->ev0);
+        if (m->ev1) hipEventDestroy(m->ev1);
+        delete m;
+    });
+}
+
+pcv_status pcv_model_output_dim(pcv_model* m, int* out_dim) {
+    return guarded([&] {
+        PCV_REQUIRE(m != nullptr && out_dim != nullptr, "model_output_dim: NULL argument");
+        *out_dim = m->d.dense_out > 0 ? m->d.dense_out : m->d.hidden;
+    });
+}
+
+pcv_status pcv_model_set_tensor(pcv_model* m, const char* name, const float* data, int64_t n) {
+    return guarded([&] {
+        PCV_REQUIRE(m != nullptr && name != nullptr && data != nullptr, "model_set_tensor: NULL argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        auto it = m->table.find(name);
+        PCV_REQUIRE(it != m->table.end(), "model_set_tensor: unknown tensor '%s'", name);
+        PCV_REQUIRE(it->second.n == n, "model_set_tensor: '%s' has %lld elements, got %lld", name,
+                    (long long)it->second.n, (long long)n);
+        PCV_HIP(hipSetDevice(m->ctx->device));
+        PCV_HIP(hipStreamSynchronize(m->ctx->stream));
+        PCV_HIP(hipMemcpy(it->second.p, data, (size_t)n * 4, hipMemcpyHostToDevice));
+    });
+}
+
+pcv_status pcv_model_get_tensor(pcv_model* m, const char* name, float* out, int64_t cap, int64_t* out_n) {
+    return guarded([&] {
+        PCV_REQUIRE(m != nullptr && name != nullptr, "model_get_tensor: NULL argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        auto it = m->table.find(name);
+        PCV_REQUIRE(it != m->table.end(), "model_get_tensor: unknown tensor '%s'", name);
+        if (out_n) *out_n = it->second.n;
+        if (!out) return;  // size query
+        PCV_REQUIRE(cap >= it->second.n, "model_get_tensor: '%s' needs room for %lld values", name,
+                    (long long)it->second.n);
+        PCV_HIP(hipSetDevice(m->ctx->device));
+        PCV_HIP(hipStreamSynchronize(m->ctx->stream));
+        PCV_HIP(hipMemcpy(out, it->second.p, (size_t)it->second.n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+pcv_status pcv_model_encode_tokens(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L, float* out) {
+    return guarded([&] {
+        check_tokens(m, ids, mask, B, L);
+        PCV_REQUIRE(out != nullptr, "encode_tokens: out is NULL");
+        std::lock_guard<std::mutex> lk(m->mu);  // one forward at a time, like the worker channel (model.rs:161,187)
+        PCV_HIP(hipSetDevice(m->ctx->device));
+        forward(m, ids, mask, B, L);
+        const int OD = m->d.dense_out > 0 ? m->d.dense_out : m->d.hidden;
+        PCV_HIP(hipMemcpyAsync(out, m->out, (size_t)B * OD * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+        PCV_HIP(hipStreamSynchronize(m->ctx->stream));
+        PCV_HIP(hipGetLastError());
+        finish_stats(m);
+    });
+}
+
+pcv_status pcv_model_encode_tokens_device(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L,
+                                          void* d_out, int async) {
+    return guarded([&] {
+        check_tokens(m, ids, mask, B, L);
+        PCV_REQUIRE(d_out != nullptr, "encode_tokens_device: d_out is NULL");
+        std::lock_guard<std::mutex> lk(m->mu);
+        PCV_HIP(hipSetDevice(m->ctx->device));
+        forward(m, ids, mask, B, L);
+        const int OD = m->d.dense_out > 0 ? m->d.dense_out : m->d.hidden;
+        PCV_HIP(hipMemcpyAsync(d_out, m->out, (size_t)B * OD * 4, hipMemcpyDeviceToDevice, m->ctx->stream));
+        if (!async) {
+            PCV_HIP(hipStreamSynchronize(m->ctx->stream));
+            PCV_HIP(hipGetLastError());
+            finish_stats(m);
+        }
+    });
+}
+
+pcv_status pcv_model_debug_hidden(pcv_model* m, int layer, float* out, int64_t cap) {
+    return guarded([&] {
+        PCV_REQUIRE(m != nullptr && out != nullptr, "model_debug_hidden: NULL argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        PCV_REQUIRE(m->dbg_tokens > 0, "model_debug_hidden: no hidden states kept (batch larger than %lld tokens?)",
+                    (long long)kDebugTokenLimit);
+        PCV_REQUIRE(layer >= 0 && layer <= m->d.layers, "model_debug_hidden: layer %d outside [0,%d]", layer, m->d.layers);
+        const int64_t n = m->dbg_tokens * m->d.hidden;
+        PCV_REQUIRE(cap >= n, "model_debug_hidden: need room for %lld values", (long long)n);
+        PCV_HIP(hipSetDevice(m->ctx->device));
+        PCV_HIP(hipStreamSynchronize(m->ctx->stream));
+        PCV_HIP(hipMemcpy(out, m->dbg + (size_t)layer * n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+pcv_status pcv_model_last_stats(pcv_model* m, pcv_encode_stats* out) {
+    return guarded([&] {
+        PCV_REQUIRE(m != nullptr && out != nullptr, "model_last_stats: NULL argument");
+        std::lock_guard<std::mutex> lk(m->mu);
+        *out = m->stats;
+    });
+}
 
 }  // extern "C"

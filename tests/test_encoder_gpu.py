@@ -1,0 +1,154 @@
+"""GPU parity tests of the encoder (pcv_model_*), through the C ABI, against the CPU oracle
+(oracle/encoder.c) and the committed Hugging Face BertModel vectors.
+
+Tolerance: the scan's parity bar is cosine within 1e-4 (BASELINE.json north_star); embeddings are
+unit vectors, so 1e-4 absolute per component is the matching bar here.  f32 end to end on both
+sides: the observed differences are ~1e-6 (summation order only)."""
+import os
+
+import numpy as np
+import pytest
+
+import perceive_amd as pa
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def load_tiny(golden_dir):
+    g = np.load(os.path.join(golden_dir, "encoder_tiny.npz"))
+    v, h, ly, nh, it, mp = [int(x) for x in g["desc"]]
+    desc = dict(vocab=v, hidden=h, layers=ly, heads=nh, inter=it, max_pos=mp, eps=1e-12, pooling=0, normalize=1)
+    weights = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+    return g, desc, weights
+
+
+def make_model(ctx, desc, weights=None, seed=0, **kw):
+    d = pa.make_desc(desc["vocab"], desc["hidden"], desc["layers"], desc["heads"], desc["inter"], desc["max_pos"],
+                     layer_norm_eps=desc.get("eps", 1e-12), **kw)
+    m = pa.Model(ctx, d, synthetic_seed=seed)
+    if weights is not None:
+        m.load_state_dict(weights)
+    return m
+
+
+def test_hf_golden_tiny(ctx, oracle, golden_dir):
+    g, desc, weights = load_tiny(golden_dir)
+    m = make_model(ctx, desc, weights)
+    out = m.encode_tokens(g["ids"], g["mask"])
+    assert np.abs(out - g["normed"]).max() < TOL
+    B, L = g["ids"].shape
+    msk = g["mask"].astype(bool)
+    for ly in range(desc["layers"] + 1):
+        hid = m.debug_hidden(ly, B, L)
+        assert np.abs(hid[msk] - g["hidden"][ly][msk]).max() < TOL, ly
+    # and the C oracle on the same inputs (padded positions too: same -10000 mask convention)
+    oout, ohid = oracle.encode_tokens(desc, weights, g["ids"], g["mask"], want_hidden=True)
+    np.testing.assert_allclose(out, oout, atol=1e-5)
+    np.testing.assert_allclose(m.debug_hidden(desc["layers"], B, L), ohid[-1], atol=5e-5)
+    m.close()
+    # un-normalised mean pooling (e.g. msmarco dot-product models: has_normalization() false, model.rs:151)
+    m2 = make_model(ctx, desc, weights, normalize=False)
+    assert np.abs(m2.encode_tokens(g["ids"], g["mask"]) - g["mean"]).max() < TOL
+    m2.close()
+
+
+def test_ragged_lengths_and_padding_invariance(ctx, oracle, golden_dir):
+    g, desc, weights = load_tiny(golden_dir)
+    m = make_model(ctx, desc, weights)
+    rng = np.random.default_rng(0)
+    # L not a multiple of 32, one-token and full-length rows, batch of 7
+    toks = [list(rng.integers(1, desc["vocab"], n)) for n in (1, 5, 33, 40, 17, 2, 40)]
+    ids, mask = m.generate_token_tensors(toks)
+    assert ids.shape == (7, 40) and mask.sum(1).tolist() == [1, 5, 33, 40, 17, 2, 40]
+    out = m.encode_tokens(ids, mask)
+    oout, _ = oracle.encode_tokens(desc, weights, ids, mask)
+    np.testing.assert_allclose(out, oout, atol=2e-5)
+    # each row alone (no padding) gives the same embedding: tokenize.rs pads to the batch max
+    for i in (0, 2, 4):
+        ids1, mask1 = m.generate_token_tensors([toks[i]])
+        np.testing.assert_allclose(m.encode_tokens(ids1, mask1)[0], out[i], atol=2e-5)
+    m.close()
+
+
+@pytest.mark.parametrize("pooling", ["cls", "max", "mean_sqrt_len"])
+def test_pooling_modes(ctx, oracle, golden_dir, pooling):
+    g, desc, weights = load_tiny(golden_dir)
+    code = {"cls": 1, "max": 2, "mean_sqrt_len": 3}[pooling]
+    m = make_model(ctx, desc, weights, pooling=pooling, normalize=False)
+    out = m.encode_tokens(g["ids"], g["mask"])
+    oout, _ = oracle.encode_tokens(dict(desc, pooling=code, normalize=0), weights, g["ids"], g["mask"])
+    np.testing.assert_allclose(out, oout, atol=5e-5)
+    m.close()
+
+
+def test_dense_module(ctx, oracle, golden_dir):
+    g, desc, weights = load_tiny(golden_dir)
+    rng = np.random.default_rng(1)
+    w2 = dict(weights)
+    w2["dense.linear.weight"] = (rng.standard_normal((64, desc["hidden"])) * 0.1).astype(np.float32)
+    w2["dense.linear.bias"] = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    m = make_model(ctx, desc, w2, dense_out=64, dense_activation="tanh", normalize=True)
+    assert m.output_dim == 64
+    out = m.encode_tokens(g["ids"], g["mask"])
+    oout, _ = oracle.encode_tokens(dict(desc, dense_out=64, dense_act=1, normalize=1), w2, g["ids"], g["mask"])
+    np.testing.assert_allclose(out, oout, atol=2e-5)
+    m.close()
+
+
+def test_minilm_shape_synthetic_weights(ctx, oracle):
+    # the BASELINE model shape (384 hidden, 6 layers, 12 heads x 32, FFN 1536) with the library's
+    # seeded synthetic weights, downloaded and fed to the oracle
+    m = pa.Model(ctx, synthetic_seed=7)
+    assert m.output_dim == 384 and m.model_type.model_id == 0
+    sd = m.state_dict()
+    assert sd["embeddings.word_embeddings.weight"].shape == (30522, 384)
+    rng = np.random.default_rng(2)
+    toks = [list(rng.integers(1000, 30000, n)) for n in (48, 7, 31, 20)]
+    ids, mask = m.generate_token_tensors(toks)
+    out = m.encode_tokens(ids, mask)
+    desc = dict(vocab=30522, hidden=384, layers=6, heads=12, inter=1536, max_pos=512, eps=1e-12, pooling=0, normalize=1)
+    oout, ohid = oracle.encode_tokens(desc, sd, ids, mask, want_hidden=True)
+    assert np.abs(out - oout).max() < TOL
+    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+    assert np.abs(m.debug_hidden(6, 4, 48) - ohid[-1]).max() < 5e-4  # activations are O(1..3)
+    st = m.last_stats()
+    assert st["batch"] == 4 and st["seq_len"] == 48 and st["flops"] > 0 and st["total_ms"] > 0
+    # cosine ranking from GPU embeddings == from oracle embeddings (the end-to-end contract)
+    assert (np.argsort(-(out @ out.T), 1) == np.argsort(-(oout @ oout.T), 1)).all()
+    m.close()
+
+
+def test_head_dim_64_and_long_sequence(ctx, oracle):
+    # bert-base-like heads (64 wide) and L = 300 > one 128-key chunk: exercises the online softmax
+    desc = dict(vocab=500, hidden=256, layers=1, heads=4, inter=512, max_pos=512, eps=1e-12, pooling=0, normalize=1)
+    m = make_model(ctx, desc, seed=3)
+    sd = m.state_dict()
+    rng = np.random.default_rng(4)
+    toks = [list(rng.integers(1, 500, n)) for n in (300, 129, 64)]
+    ids, mask = m.generate_token_tensors(toks)
+    out = m.encode_tokens(ids, mask)
+    oout, _ = oracle.encode_tokens(desc, sd, ids, mask)
+    assert np.abs(out - oout).max() < TOL
+    m.close()
+
+
+def test_weight_file_roundtrip_and_errors(ctx, golden_dir, tmp_path):
+    g, desc, weights = load_tiny(golden_dir)
+    path = str(tmp_path / "tiny.pcvw")
+    pa.save_weights(path, weights)
+    d = pa.make_desc(desc["vocab"], desc["hidden"], desc["layers"], desc["heads"], desc["inter"], desc["max_pos"])
+    m = pa.Model(ctx, d, weights_path=path)
+    assert np.abs(m.encode_tokens(g["ids"], g["mask"]) - g["normed"]).max() < TOL
+    np.testing.assert_array_equal(m.get_tensor("encoder.layer.1.output.dense.bias"), weights["encoder.layer.1.output.dense.bias"])
+    with pytest.raises(pa.ModelError):
+        m.encode_tokens(np.ones((1, 100), np.int64), np.ones((1, 100), np.int64))  # L > max_position_embeddings
+    with pytest.raises(pa.ModelError):
+        m.encode(["needs a tokenizer"])
+    m.close()
+    with pytest.raises(pa.PcvError):
+        pa.Model(ctx, d, weights_path=str(tmp_path / "missing.pcvw"))
+    bad = pa.make_desc(100, 100, 1, 4, 256, 64)  # hidden not a multiple of 128
+    with pytest.raises(pa.PcvError) as e:
+        pa.Model(ctx, bad)
+    assert e.value.status == 3
