@@ -1,0 +1,97 @@
+// Drives the C++ host mirror (include/perceive.hpp) end to end on the GPU: build a Searcher from
+// a blob row stream, search_vector with the reference's distance convention, rebuild_source, and a
+// Model::encode_tokens round.  Expected values are recomputed here with plain f64 loops (the same
+// canonical definition as oracle/scan.c, restated so this binary links only the product library).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "perceive.hpp"
+
+using namespace perceive;
+
+static int failures = 0;
+#define EXPECT(cond)                                                      \
+    do {                                                                  \
+        if (!(cond)) {                                                    \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+            ++failures;                                                   \
+        }                                                                 \
+    } while (0)
+
+int main() {
+    Context ctx(0);
+    const int D = 384, N = 3000;
+    std::mt19937 rng(7);
+    std::normal_distribution<float> nd;
+    std::vector<std::vector<float>> emb(N, std::vector<float>(D));
+    std::vector<EmbeddingRow> rows;
+    for (int i = 0; i < N; ++i) {
+        for (auto& v : emb[i]) v = nd(rng);
+        rows.push_back({1000 + i, i % 2 == 0 ? 1 : 2, serialize_embedding(emb[i])});
+    }
+    EXPECT(deserialize_embedding(rows[5].embedding) == emb[5]);
+    auto s = Searcher::build(ctx, rows, D, Metric::Dot);
+    EXPECT(s->num_rows() == N);
+
+    std::vector<float> q(D);
+    for (auto& v : q) v = nd(rng);
+    auto expect = [&](int64_t source) {
+        std::vector<std::pair<double, int64_t>> sc;
+        for (int i = 0; i < N; ++i) {
+            if (rows[i].source_id != source) continue;
+            double dot = 0;
+            for (int k = 0; k < D; ++k) dot += (double)q[k] * (double)emb[i][k];
+            sc.push_back({dot, rows[i].item_id});
+        }
+        std::stable_sort(sc.begin(), sc.end(), [](auto& a, auto& b) { return a.first > b.first; });
+        return sc;
+    };
+    for (int64_t source : {1, 2}) {
+        auto items = s->search_vector({source}, 10, q);
+        auto ref = expect(source);
+        EXPECT(items.size() == 10);
+        for (size_t j = 0; j < items.size(); ++j) {
+            EXPECT(items[j].id == ref[j].second);
+            const float d = (float)std::max(0.0, 1.0 - ref[j].first / D);  // search.rs:275-277
+            EXPECT(std::fabs(items[j].score - d) < 1e-6f);
+            if (j) EXPECT(items[j].score >= items[j - 1].score);  // ascending, search.rs:179
+        }
+    }
+    EXPECT(s->search_vector({}, 10, q).empty());
+    // rebuild_source: source 2 shrinks to 5 rows
+    std::vector<EmbeddingRow> repl(rows.begin() + 1, rows.begin() + 11);
+    s->rebuild_source(repl, 2);
+    EXPECT(s->num_rows() == N / 2 + 5);
+    s->hidden.insert(42);
+
+    // Model::encode_tokens on a tiny synthetic-weight model: unit-norm rows, deterministic
+    pcv_model_desc d;
+    pcv_model_desc_minilm_l6(&d);
+    d.vocab_size = 1000;
+    d.layers = 2;
+    Model m(ctx, d, nullptr, 3);
+    auto t = generate_token_tensors({{5, 6, 7, 8}, {9, 10}});
+    EXPECT(t.len == 4 && t.tokens_masks[6] == 0 && t.tokens_masks[5] == 1);
+    auto e1 = m.encode_tokens(t), e2 = m.encode_tokens(t);
+    EXPECT(e1.size() == 2 && (int)e1[0].size() == m.output_dim() && e1 == e2);
+    for (auto& row : e1) {
+        double n = 0;
+        for (float v : row) n += (double)v * v;
+        EXPECT(std::fabs(n - 1.0) < 1e-5);
+    }
+    EXPECT(model_id(m.model_type) == 0);
+    try {
+        TokenTensors bad = generate_token_tensors({std::vector<int64_t>(600, 5)});
+        m.encode_tokens(bad);
+        EXPECT(false);
+    } catch (const ModelError& e) {
+        EXPECT(e.status == PCV_ERR_INVALID);
+    }
+    auto sim = cosine_similarity_single_query(ctx, e1[0], e1[0], 1, m.output_dim());
+    EXPECT(std::fabs(sim[0] - 1.0f) < 1e-5f);
+
+    std::printf(failures ? "host_mirror_test: %d failure(s)\n" : "host_mirror_test: ok\n", failures);
+    return failures ? 1 : 0;
+}
