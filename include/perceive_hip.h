@@ -247,6 +247,30 @@ typedef struct pcv_encode_stats {
 } pcv_encode_stats;
 pcv_status pcv_model_last_stats(pcv_model* m, pcv_encode_stats* out);
 
+/* ---- Tokenizer (model/tokenize.rs:60-77; rust_tokenizers BertTokenizer) -------------------------
+ * Host code, like the reference's tokenizer: BERT BasicTokenizer (clean text, CJK spacing, lower-casing,
+ * accent stripping, punctuation split) + greedy WordPiece over `vocab.txt` (one token per line, id =
+ * line number).  Needs no GPU. */
+typedef struct pcv_tokenizer pcv_tokenizer;
+
+/* TokenizerOption::from_file (model.rs:96-113).  strip_accents < 0: follow lower_case (the default of
+ * rust_tokenizers / HF when tokenizer_config.strip_accents is absent). */
+pcv_status pcv_tokenizer_create(const char* vocab_path, int lower_case, int strip_accents, pcv_tokenizer** out);
+pcv_status pcv_tokenizer_destroy(pcv_tokenizer* t);
+pcv_status pcv_tokenizer_vocab_size(pcv_tokenizer* t, int* out_n);
+/* ids of [PAD] (get_pad_id, tokenize.rs:19), [UNK], [CLS], [SEP]; -1 when the vocab lacks one */
+pcv_status pcv_tokenizer_special_ids(pcv_tokenizer* t, int64_t* pad, int64_t* unk, int64_t* cls, int64_t* sep);
+
+/* One element of encode_list(inputs, max_len, TruncationStrategy::LongestFirst, stride 0)
+ * (tokenize.rs:64-75): [CLS] pieces... [SEP], truncated to max_len tokens in all.
+ *   out_ids           token ids
+ *   out_begin/out_end char (Unicode scalar) offsets of each token in `text`, -1 for special tokens
+ *                     (TokenIdsWithOffsets::token_offsets, used by highlight.rs:129-147); may be NULL
+ *   out_special       special_tokens_mask (highlight.rs:58-84); may be NULL
+ *   cap               capacity of the output arrays; out_len receives the token count */
+pcv_status pcv_tokenizer_encode(pcv_tokenizer* t, const char* text, size_t n_bytes, int max_len, int64_t* out_ids,
+                                int32_t* out_begin, int32_t* out_end, uint8_t* out_special, int cap, int* out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,3 +23,4 @@ from .model import (  # noqa: F401,E402
     minilm_l6_desc,
     save_weights,
 )
+from .tokenizer import BertTokenizer, TokenizedInput  # noqa: F401,E402

@@ -8,6 +8,7 @@ restates the padding/mask layout of tokenize.rs:9-57 for callers that bring thei
 """
 import ctypes as C
 import enum
+import os
 import struct
 
 import numpy as np
@@ -68,14 +69,24 @@ def save_weights(path, tensors):
             f.write(a.tobytes())
 
 
+def _env_usize(name, default):
+    try:
+        return int(os.environ.get(name, ""))  # highlight.rs:9-17: unparsable / unset -> default
+    except ValueError:
+        return default
+
+
 class Model:
     """model.rs:56-65.  `model_type` is kept as the pub field it is in the reference."""
 
     def __init__(self, ctx: Context, desc=None, weights_path=None, synthetic_seed=0,
-                 model_type=SentenceEmbeddingsModelType.AllMiniLmL6V2, pad_token_id=0):
+                 model_type=SentenceEmbeddingsModelType.AllMiniLmL6V2, pad_token_id=0, tokenizer=None):
         self.ctx = ctx
         self.model_type = model_type
         self.desc = desc if desc is not None else minilm_l6_desc()
+        self.tokenizer = tokenizer  # perceive_amd.BertTokenizer (model.rs:61-63)
+        if tokenizer is not None and tokenizer.get_pad_id() is not None:
+            pad_token_id = tokenizer.get_pad_id()  # tokenize.rs:19
         self.pad_token_id = pad_token_id
         self._h = C.c_void_p()
         wp = weights_path.encode() if weights_path else None
@@ -117,10 +128,94 @@ class Model:
         _ffi.check(_ffi.lib().pcv_model_encode_tokens_device(self._handle, _ffi.i64p(ids), _ffi.i64p(mask), ids.shape[0],
                                                              ids.shape[1], C.c_void_p(d_out), 1 if async_ else 0))
 
+    def tokenize(self, inputs):
+        """Model::tokenize (tokenize.rs:60-77): encode_list(inputs, max_seq_length, LongestFirst, 0),
+        then generate_token_tensors."""
+        if self.tokenizer is None:
+            raise ModelError("this Model was built without a tokenizer (pass tokenizer=BertTokenizer(vocab.txt))")
+        enc = self.tokenizer.encode_list(list(inputs), self.desc.max_seq_length)
+        return self.generate_token_tensors([e.token_ids for e in enc])
+
     def encode(self, inputs):
-        """model.rs:176-179.  Needs the WordPiece tokenizer (not built yet)."""
-        raise ModelError("Model.encode(&[str]) needs the tokenizer, which is not available offline; "
-                         "use encode_tokens(ids, masks)")
+        """Model::encode (model.rs:176-179)."""
+        ids, mask = self.tokenize(inputs)
+        return self.encode_tokens(ids, mask)
+
+    def highlight(self, query, documents):
+        """Model::highlight (highlight.rs:23-165): for each document the text chunk whose embedding has
+        the largest dot product with the query's.  Chunks of CHUNK_SIZE tokens overlapping by
+        CHUNK_OVERLAP (env, defaults 20 / 4, highlight.rs:7-18).  Restated line by line, including
+        the reference's boundary quirks (a chunk's longest non-special run starts AT the special
+        token that precedes it; the returned slice runs one char past the last token, and is empty
+        when that char does not exist)."""
+        from .search import dot_product
+
+        if self.tokenizer is None:
+            raise ModelError("highlight needs a tokenizer")
+        documents = list(documents)
+        query_encoding = self.encode([query])                                          # highlight.rs:29
+        tokenized_docs = self.tokenizer.encode_list(documents, 1_000_000)              # highlight.rs:32-38
+        chunk_size = _env_usize("CHUNK_SIZE", 20)
+        chunk_overlap = _env_usize("CHUNK_OVERLAP", 4)
+        chunk_index_inc = chunk_size - chunk_overlap                                   # highlight.rs:43
+        token_chunks, token_chunk_boundaries, document_chunk_boundaries = [], [], []
+        for tokens in tokenized_docs:                                                  # highlight.rs:53-100
+            n = len(tokens.token_ids)
+            i = 0
+            while i + chunk_overlap < n:
+                start_index = i
+                end_index = min(i + chunk_size, n)
+                longest_start = longest_length = current_start = current_length = 0
+                for index, is_special in enumerate(tokens.special_tokens_mask[start_index:end_index]):
+                    if is_special == 0:
+                        current_length += 1
+                    else:
+                        if current_length > longest_length:
+                            longest_start, longest_length = current_start, current_length
+                        current_start, current_length = index, 0
+                if current_length > longest_length:
+                    longest_start, longest_length = current_start, current_length
+                start_index = start_index + longest_start
+                end_index = min(start_index + longest_length, end_index)
+                if end_index - start_index >= chunk_size // 2:
+                    token_chunk_boundaries.append((start_index, end_index))
+                    token_chunks.append(tokens.token_ids[start_index:end_index])
+                i += chunk_index_inc
+            document_chunk_boundaries.append(len(token_chunks))
+        if token_chunks:                                                               # highlight.rs:102-111
+            ids, mask = self.generate_token_tensors(token_chunks)
+            docs_encoding = self.encode_tokens(ids, mask)
+            scores = dot_product(self.ctx, query_encoding, docs_encoding)[0]
+        else:
+            scores = np.zeros(0, np.float32)
+        highlights = []
+        for index, overall_chunk_end in enumerate(document_chunk_boundaries):          # highlight.rs:114-162
+            overall_chunk_start = 0 if index == 0 else document_chunk_boundaries[index - 1]
+            doc_scores = scores[overall_chunk_start:overall_chunk_end]
+            if doc_scores.size == 0:
+                highlights.append(None)
+                continue
+            if np.isnan(doc_scores).any():
+                raise ModelError("NaN chunk score (the reference unwraps partial_cmp and panics)")
+            mx = doc_scores.max()
+            best = int(np.nonzero(doc_scores == mx)[0][-1])  # itertools position_max_by: last of equal maxima
+            lo, hi = token_chunk_boundaries[overall_chunk_start + best]
+            text_start = text_end = 0
+            for off in tokenized_docs[index].token_offsets[lo:hi]:
+                if off is None:
+                    continue
+                if text_start == 0 and text_end == 0:
+                    text_start, text_end = off
+                else:
+                    text_start, text_end = min(text_start, off[0]), max(text_end, off[1])
+            doc = documents[index]
+            # char_indices().nth(text_start), then .nth(text_end - text_start) on the same iterator
+            # -> chars text_start and text_end + 1 must both exist (highlight.rs:150-158)
+            if text_start < len(doc) and text_end + 1 < len(doc):
+                highlights.append(doc[text_start:text_end + 1])
+            else:
+                highlights.append("")
+        return highlights
 
     # ---- weights / diagnostics ----------------------------------------------------------------
     def get_tensor(self, name):

@@ -1,0 +1,77 @@
+"""Host-side mirror of the tokenizer calls of perceive-core (model/tokenize.rs:60-77,
+model/highlight.rs:32-38) over the C ABI's WordPiece tokenizer (csrc/tokenizer.cpp).
+rust_tokenizers names are kept: `encode_list` returns objects with `token_ids`, `token_offsets`
+(char offsets or None for special tokens) and `special_tokens_mask`."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+
+
+@dataclass
+class TokenizedInput:
+    token_ids: List[int]
+    token_offsets: List[Optional[Tuple[int, int]]]
+    special_tokens_mask: List[int]
+
+
+class BertTokenizer:
+    """TokenizerOption::from_file(Bert, vocab, lower_case, strip_accents) — model.rs:96-113."""
+
+    def __init__(self, vocab_path, lower_case=True, strip_accents=None):
+        self._h = C.c_void_p()
+        sa = -1 if strip_accents is None else (1 if strip_accents else 0)
+        _ffi.check(_ffi.lib().pcv_tokenizer_create(str(vocab_path).encode(), 1 if lower_case else 0, sa, C.byref(self._h)))
+        ids = [C.c_int64() for _ in range(4)]
+        _ffi.check(_ffi.lib().pcv_tokenizer_special_ids(self._h, *[C.byref(x) for x in ids]))
+        self.pad_id, self.unk_id, self.cls_id, self.sep_id = [x.value for x in ids]
+
+    def get_pad_id(self):
+        """tokenize.rs:19: `self.tokenizer.get_pad_id().unwrap_or(0)` at the call site."""
+        return self.pad_id if self.pad_id >= 0 else None
+
+    @property
+    def vocab_size(self):
+        n = C.c_int()
+        _ffi.check(_ffi.lib().pcv_tokenizer_vocab_size(self._h, C.byref(n)))
+        return n.value
+
+    def encode(self, text, max_len):
+        b = text.encode("utf-8")
+        cap = min(max_len, len(b) + 2)  # a token covers at least one byte
+        while True:
+            ids = np.empty(cap, np.int64)
+            beg = np.empty(cap, np.int32)
+            end = np.empty(cap, np.int32)
+            sp = np.empty(cap, np.uint8)
+            n = C.c_int()
+            st = _ffi.lib().pcv_tokenizer_encode(
+                self._h, b, len(b), int(max_len), _ffi.i64p(ids), beg.ctypes.data_as(C.POINTER(C.c_int32)),
+                end.ctypes.data_as(C.POINTER(C.c_int32)), _ffi.u8p(sp), cap, C.byref(n))
+            if st != 0 and n.value > cap:
+                cap = n.value
+                continue
+            _ffi.check(st)
+            k = n.value
+            offs = [None if sp[i] else (int(beg[i]), int(end[i])) for i in range(k)]
+            return TokenizedInput([int(x) for x in ids[:k]], offs, [int(x) for x in sp[:k]])
+
+    def encode_list(self, inputs, max_len, truncation_strategy="LongestFirst", stride=0):
+        """rust_tokenizers `encode_list` as called at tokenize.rs:64-75 / highlight.rs:32-38."""
+        if truncation_strategy != "LongestFirst" or stride != 0:
+            raise ValueError("only TruncationStrategy::LongestFirst with stride 0 is used by the reference")
+        return [self.encode(t, max_len) for t in inputs]
+
+    def close(self):
+        if self._h:
+            _ffi.lib().pcv_tokenizer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

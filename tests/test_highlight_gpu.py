@@ -1,0 +1,64 @@
+"""GPU: text in -> embedding / highlight out (Model::encode, Model::highlight) against the CPU
+restatement (tests/oracle_highlight.py: HF tokenizer + C oracle encoder + numpy)."""
+import os
+
+import numpy as np
+import pytest
+
+import perceive_amd as pa
+
+pytestmark = pytest.mark.gpu
+
+DOCS = [
+    "The search of embeddings is made by cosine similarity. A query vector and a document vector are used; "
+    "the model will make each sentence into a vector first. Then people search many documents at the same time, "
+    "and the great old world will know how good the new model really is, because it can take three years of work.",
+    "Hello world. This document is about Tokyo and Istanbul and a cafe where people work each day. "
+    "They said the time was right, and so the work could go on for years. Still, no one would know where it came from.",
+    "short one",
+    "",
+    "Hello hello hello hello hello hello hello hello hello hello hello hello hello hello hello hello hello hello",
+]
+
+
+@pytest.fixture(scope="module")
+def setup(ctx, golden_dir):
+    vocab = os.path.join(golden_dir, "tokenizer_vocab.txt")
+    tok = pa.BertTokenizer(vocab)
+    desc = dict(vocab=tok.vocab_size, hidden=128, layers=2, heads=4, inter=256, max_pos=512, eps=1e-12, pooling=0,
+                normalize=1)
+    d = pa.make_desc(desc["vocab"], 128, 2, 4, 256, 512, max_seq_length=64)
+    m = pa.Model(ctx, d, synthetic_seed=11, tokenizer=tok)
+    yield m, desc, vocab
+    m.close()
+
+
+def test_encode_text_matches_oracle(setup, oracle):
+    m, desc, vocab = setup
+    texts = ["Hello world", "the search of embeddings, really?", "x " * 200]  # last one truncated to max_seq_length
+    out = m.encode(texts)
+    ids, mask = m.tokenize(texts)
+    assert ids.shape[1] == 64 and mask[2].sum() == 64 and mask[0].sum() == 4
+    oout, _ = oracle.encode_tokens(desc, m.state_dict(), ids, mask)
+    assert np.abs(out - oout).max() < 1e-4
+    q = pa.encode_query(m, "hello world")  # search.rs:262-264
+    np.testing.assert_allclose(q, out[0], atol=1e-6)
+
+
+def test_highlight_matches_oracle(setup, oracle):
+    import oracle_highlight
+
+    m, desc, vocab = setup
+    got = m.highlight("how good is the search model", DOCS)
+    exp, scores = oracle_highlight.highlight(oracle, desc, m.state_dict(), vocab, 64, "how good is the search model", DOCS)
+    assert got == exp
+    assert got[2] is None and got[3] is None          # too short for a chunk: no highlight (highlight.rs:122-125)
+    assert isinstance(got[0], str) and len(got[0]) > 20 and got[0] in DOCS[0]
+    # env-overridable chunking (highlight.rs:7-18)
+    os.environ["CHUNK_SIZE"], os.environ["CHUNK_OVERLAP"] = "8", "2"
+    try:
+        got8 = m.highlight("tokyo cafe", DOCS)
+        exp8, _ = oracle_highlight.highlight(oracle, desc, m.state_dict(), vocab, 64, "tokyo cafe", DOCS, 8, 2)
+        assert got8 == exp8 and got8[2] is None
+    finally:
+        del os.environ["CHUNK_SIZE"], os.environ["CHUNK_OVERLAP"]

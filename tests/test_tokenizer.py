@@ -1,0 +1,65 @@
+"""CPU: the C++ WordPiece tokenizer (csrc/tokenizer.cpp, host code like the reference's tokenizer)
+against Hugging Face BertTokenizer / BertTokenizerFast vectors (tests/golden/gen_tokenizer_golden.py).
+Bit-exact: ids, special-token masks and char offsets."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import perceive_amd as pa
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    with open(os.path.join(golden_dir, "tokenizer_golden.json"), encoding="utf-8") as f:
+        return json.load(f)["cases"]
+
+
+@pytest.fixture(scope="module")
+def vocab_path(golden_dir):
+    return os.path.join(golden_dir, "tokenizer_vocab.txt")
+
+
+def test_ids_offsets_and_masks_match_hf(golden, vocab_path):
+    toks = {}
+    bad = []
+    for c in golden:
+        key = (c["lower"], c["strip"])
+        if key not in toks:
+            toks[key] = pa.BertTokenizer(vocab_path, lower_case=c["lower"], strip_accents=c["strip"])
+        enc = toks[key].encode(c["text"], c["max_len"])
+        exp_off = [None if o is None else tuple(o) for o in c["offsets"]]
+        if enc.token_ids != c["ids"] or enc.special_tokens_mask != c["special"] or enc.token_offsets != exp_off:
+            bad.append((key, c["text"][:40], c["max_len"], enc.token_ids, c["ids"], enc.token_offsets, exp_off))
+    assert not bad, f"{len(bad)} of {len(golden)} cases differ; first: {bad[0]}"
+    assert len(golden) >= 300
+
+
+def test_encode_list_and_padding_layout(vocab_path):
+    # Model::tokenize (tokenize.rs:60-77): encode_list -> token_ids -> generate_token_tensors
+    t = pa.BertTokenizer(vocab_path)
+    enc = t.encode_list(["hello world", "the search of embeddings, really?"], 256)
+    assert [e.token_ids[0] for e in enc] == [t.cls_id] * 2 and [e.token_ids[-1] for e in enc] == [t.sep_id] * 2
+    assert t.get_pad_id() == 0 and t.vocab_size == 340
+    L = max(len(e.token_ids) for e in enc)
+    ids = np.full((2, L), t.pad_id, np.int64)
+    for i, e in enumerate(enc):
+        ids[i, : len(e.token_ids)] = e.token_ids
+    mask = (ids != t.pad_id).astype(np.int64)  # tokenize.rs:36-46
+    assert mask.sum(1).tolist() == [len(e.token_ids) for e in enc]
+    with pytest.raises(ValueError):
+        t.encode_list(["x"], 8, truncation_strategy="OnlyFirst")
+
+
+def test_errors(tmp_path, vocab_path):
+    with pytest.raises(pa.PcvError) as e:
+        pa.BertTokenizer(str(tmp_path / "missing.txt"))
+    assert e.value.status == 4
+    p = tmp_path / "v.txt"
+    p.write_text("a\nb\n")
+    with pytest.raises(pa.PcvError):
+        pa.BertTokenizer(str(p))  # no [UNK]/[CLS]/[SEP]
+    t = pa.BertTokenizer(vocab_path)
+    with pytest.raises(pa.PcvError):
+        t.encode("hello", 1)
