@@ -9,7 +9,9 @@ import perceive_amd as pa
 
 pytestmark = pytest.mark.gpu
 
+FILL = "the of and to in a is that for it as was with be by on not he this are or his from at which but have an they "
 DOCS = [
+    FILL * 3 + "people ask how good is the search model in the world today " + FILL * 3,
     "The search of embeddings is made by cosine similarity. A query vector and a document vector are used; "
     "the model will make each sentence into a vector first. Then people search many documents at the same time, "
     "and the great old world will know how good the new model really is, because it can take three years of work.",
@@ -52,13 +54,15 @@ def test_highlight_matches_oracle(setup, oracle):
     got = m.highlight("how good is the search model", DOCS)
     exp, scores = oracle_highlight.highlight(oracle, desc, m.state_dict(), vocab, 64, "how good is the search model", DOCS)
     assert got == exp
-    assert got[2] is None and got[3] is None          # too short for a chunk: no highlight (highlight.rs:122-125)
-    assert isinstance(got[0], str) and len(got[0]) > 20 and got[0] in DOCS[0]
+    assert got[3] is None and got[4] is None          # too short for a chunk: no highlight (highlight.rs:122-125)
+    for g, d in zip(got, DOCS):
+        assert g is None or g in d  # a slice of the document ('' when the reference's end char is missing)
+    assert any(g for g in got), got
     # env-overridable chunking (highlight.rs:7-18)
     os.environ["CHUNK_SIZE"], os.environ["CHUNK_OVERLAP"] = "8", "2"
     try:
         got8 = m.highlight("tokyo cafe", DOCS)
         exp8, _ = oracle_highlight.highlight(oracle, desc, m.state_dict(), vocab, 64, "tokyo cafe", DOCS, 8, 2)
-        assert got8 == exp8 and got8[2] is None
+        assert got8 == exp8 and got8[4] is None
     finally:
         del os.environ["CHUNK_SIZE"], os.environ["CHUNK_OVERLAP"]
