@@ -24,3 +24,12 @@ from .model import (  # noqa: F401,E402
     save_weights,
 )
 from .tokenizer import BertTokenizer, TokenizedInput  # noqa: F401,E402
+from .database import (  # noqa: F401,E402
+    Database,
+    Item,
+    ItemMetadata,
+    build_searcher,
+    rebuild_source,
+    search_and_retrieve,
+    search_vector_and_retrieve,
+)

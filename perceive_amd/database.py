@@ -1,0 +1,125 @@
+"""The slice of perceive-core's SQLite storage the hot path touches (crates/perceive-core/db.rs,
+search.rs:38-113,195-259): reading `(items.id, source_id, embedding)` rows for a model version and
+hydrating result items.  Storage itself is out of scope; this module only runs the
+reference's read queries against a database the reference's pipeline wrote
+(`item_embeddings.embedding` = little-endian f32 blob, update_db.rs:118-126).
+"""
+import sqlite3
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from .search import SearchItem, Searcher
+
+
+@dataclass
+class ItemMetadata:  # lib.rs:14-21
+    name: Optional[str] = None
+    author: Optional[str] = None
+    description: Optional[str] = None
+    mtime: Optional[int] = None
+    atime: Optional[int] = None
+
+
+@dataclass
+class Item:  # lib.rs:49-61
+    id: int
+    source_id: int
+    external_id: str
+    hash: Optional[str] = None
+    content: Optional[str] = None
+    raw_content: Optional[bytes] = None
+    process_version: int = 0
+    metadata: ItemMetadata = field(default_factory=ItemMetadata)
+    skipped: Optional[str] = None
+
+
+class Database:
+    """db.rs:43-59 reduced to a read connection."""
+
+    def __init__(self, path):
+        self.conn = sqlite3.connect(f"file:{path}?mode=ro", uri=True) if path != ":memory:" else sqlite3.connect(path)
+
+    @classmethod
+    def from_connection(cls, conn):
+        d = cls.__new__(cls)
+        d.conn = conn
+        return d
+
+
+_ROWS_SQL = """SELECT items.id, source_id, embedding
+        FROM items
+        JOIN item_embeddings ie ON model_id=? AND model_version=? AND ie.item_id=items.id
+        WHERE skipped IS NULL AND hidden_at IS NULL"""  # search.rs:87-93
+
+
+def _embedding_dim(conn, model_id, model_version):
+    row = conn.execute("SELECT length(embedding) FROM item_embeddings WHERE model_id=? AND model_version=? LIMIT 1",
+                       (model_id, model_version)).fetchone()
+    return None if row is None else row[0] // 4
+
+
+def _load(searcher, conn, model_id, model_version, sources):
+    """build_sources (search.rs:81-155): stream the join, keep rows of `sources`, group by source."""
+    src_set = set(int(s) for s in sources)
+    by_source = {int(s): ([], bytearray()) for s in sources}
+    for item_id, source_id, blob in conn.execute(_ROWS_SQL, (model_id, model_version)):
+        if source_id not in src_set:  # search.rs:106-109
+            continue
+        if len(blob) != searcher.dim * 4:
+            raise ValueError(f"embedding of item {item_id} has {len(blob)} bytes, index is {searcher.dim}-d")
+        ids, blobs = by_source[source_id]
+        ids.append(item_id)
+        blobs.extend(blob)
+    for source_id, (ids, blobs) in by_source.items():
+        if ids:
+            searcher.add_blobs(source_id, bytes(blobs), len(ids), np.asarray(ids, dtype=np.int64))
+
+
+def build_searcher(ctx, database, model_id, model_version, metric="dot", dim=None):
+    """Searcher::build(database, model_id, model_version) — search.rs:38-56."""
+    conn = database.conn
+    sources = [r[0] for r in conn.execute("SELECT id FROM sources")]  # search.rs:45-48
+    dim = dim or _embedding_dim(conn, model_id, model_version)
+    if dim is None:
+        raise ValueError("no embeddings stored for this model version; pass dim= to build an empty index")
+    s = Searcher(ctx, dim, metric)
+    _load(s, conn, model_id, model_version, sources)
+    s.finalize()
+    return s
+
+
+def rebuild_source(searcher, database, source_id, model_id, model_version):
+    """Searcher::rebuild_source — search.rs:58-79."""
+    from . import _ffi
+
+    _ffi.check(_ffi.lib().pcv_searcher_clear_source(searcher._handle, int(source_id)))
+    _load(searcher, database.conn, model_id, model_version, [source_id])
+    searcher.finalize()
+
+
+def search_vector_and_retrieve(searcher, database, sources, num_results, vector):
+    """search.rs:195-247: search, hydrate the items that are still visible, re-sort ascending."""
+    items = searcher.search_vector(sources, num_results, vector)
+    if not items:
+        return []
+    by_id = {it.id: it for it in items}
+    marks = ",".join("?" * len(items))  # `id IN rarray(?)`
+    rows = database.conn.execute(
+        f"""SELECT id, source_id, external_id, content, name, author, description, modified, last_accessed
+            FROM items WHERE skipped is NULL AND hidden_at IS NULL AND id IN ({marks})""", [it.id for it in items])
+    out = []
+    for r in rows:
+        item = Item(id=r[0], source_id=r[1], external_id=r[2], content=r[3],
+                    metadata=ItemMetadata(name=r[4], author=r[5], description=r[6], mtime=r[7], atime=r[8]))
+        out.append((item, by_id[item.id]))
+    out.sort(key=lambda p: p[1].score)  # search.rs:245 (cosine searchers: use reverse order at the call site)
+    return out
+
+
+def search_and_retrieve(searcher, database, model, sources, num_results, query):
+    """search.rs:249-259"""
+    from .search import encode_query
+
+    return search_vector_and_retrieve(searcher, database, sources, num_results, encode_query(model, query))
