@@ -423,14 +423,14 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
 // more survivors than an f32 screen on random data, for 1/16 of the f32 matrix cost; survivors are
 // re-ranked exactly anyway.  Each wave streams its own blocks straight into registers: the blocked
 // HBM layout makes every load two contiguous 512 B runs, so there is no LDS round trip for the corpus.
-template <int NT, bool NTL>
-__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const ScanParams* __restrict__ pp) {
+template <int NT, bool NTL, int WPB>
+__global__ __launch_bounds__(WPB * 64, WPB == 4 ? 3 : 4) void scan_mfma_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
     extern __shared__ uint4 lq[];  // [NT*32][Dp/8] 16-byte pieces of 8 bf16, swizzled
     const int D4 = p.D4;
     const int P8 = D4 >> 1;   // 16-B pieces per query row
     const int NCH = D4 >> 4;  // chunks of 64 features
-    for (int i = threadIdx.x; i < NT * 32 * P8; i += 256) {
+    for (int i = threadIdx.x; i < NT * 32 * P8; i += WPB * 64) {
         const int q = i / P8, pc = i - q * P8;
         lq[q * P8 + ((pc & ~15) | ((pc ^ q) & 15))] = ((const uint4*)p.qbf16)[i];
     }
@@ -441,8 +441,8 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const ScanParams* __r
 #pragma unroll
     for (int t = 0; t < NT; ++t) mrg[t] = (32 * t + c < p.B) ? p.margin[32 * t + c] : 0.0f;
 
-    const uint32_t total_waves = gridDim.x * 4;
-    uint32_t gb = blockIdx.x * 4 + wave;
+    const uint32_t total_waves = gridDim.x * WPB;
+    uint32_t gb = blockIdx.x * WPB + wave;
     if (gb >= p.total_blocks) return;
 
     f32x16 acc[NT];
@@ -628,6 +628,80 @@ __global__ __launch_bounds__(256) void rescore_kernel(const ScanParams* __restri
         if (cc < inf && cc > -inf) score = cc;
     }
     p.cand_score[(size_t)q * p.cand_cap + j] = score;
+}
+
+// Cooperative form of the rescoring for dim <= 512: a workgroup takes a slice of 1024 survivors of
+// one query, compacts the ones the final threshold still admits, then every wave handles 8 of them
+// at a time — 8 lanes per row fetch its pieces together (all loads in flight at once) into LDS, and
+// one lane per row runs the canonical feature-order f64 sums from there.  Same arithmetic as
+// rescore_kernel, ~10x less latency.
+constexpr int kCoopMaxD4 = 112;  // LDS: (D4 + 32*(D4+1)) * 16 B <= 64 KB
+__global__ __launch_bounds__(256) void rescore_coop_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
+    extern __shared__ float4 lds4[];  // [D4] raw query | 4 waves x 8 slots x (D4+1) row pieces
+    __shared__ uint32_t surv[1024];
+    __shared__ uint32_t nsurv;
+    const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D4 = p.D4;
+    const uint32_t cnt = min(p.cand_cnt[q], p.cand_cap);
+    const uint32_t base = blockIdx.x * 1024u;
+    if (base >= cnt) return;
+    float4* sq = lds4;
+    float4* rows = lds4 + D4 + (size_t)wave * 8 * (D4 + 1);
+    for (int i = tid; i < D4; i += 256) sq[i] = ((const float4*)(p.qraw + (size_t)q * D4 * 4))[i];
+    if (tid == 0) nsurv = 0;
+    __syncthreads();
+    const float thr_final = key_f32(p.tau[q]) - p.margin[q];
+    for (uint32_t j = base + tid; j < min(cnt, base + 1024u); j += 256) {
+        if (p.cand_s[(size_t)q * p.cand_cap + j] < thr_final)
+            p.cand_score[(size_t)q * p.cand_cap + j] = __builtin_nan("");
+        else
+            surv[atomicAdd(&nsurv, 1u)] = j;
+    }
+    __syncthreads();
+    const uint32_t ns = nsurv;
+    const int slot = lane >> 3, part = lane & 7;
+    const double nq = p.qnorm2[q];
+    const double inf = __builtin_inf();
+    for (uint32_t g = wave * 8; g < ns; g += 32) {
+        const uint32_t si = g + slot;
+        const bool live = si < ns;
+        const uint32_t j = live ? surv[si] : 0;
+        if (live) {
+            const uint64_t e = p.cand[(size_t)q * p.cand_cap + j];
+            const SegDesc& sg = p.seg[(int)(e >> 32)];
+            const uint32_t row = (uint32_t)e;
+            const float4* src = sg.blk + (size_t)(row >> 5) * D4 * 32 + (row & 31);
+            for (int f4 = part; f4 < D4; f4 += 8) rows[slot * (D4 + 1) + f4] = src[(size_t)f4 * 32];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0);  // the row pieces of this wave are in LDS
+        if (live && part == 0) {
+            const float4* r = rows + slot * (D4 + 1);
+            double dot = 0.0, nx = 0.0;
+            for (int f4 = 0; f4 < D4; ++f4) {
+                const float4 v = r[f4];
+                const float4 qv = sq[f4];
+                dot += (double)qv.x * (double)v.x;
+                nx += (double)v.x * (double)v.x;
+                dot += (double)qv.y * (double)v.y;
+                nx += (double)v.y * (double)v.y;
+                dot += (double)qv.z * (double)v.z;
+                nx += (double)v.z * (double)v.z;
+                dot += (double)qv.w * (double)v.w;
+                nx += (double)v.w * (double)v.w;
+            }
+            double score = __builtin_nan("");
+            if (p.metric == PCV_METRIC_DOT) {
+                if (dot < inf && dot > -inf && nq == nq) score = dot;
+            } else if (nq >= 0x1p-126 && nq < inf && nx >= 0x1p-126 && nx < inf) {
+                const double cc = dot / (sqrt(nq) * sqrt(nx));
+                if (cc < inf && cc > -inf) score = cc;
+            }
+            p.cand_score[(size_t)q * p.cand_cap + j] = score;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 struct Best {
@@ -901,24 +975,32 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
     const int NT = p.B <= 32 ? 1 : 2;
     const size_t lds = (size_t)NT * 32 * p.D4 * 4 * sizeof(uint16_t);
     const unsigned gm = (p.flags >> 8) & 0xff;
-    unsigned grid = (unsigned)num_cus * (gm ? gm : 3);
-    const unsigned need = (p.total_blocks + 3) / 4;
+    const bool wide = (p.flags & 2) != 0;  // 512-thread workgroups, 4 waves/SIMD (tuning)
+    const unsigned wpb = wide ? 8 : 4;
+    unsigned grid = (unsigned)num_cus * (gm ? gm : (wide ? 2 : 3));
+    const unsigned need = (p.total_blocks + wpb - 1) / wpb;
     if (grid > need) grid = need;
     const bool ntl = (p.flags & 1) == 0;  // non-temporal corpus loads unless flag bit 0 is set
+#define PCV_MFMA(NT_, NTL_)                                                     \
+    if (wide)                                                                   \
+        scan_mfma_kernel<NT_, NTL_, 8><<<grid, 512, lds, st>>>(dp);             \
+    else                                                                        \
+        scan_mfma_kernel<NT_, NTL_, 4><<<grid, 256, lds, st>>>(dp);
     if (NT == 1) {
-        if (ntl)
-            scan_mfma_kernel<1, true><<<grid, 256, lds, st>>>(dp);
-        else
-            scan_mfma_kernel<1, false><<<grid, 256, lds, st>>>(dp);
+        if (ntl) { PCV_MFMA(1, true) } else { PCV_MFMA(1, false) }
     } else {
-        if (ntl)
-            scan_mfma_kernel<2, true><<<grid, 256, lds, st>>>(dp);
-        else
-            scan_mfma_kernel<2, false><<<grid, 256, lds, st>>>(dp);
+        if (ntl) { PCV_MFMA(2, true) } else { PCV_MFMA(2, false) }
     }
+#undef PCV_MFMA
 }
 
 void launch_rescore(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
+    if (p.D4 <= kCoopMaxD4) {
+        const size_t lds = ((size_t)p.D4 + 4 * 8 * ((size_t)p.D4 + 1)) * sizeof(float4);
+        dim3 grid((p.cand_cap + 1023) / 1024, p.B);
+        rescore_coop_kernel<<<grid, 256, lds, st>>>(dp);
+        return;
+    }
     const size_t lds = (size_t)p.D4 * 4 * sizeof(float);
     dim3 grid((p.cand_cap + 255) / 256, p.B);
     rescore_kernel<<<grid, 256, lds, st>>>(dp);

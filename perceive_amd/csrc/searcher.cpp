@@ -87,7 +87,15 @@ struct pcv_searcher {
     DevBuf<uint64_t> d_cand;
     DevBuf<pcv_hit_dev> d_hits;
     DevBuf<ScanParams> d_params;
-    ScanParams h_params{};  // stays alive while the async upload of a pass is in flight
+    // pinned host staging of one pass: inputs go up and results come down with async copies that
+    // never bounce through a driver staging buffer
+    struct Pinned {
+        ScanParams params;
+        uint32_t cnt[kMfmaQueries];
+        pcv_hit_dev hits[kMfmaQueries * kMaxK];
+    };
+    Pinned* pin = nullptr;
+    float* pin_queries = nullptr;  // [64][D]
     uint32_t cand_cap = 8192;
     uint32_t scan_flags = 0;  // tuning knobs, PCV_SCAN_FLAGS
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -246,6 +254,8 @@ void ensure_workspace(pcv_searcher* s) {
     s->d_seed_part.ensure(Q * kSeedParts * kMaxK);
     s->d_hits.ensure(Q * kMaxK);
     s->d_params.ensure(1);
+    if (!s->pin) PCV_HIP(hipHostMalloc((void**)&s->pin, sizeof(pcv_searcher::Pinned), hipHostMallocDefault));
+    if (!s->pin_queries) PCV_HIP(hipHostMalloc((void**)&s->pin_queries, Q * s->D * sizeof(float), hipHostMallocDefault));
     for (auto& e : s->ev)
         if (!e) PCV_HIP(hipEventCreate(&e));
 }
@@ -254,10 +264,11 @@ void ensure_workspace(pcv_searcher* s) {
 void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel) {
     hipStream_t st = s->ctx->stream;
     ensure_workspace(s);
-    PCV_HIP(hipMemcpyAsync(s->d_queries.p, queries_host, (size_t)B * s->D * sizeof(float), hipMemcpyHostToDevice, st));
+    std::memcpy(s->pin_queries, queries_host, (size_t)B * s->D * sizeof(float));
+    PCV_HIP(hipMemcpyAsync(s->d_queries.p, s->pin_queries, (size_t)B * s->D * sizeof(float), hipMemcpyHostToDevice, st));
 
     for (int attempt = 0;; ++attempt) {
-        ScanParams& p = s->h_params;
+        ScanParams& p = s->pin->params;
         p = ScanParams{};
         uint32_t blk0 = 0;
         int64_t rows = 0;
@@ -310,8 +321,9 @@ void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* s
         launch_rescore(st, p, dp);
         launch_select(st, p, dp, s->d_hits.p);
         PCV_HIP(hipEventRecord(s->ev[3], st));
-        uint32_t cnt[kMfmaQueries];
+        uint32_t* cnt = s->pin->cnt;
         PCV_HIP(hipMemcpyAsync(cnt, s->d_cnt.p, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PCV_HIP(hipMemcpyAsync(s->pin->hits, s->d_hits.p, (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
         PCV_HIP(hipStreamSynchronize(st));
         PCV_HIP(hipGetLastError());
 
@@ -379,7 +391,7 @@ void search_hits(pcv_searcher* s, const float* queries, int n_queries, const int
         for (size_t g0 = 0; g0 < segs.size(); g0 += kMaxSeg) {
             const int nseg = (int)std::min<size_t>(kMaxSeg, segs.size() - g0);
             run_pass(s, queries + (size_t)q0 * s->D, B, segs.data() + g0, nseg, k, kernel);
-            PCV_HIP(hipMemcpy(tmp.data(), s->d_hits.p, (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost));
+            std::memcpy(tmp.data(), s->pin->hits, (size_t)B * k * sizeof(pcv_hit_dev));  // came down with the pass
             for (int b = 0; b < B; ++b) {
                 pcv_hit_dev* dst = out.data() + (size_t)(q0 + b) * k;
                 if (g0 == 0) {
@@ -476,6 +488,8 @@ pcv_status pcv_searcher_destroy(pcv_searcher* s) {
         s->d_cand.release();
         s->d_hits.release();
         s->d_params.release();
+        if (s->pin) hipHostFree(s->pin);
+        if (s->pin_queries) hipHostFree(s->pin_queries);
         if (s->d_max_norm_bits) hipFree(s->d_max_norm_bits);
         for (auto& e : s->ev)
             if (e) hipEventDestroy(e);
