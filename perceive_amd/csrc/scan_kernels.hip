@@ -423,8 +423,11 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
 // more survivors than an f32 screen on random data, for 1/16 of the f32 matrix cost; survivors are
 // re-ranked exactly anyway.  Each wave streams its own blocks straight into registers: the blocked
 // HBM layout makes every load two contiguous 512 B runs, so there is no LDS round trip for the corpus.
-template <int NT, bool NTL, int WPB>
-__global__ __launch_bounds__(WPB * 64, WPB == 4 ? 3 : 4) void scan_mfma_kernel(const ScanParams* __restrict__ pp) {
+// (A 512-thread / 4-waves-per-SIMD build was tried: the 128-VGPR cap spills 23 registers into the
+// chunk loop and runs 15 % slower; 3 waves/SIMD at 155 VGPRs is the measured optimum.)
+template <int NT, bool NTL>
+__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const ScanParams* __restrict__ pp) {
+    constexpr int WPB = 4;
     const ScanParams& p = *pp;
     extern __shared__ uint4 lq[];  // [NT*32][Dp/8] 16-byte pieces of 8 bf16, swizzled
     const int D4 = p.D4;
@@ -975,17 +978,11 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
     const int NT = p.B <= 32 ? 1 : 2;
     const size_t lds = (size_t)NT * 32 * p.D4 * 4 * sizeof(uint16_t);
     const unsigned gm = (p.flags >> 8) & 0xff;
-    const bool wide = (p.flags & 2) != 0;  // 512-thread workgroups, 4 waves/SIMD (tuning)
-    const unsigned wpb = wide ? 8 : 4;
-    unsigned grid = (unsigned)num_cus * (gm ? gm : (wide ? 2 : 3));
-    const unsigned need = (p.total_blocks + wpb - 1) / wpb;
+    unsigned grid = (unsigned)num_cus * (gm ? gm : 3);
+    const unsigned need = (p.total_blocks + 3) / 4;
     if (grid > need) grid = need;
     const bool ntl = (p.flags & 1) == 0;  // non-temporal corpus loads unless flag bit 0 is set
-#define PCV_MFMA(NT_, NTL_)                                                     \
-    if (wide)                                                                   \
-        scan_mfma_kernel<NT_, NTL_, 8><<<grid, 512, lds, st>>>(dp);             \
-    else                                                                        \
-        scan_mfma_kernel<NT_, NTL_, 4><<<grid, 256, lds, st>>>(dp);
+#define PCV_MFMA(NT_, NTL_) scan_mfma_kernel<NT_, NTL_><<<grid, 256, lds, st>>>(dp);
     if (NT == 1) {
         if (ntl) { PCV_MFMA(1, true) } else { PCV_MFMA(1, false) }
     } else {
