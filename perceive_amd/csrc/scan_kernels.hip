@@ -45,18 +45,10 @@ __device__ __forceinline__ int find_seg(const ScanParams& p, uint32_t gb) {
     return s;
 }
 
-// A surviving (query,row) pair: append to the query's candidate list and, unless the row was
-// already ranked by the seed kernel, try to raise the running k-th best.
 // slots[q][0..k) always hold approximate scores of k DISTINCT rows (or -inf), each slot only ever
 // grows, so min(slots) is a valid lower bound of the final k-th best approximate score.
-__device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint32_t row, float s,
-                                      bool feeds_slots) {
-    uint32_t idx = atomicAdd(&p.cand_cnt[q], 1u);
-    if (idx < p.cand_cap) {
-        p.cand[(size_t)q * p.cand_cap + idx] = ((uint64_t)(uint32_t)seg << 32) | row;
-        p.cand_s[(size_t)q * p.cand_cap + idx] = s;
-    }
-    if (!feeds_slots || !isfinite(s)) return;
+// offer_slot: try to replace the current minimum by the score `s` of a row not yet in the slots.
+__device__ __forceinline__ void offer_slot(const ScanParams& p, int q, float s) {
     const uint32_t key = f32_key(s);
     uint32_t* sl = p.slots + (size_t)q * kMaxK;
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -77,6 +69,18 @@ __device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint3
             return;
         }
     }
+}
+
+// A surviving (query,row) pair: append to the query's candidate list and, unless the row was
+// already ranked by the seed kernel, try to raise the running k-th best.
+__device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint32_t row, float s,
+                                      bool feeds_slots) {
+    uint32_t idx = atomicAdd(&p.cand_cnt[q], 1u);
+    if (idx < p.cand_cap) {
+        p.cand[(size_t)q * p.cand_cap + idx] = ((uint64_t)(uint32_t)seg << 32) | row;
+        p.cand_s[(size_t)q * p.cand_cap + idx] = s;
+    }
+    if (feeds_slots && isfinite(s)) offer_slot(p, q, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -501,18 +505,45 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const ScanParams* __r
             for (int i = 0; i < 16; ++i) any |= !(acc[t][i] < thr[t]);
         }
         if (__any(any)) {
+            // Rare path, kept short because every wave takes it in its first block (the threshold is
+            // still the seed's): each lane owns one query per tile, so it reserves list space for all
+            // its hits with ONE atomic, stores them, and offers only its best hit to the running
+            // top-k — a handful of memory round trips per block instead of one chain per hit.
             const bool feeds = !(esi == 0 && elb < p.seed_blocks);
             const float* scp = p.seg[esi].scale + (size_t)elb * 32;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int q = 32 * t + c;
+                uint32_t hitmask = 0;
+                float best = -__builtin_inff();
+                if (q < p.B) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float s = acc[t][i];  // the row scale is already folded into the A operand
-                    if (!(s < thr[t]) && q < p.B) {
-                        const uint32_t r = (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (scp[r] != 0.0f) emit_hit(p, q, esi, elb * 32 + r, s, feeds);
+                    for (int i = 0; i < 16; ++i) {
+                        const float s = acc[t][i];  // the row scale is already folded into the A operand
+                        if (!(s < thr[t])) {
+                            // a zero / non-finite score may belong to a padding or invalid row (scale 0)
+                            const bool suspect = (s == 0.0f) || !isfinite(s);
+                            if (!suspect || scp[(i & 3) + 8 * (i >> 2) + 4 * h] != 0.0f) {
+                                hitmask |= 1u << i;
+                                if (isfinite(s)) best = fmaxf(best, s);
+                            }
+                        }
                     }
+                }
+                if (hitmask) {
+                    const uint32_t n = __builtin_popcount(hitmask);
+                    uint32_t idx = atomicAdd(&p.cand_cnt[q], n);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (hitmask & (1u << i)) {
+                            if (idx < p.cand_cap) {
+                                const uint32_t row = elb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                                p.cand[(size_t)q * p.cand_cap + idx] = ((uint64_t)(uint32_t)esi << 32) | row;
+                                p.cand_s[(size_t)q * p.cand_cap + idx] = acc[t][i];
+                            }
+                            ++idx;
+                        }
+                    if (feeds && best > -__builtin_inff()) offer_slot(p, q, best);
                 }
             }
         }
