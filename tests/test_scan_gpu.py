@@ -331,3 +331,76 @@ def test_error_paths(ctx):
     s.close()
     with pytest.raises(pa.PcvError):
         pa.Searcher(ctx, 0, "cosine")
+
+
+def test_dim_768_and_more_than_64_queries(ctx, oracle):
+    # the product's default model (MsMarcoBertBaseDotV5) is 768-d and ranks by dot product;
+    # 130 queries = three passes of <= 64
+    rng = np.random.default_rng(31)
+    N, D, B = 20_000, 768, 130
+    m = rng.standard_normal((N, D)).astype(np.float32)
+    q = rng.standard_normal((B, D)).astype(np.float32)
+    for metric in ("dot", "cosine"):
+        s = build(ctx, m, metric=metric)
+        ids, sc, cnt = s.search_vectors(None, 10, q)
+        opos, osc, _ = oracle.topk(q, m, 10, metric=1 if metric == "dot" else 0)
+        np.testing.assert_array_equal(ids, opos)
+        if metric == "cosine":
+            np.testing.assert_allclose(sc, osc.astype(np.float32), atol=1e-7)
+        else:
+            np.testing.assert_allclose(sc, np.maximum(0, 1 - osc / D).astype(np.float32), atol=1e-6)
+        s.close()
+
+
+def test_concurrent_searches_from_threads(ctx, oracle):
+    # `&self` search is called from a thread pool in the reference (Arc<Searcher>, app_state.rs:52-57)
+    import threading
+
+    rng = np.random.default_rng(41)
+    m = rng.standard_normal((30_000, 384)).astype(np.float32)
+    s = build(ctx, m)
+    qs = rng.standard_normal((8, 3, 384)).astype(np.float32)
+    exp = [oracle.topk(qs[i], m, 5)[0] for i in range(8)]
+    got, errs = [None] * 8, []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                got[i] = s.search_vectors(None, 5, qs[i])[0]
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    for i in range(8):
+        np.testing.assert_array_equal(got[i], exp[i])
+    s.close()
+
+
+def test_create_destroy_does_not_leak(ctx):
+    import ctypes as C
+
+    from perceive_amd import _ffi
+
+    hip = C.CDLL("libamdhip64.so")
+    free0, total = C.c_size_t(), C.c_size_t()
+    rng = np.random.default_rng(1)
+    m = rng.standard_normal((50_000, 384)).astype(np.float32)
+    q = rng.standard_normal((5, 384)).astype(np.float32)
+
+    def cycle():
+        s = build(ctx, m)
+        s.search_vectors(None, 10, q)
+        s.close()
+
+    cycle()
+    ctx.synchronize()
+    hip.hipMemGetInfo(C.byref(free0), C.byref(total))
+    for _ in range(5):
+        cycle()
+    ctx.synchronize()
+    free1 = C.c_size_t()
+    hip.hipMemGetInfo(C.byref(free1), C.byref(total))
+    assert free0.value - free1.value < 64 << 20, (free0.value, free1.value)
