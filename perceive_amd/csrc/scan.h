@@ -21,7 +21,7 @@ constexpr int kMaxK = 128;          // largest num_results the running top-k slo
 constexpr int kSeedPartRows = 1024;  // rows one seed workgroup ranks
 constexpr int kSeedParts = 16;       // seed workgroups per query -> up to 16384 seed rows
 constexpr int kMaxWaveQueries = 4;  // wave-reduction kernel handles 1..4 queries per pass
-constexpr int kMfmaQueries = 64;    // MFMA kernel handles up to 64 queries per pass
+constexpr int kMfmaQueries = 128;   // MFMA kernel handles up to 128 queries per pass
 
 struct SegDesc {
     const float4* blk;   // blocked matrix
@@ -57,7 +57,7 @@ struct ScanParams {
     uint32_t* seed_part;     // [B][kSeedParts][kMaxK] per-part seed keys
     uint32_t cand_cap;
     uint32_t seed_blocks;    // leading blocks of segment 0 ranked by the seed kernel
-    uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bits 8..: grid multiplier override (tuning)
+    uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bits 8..15: workgroups per CU override (tuning)
 };
 
 // float <-> order-preserving uint32 key (for atomicMax / CAS on scores)
@@ -95,6 +95,7 @@ void launch_prep_queries(hipStream_t st, const float* d_queries, int B, int D, i
 void launch_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp);  // seed_partial + seed_merge
 void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);
 void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);
+int mfma_pass_queries(int Dp);  // queries one MFMA pass can take at this padded dim (LDS-limited), 0 = none
 void launch_rescore(hipStream_t st, const ScanParams& p, const ScanParams* dp);
 void launch_select(hipStream_t st, const ScanParams& p, const ScanParams* dp, pcv_hit_dev* out);
 void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out);

@@ -427,11 +427,25 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
 // more survivors than an f32 screen on random data, for 1/16 of the f32 matrix cost; survivors are
 // re-ranked exactly anyway.  Each wave streams its own blocks straight into registers: the blocked
 // HBM layout makes every load two contiguous 512 B runs, so there is no LDS round trip for the corpus.
-// (A 512-thread / 4-waves-per-SIMD build was tried: the 128-VGPR cap spills 23 registers into the
-// chunk loop and runs 15 % slower; 3 waves/SIMD at 155 VGPRs is the measured optimum.)
-template <int NT, bool NTL>
-__global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const ScanParams* __restrict__ pp) {
-    constexpr int WPB = 4;
+// Variants: NT = 32-query tiles per wave (1, 2 -> B <= 64; 4 -> B <= 128), WPB = waves per
+// workgroup, NBUF = chunk buffers per wave (NBUF-1 chunks of loads in flight while one is consumed).
+//   B <= 64 : 256 threads, 3 workgroups/CU (155 VGPR, 3 waves/SIMD), NBUF 2 (NBUF 3 at 2 waves/SIMD
+//             measured no faster)
+//   B <= 128: 512 threads sharing one 96 KB query tile, 1 workgroup/CU, 2 waves/SIMD, NBUF 3: the
+//             scan stays HBM-bound (MFMA ~25 % busy), so 128 queries cost the same 23 ms as 64
+// (A 512-thread / 4-waves-per-SIMD build of the B <= 64 kernel was tried: the 128-VGPR cap spills 23
+// registers into the chunk loop and runs 15 % slower.)
+struct BlockCursor {  // position of a wave in its flat (block, chunk) stream
+    uint32_t gb;      // launch-wide block index (>= total_blocks: exhausted)
+    int si;           // segment
+    uint32_t lb;      // block inside the segment
+    const float4* base;
+    int ch;           // chunk inside the block
+};
+
+template <int NT, bool NTL, int WPB, int NBUF>
+__global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void scan_mfma_kernel(
+    const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
     extern __shared__ uint4 lq[];  // [NT*32][Dp/8] 16-byte pieces of 8 bf16, swizzled
     const int D4 = p.D4;
@@ -449,8 +463,7 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const ScanParams* __r
     for (int t = 0; t < NT; ++t) mrg[t] = (32 * t + c < p.B) ? p.margin[32 * t + c] : 0.0f;
 
     const uint32_t total_waves = gridDim.x * WPB;
-    uint32_t gb = blockIdx.x * WPB + wave;
-    if (gb >= p.total_blocks) return;
+    if (blockIdx.x * WPB + wave >= p.total_blocks) return;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -458,43 +471,46 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const ScanParams* __r
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
-    int si = find_seg(p, gb);
-    uint32_t lb = gb - p.seg[si].blk0;
-    const float4* base = p.seg[si].blk + (size_t)lb * D4 * 32 + h * 64 + c;
-    int ch = 0;
+    auto enter_block = [&](BlockCursor& k, uint32_t gb) {
+        k.gb = gb;
+        k.ch = 0;
+        if (gb < p.total_blocks) {
+            k.si = find_seg(p, gb);
+            k.lb = gb - p.seg[k.si].blk0;
+            k.base = p.seg[k.si].blk + (size_t)k.lb * D4 * 32 + h * 64 + c;
+        }
+    };
+    BlockCursor cons, prod;  // consumer (MFMA) and producer (loads) positions; prod runs NBUF-1 chunks ahead
+    enter_block(cons, blockIdx.x * WPB + wave);
+    prod = cons;
     // scale of this lane's row (1/|x|, 1 or 0): multiplied into the A operand before the bf16
-    // rounding, so the accumulators are final screening scores
-    float sc_cur = p.seg[si].scale[(size_t)lb * 32 + c], sc_next = 0.0f;
+    // rounding, so the accumulators are final screening scores.  sc_next belongs to the block the
+    // producer has entered but the consumer has not.
+    float sc_cur = p.seg[cons.si].scale[(size_t)cons.lb * 32 + c], sc_next = 0.0f;
 
-    float4 buf0[8], buf1[8];
-#define PCV_LOAD(buf, bptr, chunk)                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)(buf)[i_] =                         \
-        ld_row<NTL>((bptr) + (size_t)((chunk)*16 + (i_ >> 1) * 4 + (i_ & 1)) * 32);
-    // lane's pieces of k-step ks of the chunk: f4 = chunk*16 + ks*4 + 2h + e  (2h folded into base)
+    float4 buf[NBUF][8];
+    // lane's pieces of k-step ks of a chunk: f4 = chunk*16 + ks*4 + 2h + e  (2h folded into base)
+    auto produce = [&](float4 (&b)[8]) {
+        if (prod.gb >= p.total_blocks) return;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 16 + (i >> 1) * 4 + (i & 1)) * 32);
+        if (++prod.ch == NCH) {
+            enter_block(prod, prod.gb + total_waves);
+            if (prod.gb < p.total_blocks) sc_next = p.seg[prod.si].scale[(size_t)prod.lb * 32 + c];
+        }
+    };
 
-#define PCV_COMPUTE(buf, chunk)                                                                        \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                              \
-        f32x8 v_ = {(buf)[2 * ks_].x,     (buf)[2 * ks_].y,     (buf)[2 * ks_].z,     (buf)[2 * ks_].w,  \
-                    (buf)[2 * ks_ + 1].x, (buf)[2 * ks_ + 1].y, (buf)[2 * ks_ + 1].z, (buf)[2 * ks_ + 1].w}; \
-        const bf16x8 a_ = __builtin_convertvector(v_ * sc_cur, bf16x8);                                         \
-        const int pc_ = 2 * ((chunk)*4 + ks_) + h;                                                     \
-        const int ph_ = (pc_ & ~15) | ((pc_ ^ c) & 15);                                                \
-        _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) {                                            \
-            const bf16x8 b_ = *(const bf16x8*)&lq[(32 * t_ + c) * P8 + ph_];                           \
-            acc[t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, acc[t_], 0, 0, 0);               \
-        }                                                                                              \
-    }
-
-    // thresholds of the block being finished: issued one step ahead of the epilogue (together with
-    // the prefetch of the block's last chunk) so their latency is not exposed
+    // thresholds of the block being finished: issued one chunk ahead of the epilogue so their
+    // latency is not exposed
     uint32_t tauk[NT];
-    auto ep_prefetch = [&](int, uint32_t) {
+    auto tau_prefetch = [&]() {
 #pragma unroll
         for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? ld_relaxed(&p.tau[32 * t + c]) : 0u;
     };
 
     auto epilogue = [&](int esi, uint32_t elb) {
-        if (NCH < 2) ep_prefetch(esi, elb);
+        if (NCH < 2) tau_prefetch();
         float thr[NT];
         bool any = false;
 #pragma unroll
@@ -553,65 +569,50 @@ __global__ __launch_bounds__(256, 3) void scan_mfma_kernel(const ScanParams* __r
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     };
 
-    // flat (block, chunk) stream with two register buffers: the loads of step g+1 are in flight
-    // while step g feeds the matrix cores
-    PCV_LOAD(buf0, base, 0);
-    while (true) {
-        // ---- even step: consume buf0, prefetch into buf1
-        int nch = ch + 1;
-        uint32_t ngb = gb;
-        int nsi = si;
-        uint32_t nlb = lb;
-        const float4* nbase = base;
-        if (nch == NCH) {
-            nch = 0;
-            ngb = gb + total_waves;
-            if (ngb < p.total_blocks) {
-                nsi = find_seg(p, ngb);
-                nlb = ngb - p.seg[nsi].blk0;
-                nbase = p.seg[nsi].blk + (size_t)nlb * D4 * 32 + h * 64 + c;
-                sc_next = p.seg[nsi].scale[(size_t)nlb * 32 + c];
+    auto consume = [&](const float4 (&b)[8]) {
+        if (NCH >= 2 && cons.ch == NCH - 2) tau_prefetch();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f32x8 v = {b[2 * ks].x,     b[2 * ks].y,     b[2 * ks].z,     b[2 * ks].w,
+                       b[2 * ks + 1].x, b[2 * ks + 1].y, b[2 * ks + 1].z, b[2 * ks + 1].w};
+            const bf16x8 a = __builtin_convertvector(v * sc_cur, bf16x8);
+            const int pc = 2 * (cons.ch * 4 + ks) + h;
+            const int ph = (pc & ~15) | ((pc ^ c) & 15);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 q8 = *(const bf16x8*)&lq[(32 * t + c) * P8 + ph];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q8, acc[t], 0, 0, 0);
             }
         }
-        bool more = ngb < p.total_blocks;
-        if (more) { PCV_LOAD(buf1, nbase, nch); }
-        if (ch == NCH - 2) ep_prefetch(si, lb);
-        PCV_COMPUTE(buf0, ch);
-        if (ch == NCH - 1) {
-            epilogue(si, lb);
+        if (++cons.ch == NCH) {
+            epilogue(cons.si, cons.lb);
+            enter_block(cons, cons.gb + total_waves);
             sc_cur = sc_next;
         }
-        if (!more) break;
-        ch = nch; gb = ngb; si = nsi; lb = nlb; base = nbase;
-        // ---- odd step: consume buf1, prefetch into buf0
-        nch = ch + 1;
-        ngb = gb;
-        nsi = si;
-        nlb = lb;
-        nbase = base;
-        if (nch == NCH) {
-            nch = 0;
-            ngb = gb + total_waves;
-            if (ngb < p.total_blocks) {
-                nsi = find_seg(p, ngb);
-                nlb = ngb - p.seg[nsi].blk0;
-                nbase = p.seg[nsi].blk + (size_t)nlb * D4 * 32 + h * 64 + c;
-                sc_next = p.seg[nsi].scale[(size_t)nlb * 32 + c];
-            }
+    };
+
+    // NBUF-1 chunks of loads are always in flight while one chunk feeds the matrix cores
+    // (written out per buffer: every buf[] index must be a literal, or the array moves to scratch)
+#define PCV_STEP(REFILL, CONS)          \
+    produce(buf[REFILL]);               \
+    consume(buf[CONS]);                 \
+    if (cons.gb >= p.total_blocks) return;
+    produce(buf[0]);
+    if constexpr (NBUF == 2) {
+        while (true) {
+            PCV_STEP(1, 0)
+            PCV_STEP(0, 1)
         }
-        more = ngb < p.total_blocks;
-        if (more) { PCV_LOAD(buf0, nbase, nch); }
-        if (ch == NCH - 2) ep_prefetch(si, lb);
-        PCV_COMPUTE(buf1, ch);
-        if (ch == NCH - 1) {
-            epilogue(si, lb);
-            sc_cur = sc_next;
+    } else {
+        static_assert(NBUF == 3, "2 or 3 chunk buffers");
+        produce(buf[1]);
+        while (true) {
+            PCV_STEP(2, 0)
+            PCV_STEP(0, 1)
+            PCV_STEP(1, 2)
         }
-        if (!more) break;
-        ch = nch; gb = ngb; si = nsi; lb = nlb; base = nbase;
     }
-#undef PCV_LOAD
-#undef PCV_COMPUTE
+#undef PCV_STEP
 }
 
 // Exact canonical score of every surviving (query,row) pair: f64, products exact, sums in feature
@@ -1004,20 +1005,52 @@ void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp,
 #undef PCV_WAVE
 }
 
+// Largest query count one MFMA pass can take at this padded dim: the bf16 query tile
+// (32*NT rows x Dp) must fit the 160 KB LDS of a CU.  0: the tile does not fit at all.
+int mfma_pass_queries(int Dp) {
+    for (int nt : {4, 2, 1})
+        if ((size_t)nt * 32 * Dp * 2 <= 156 * 1024) return nt * 32;
+    return 0;
+}
+
+template <int NT, bool NTL, int WPB, int NBUF>
+static void launch_mfma_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;  // one flag per instantiation
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)scan_mfma_kernel<NT, NTL, WPB, NBUF>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+    }
+    scan_mfma_kernel<NT, NTL, WPB, NBUF><<<grid, WPB * 64, lds, st>>>(dp);
+}
+
 void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
     if (p.total_blocks == 0) return;
-    const int NT = p.B <= 32 ? 1 : 2;
+    const int NT = p.B <= 32 ? 1 : (p.B <= 64 ? 2 : 4);
     const size_t lds = (size_t)NT * 32 * p.D4 * 4 * sizeof(uint16_t);
     const unsigned gm = (p.flags >> 8) & 0xff;
-    unsigned grid = (unsigned)num_cus * (gm ? gm : 3);
-    const unsigned need = (p.total_blocks + 3) / 4;
+    const bool ntl = (p.flags & 1) == 0;   // non-temporal corpus loads unless flag bit 0 is set
+    // small tiles: 256-thread workgroups, 3 per CU.  Tiles too big for that (B > 64, or dim > ~440):
+    // 512-thread workgroups sharing one tile, as many per CU as the LDS holds.
+    const bool wide = NT == 4 || lds * 3 > 156 * 1024;
+    const unsigned wpb = wide ? 8 : 4;
+    const unsigned per_cu = wide ? (unsigned)std::max<size_t>(1, std::min<size_t>(2, (156 * 1024) / lds)) : 3;
+    unsigned grid = (unsigned)num_cus * (gm ? gm : per_cu);
+    const unsigned need = (p.total_blocks + wpb - 1) / wpb;
     if (grid > need) grid = need;
-    const bool ntl = (p.flags & 1) == 0;  // non-temporal corpus loads unless flag bit 0 is set
-#define PCV_MFMA(NT_, NTL_) scan_mfma_kernel<NT_, NTL_><<<grid, 256, lds, st>>>(dp);
+#define PCV_MFMA(NT_, NTL_)                                                      \
+    if (wide)                                                                    \
+        launch_mfma_variant<NT_, NTL_, 8, 3>(st, dp, grid, lds);                 \
+    else                                                                         \
+        launch_mfma_variant<NT_, NTL_, 4, 2>(st, dp, grid, lds);
     if (NT == 1) {
         if (ntl) { PCV_MFMA(1, true) } else { PCV_MFMA(1, false) }
-    } else {
+    } else if (NT == 2) {
         if (ntl) { PCV_MFMA(2, true) } else { PCV_MFMA(2, false) }
+    } else {
+        if (ntl) { launch_mfma_variant<4, true, 8, 3>(st, dp, grid, lds); } else { launch_mfma_variant<4, false, 8, 3>(st, dp, grid, lds); }
     }
 #undef PCV_MFMA
 }

@@ -366,8 +366,15 @@ bool hit_better(const pcv_hit_dev& a, const pcv_hit_dev& b) {
 }
 
 int pick_kernel(const pcv_searcher* s, int B) {
+    const bool mfma_ok = mfma_pass_queries(s->Dp) > 0;  // the query tile must fit the LDS
+    if (s->kernel == PCV_KERNEL_MFMA && !mfma_ok)
+        PCV_FAIL(PCV_ERR_UNSUPPORTED, "the MFMA kernel cannot hold a %d-d query tile in LDS", s->D);
     if (s->kernel == PCV_KERNEL_WAVE || s->kernel == PCV_KERNEL_MFMA) return s->kernel;
-    return B <= kMaxWaveQueries ? PCV_KERNEL_WAVE : PCV_KERNEL_MFMA;
+    return (B <= kMaxWaveQueries || !mfma_ok) ? PCV_KERNEL_WAVE : PCV_KERNEL_MFMA;
+}
+
+int pass_queries(const pcv_searcher* s, int kernel) {
+    return kernel == PCV_KERNEL_WAVE ? kMaxWaveQueries : mfma_pass_queries(s->Dp);
 }
 
 // Full search: any number of queries / segments; result [n_queries][k] hits on the host.
@@ -384,7 +391,7 @@ void search_hits(pcv_searcher* s, const float* queries, int n_queries, const int
     const int kernel = pick_kernel(s, n_queries);
     s->stats.kernel_used = kernel;
     if (segs.empty()) return;
-    const int qstep = (kernel == PCV_KERNEL_WAVE) ? kMaxWaveQueries : kMfmaQueries;
+    const int qstep = pass_queries(s, kernel);
     std::vector<pcv_hit_dev> tmp((size_t)qstep * k);
     for (int q0 = 0; q0 < n_queries; q0 += qstep) {
         const int B = std::min(qstep, n_queries - q0);
@@ -688,7 +695,7 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
         PCV_HIP(hipSetDevice(s->ctx->device));
         std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
         const int kernel = pick_kernel(s, n_queries);
-        const int qstep = (kernel == PCV_KERNEL_WAVE) ? kMaxWaveQueries : kMfmaQueries;
+        const int qstep = pass_queries(s, kernel);
         s->stats = pcv_scan_stats{};
         s->stats.kernel_used = kernel;
         if (segs.size() <= (size_t)kMaxSeg && !segs.empty()) {

@@ -222,7 +222,7 @@ def test_synthetic_fill_beyond_2_pow_32_work_items(ctx, oracle):
     s.close()
 
 
-@pytest.mark.parametrize("B,kernel", [(1, "wave"), (4, "wave"), (8, "mfma"), (64, "mfma")])
+@pytest.mark.parametrize("B,kernel", [(1, "wave"), (4, "wave"), (8, "mfma"), (64, "mfma"), (100, "mfma"), (128, "mfma")])
 def test_medium_random_vs_oracle(ctx, oracle, B, kernel):
     N = 200_000 if B <= 8 else 60_000
     s = pa.Searcher(ctx, 384, "cosine")
