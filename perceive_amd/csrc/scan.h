@@ -21,6 +21,8 @@ constexpr int kMaxK = 128;          // largest num_results the running top-k slo
 constexpr int kSeedPartRows = 1024;  // rows one seed workgroup ranks
 constexpr int kSeedParts = 16;       // seed workgroups per query -> up to 16384 seed rows
 constexpr int kMaxWaveQueries = 4;  // wave-reduction kernel handles 1..4 queries per pass
+constexpr int kHot = 256;            // uint32 words between per-query hot words (tau, cand_cnt): 1 KB apart,
+                                     // so the device-wide atomics on them do not queue on one HBM channel
 constexpr int kMfmaQueries = 128;   // MFMA kernel handles up to 128 queries per pass
 
 struct SegDesc {
@@ -48,9 +50,10 @@ struct ScanParams {
     const float* qraw;       // [B][Dp]   original query values (exact rescoring)
     const double* qnorm2;    // [B]       f64 |q|^2
     const float* margin;     // [B]       2*eps in score units: rows with s < tau - margin are dropped
-    uint32_t* tau;           // [B]       ordered key of the running k-th best approximate score
+    uint32_t* tau;           // [B*kHot]  ordered key of the running k-th best approximate score (word q*kHot)
     uint32_t* slots;         // [B][kMaxK] ordered keys of k distinct rows' approximate scores
-    uint32_t* cand_cnt;      // [B]
+    uint32_t* cand_cnt;      // [B*kHot]  survivors emitted per query (word q*kHot)
+    uint32_t* cand_cnt_out;  // [B]       compact copy written by select_kernel for the host
     uint64_t* cand;          // [B][cand_cap]  (segment index << 32) | row
     float* cand_s;           // [B][cand_cap]  screening score the row was emitted with
     double* cand_score;      // [B][cand_cap]  canonical score, filled by the rescoring kernel

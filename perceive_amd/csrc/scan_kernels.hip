@@ -65,9 +65,58 @@ __device__ __forceinline__ void offer_slot(const ScanParams& p, int q, float s) 
         if (atomicCAS(&sl[mi], mn, key) == mn) {
             uint32_t nm = 0xffffffffu;
             for (int i = 0; i < p.k; ++i) nm = min(nm, ld_relaxed(&sl[i]));
-            atomicMax(&p.tau[q], nm);
+            atomicMax(&p.tau[q * kHot], nm);
             return;
         }
+    }
+}
+
+// offer_slot for the NT queries a lane owns (query 32*t + c), all chains advancing in lock step so
+// their memory round trips overlap.
+template <int NT>
+__device__ __forceinline__ void offer_slots(const ScanParams& p, int c, const bool (&want)[NT], const float (&s)[NT]) {
+    bool live[NT];
+    uint32_t key[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        live[t] = want[t];
+        key[t] = f32_key(s[t]);
+    }
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        uint32_t mn[NT];
+        int mi[NT];
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            mn[t] = 0xffffffffu;
+            mi[t] = 0;
+            if (live[t]) {
+                const uint32_t* sl = p.slots + (size_t)(32 * t + c) * kMaxK;
+                for (int i = 0; i < p.k; ++i) {
+                    const uint32_t v = ld_relaxed(&sl[i]);
+                    if (v < mn[t]) {
+                        mn[t] = v;
+                        mi[t] = i;
+                    }
+                }
+                if (key[t] <= mn[t]) live[t] = false;
+            }
+            any |= live[t];
+        }
+        if (!any) return;
+        uint32_t old[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            old[t] = live[t] ? atomicCAS(&p.slots[(size_t)(32 * t + c) * kMaxK + mi[t]], mn[t], key[t]) : 0u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (live[t] && old[t] == mn[t]) {
+                const uint32_t* sl = p.slots + (size_t)(32 * t + c) * kMaxK;
+                uint32_t nm = 0xffffffffu;
+                for (int i = 0; i < p.k; ++i) nm = min(nm, ld_relaxed(&sl[i]));
+                atomicMax(&p.tau[(32 * t + c) * kHot], nm);
+                live[t] = false;
+            }
     }
 }
 
@@ -75,7 +124,7 @@ __device__ __forceinline__ void offer_slot(const ScanParams& p, int q, float s) 
 // already ranked by the seed kernel, try to raise the running k-th best.
 __device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint32_t row, float s,
                                       bool feeds_slots) {
-    uint32_t idx = atomicAdd(&p.cand_cnt[q], 1u);
+    uint32_t idx = atomicAdd(&p.cand_cnt[q * kHot], 1u);
     if (idx < p.cand_cap) {
         p.cand[(size_t)q * p.cand_cap + idx] = ((uint64_t)(uint32_t)seg << 32) | row;
         p.cand_s[(size_t)q * p.cand_cap + idx] = s;
@@ -256,8 +305,8 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
         float m = 2.0f * eps_rel;
         if (metric == PCV_METRIC_DOT) m *= (float)sqrt(nq) * max_norm * 1.0001f;
         margin[q] = m;
-        tau[q] = kKeyNegInf;
-        cand_cnt[q] = 0;
+        tau[q * kHot] = kKeyNegInf;
+        cand_cnt[q * kHot] = 0;
     }
 }
 
@@ -355,7 +404,7 @@ __global__ __launch_bounds__(256) void seed_merge_kernel(const ScanParams* __res
     __syncthreads();
     topk_keys_lds(keys, n, p.k, red4, outk);
     for (int j = tid; j < p.k; j += 256) p.slots[(size_t)q * kMaxK + j] = outk[j] ? outk[j] : kKeyNegInf;
-    if (tid == 0) p.tau[q] = outk[p.k - 1] ? outk[p.k - 1] : kKeyNegInf;  // k-th best seed row, -inf if fewer
+    if (tid == 0) p.tau[q * kHot] = outk[p.k - 1] ? outk[p.k - 1] : kKeyNegInf;  // k-th best seed row, -inf if fewer
 }
 
 // Wave-reduction scan for 1..4 queries (BASELINE config "10M x 384, batch=1"): pure HBM streaming.
@@ -386,7 +435,7 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
         const float sc = sg.scale[row];
         uint32_t tk[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) tk[b] = ld_relaxed(&p.tau[b]);
+        for (int b = 0; b < NB; ++b) tk[b] = ld_relaxed(&p.tau[b * kHot]);
         float acc[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
@@ -506,7 +555,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
     uint32_t tauk[NT];
     auto tau_prefetch = [&]() {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? ld_relaxed(&p.tau[32 * t + c]) : 0u;
+        for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? ld_relaxed(&p.tau[(32 * t + c) * kHot]) : 0u;
     };
 
     auto epilogue = [&](int esi, uint32_t elb) {
@@ -521,17 +570,23 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
             for (int i = 0; i < 16; ++i) any |= !(acc[t][i] < thr[t]);
         }
         if (__any(any)) {
-            // Rare path, kept short because every wave takes it in its first block (the threshold is
-            // still the seed's): each lane owns one query per tile, so it reserves list space for all
-            // its hits with ONE atomic, stores them, and offers only its best hit to the running
-            // top-k — a handful of memory round trips per block instead of one chain per hit.
+            // Rare path — but every wave takes it a handful of times while the thresholds are still
+            // loose, and under a saturated memory system each dependent round trip costs ~4 us, so it
+            // is organised in phases that keep all tiles' requests in flight together:
+            //   A  per lane (= one query per tile): hit mask, count, best score          (registers)
+            //   B  one list-space reservation per tile                                   (1 round trip)
+            //   C  store the hits (fire and forget)
+            //   D  offer the best hit to the running top-k, only if it beats the threshold the lane
+            //      already holds (hits inside the 2*eps margin cannot raise it)          (<= 3 round trips)
             const bool feeds = !(esi == 0 && elb < p.seed_blocks);
             const float* scp = p.seg[esi].scale + (size_t)elb * 32;
+            uint32_t hitmask[NT], idx[NT];
+            float best[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int q = 32 * t + c;
-                uint32_t hitmask = 0;
-                float best = -__builtin_inff();
+                hitmask[t] = 0;
+                best[t] = -__builtin_inff();
                 if (q < p.B) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -540,27 +595,40 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
                             // a zero / non-finite score may belong to a padding or invalid row (scale 0)
                             const bool suspect = (s == 0.0f) || !isfinite(s);
                             if (!suspect || scp[(i & 3) + 8 * (i >> 2) + 4 * h] != 0.0f) {
-                                hitmask |= 1u << i;
-                                if (isfinite(s)) best = fmaxf(best, s);
+                                hitmask[t] |= 1u << i;
+                                if (isfinite(s)) best[t] = fmaxf(best[t], s);
                             }
                         }
                     }
                 }
-                if (hitmask) {
-                    const uint32_t n = __builtin_popcount(hitmask);
-                    uint32_t idx = atomicAdd(&p.cand_cnt[q], n);
+            }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (hitmask & (1u << i)) {
-                            if (idx < p.cand_cap) {
-                                const uint32_t row = elb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                                p.cand[(size_t)q * p.cand_cap + idx] = ((uint64_t)(uint32_t)esi << 32) | row;
-                                p.cand_s[(size_t)q * p.cand_cap + idx] = acc[t][i];
-                            }
-                            ++idx;
+            for (int t = 0; t < NT; ++t)
+                idx[t] = hitmask[t] ? atomicAdd(&p.cand_cnt[(32 * t + c) * kHot], (uint32_t)__builtin_popcount(hitmask[t])) : 0u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int q = 32 * t + c;
+                uint32_t at = idx[t];
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (hitmask[t] & (1u << i)) {
+                        if (at < p.cand_cap) {
+                            const uint32_t row = elb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            p.cand[(size_t)q * p.cand_cap + at] = ((uint64_t)(uint32_t)esi << 32) | row;
+                            p.cand_s[(size_t)q * p.cand_cap + at] = acc[t][i];
                         }
-                    if (feeds && best > -__builtin_inff()) offer_slot(p, q, best);
+                        ++at;
+                    }
+            }
+            if (feeds) {
+                bool want[NT];
+                bool anyw = false;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    want[t] = hitmask[t] && best[t] > key_f32(tauk[t]);  // tau only grows: below it, no effect
+                    anyw |= want[t];
                 }
+                if (anyw) offer_slots<NT>(p, c, want, best);
             }
         }
 #pragma unroll
@@ -622,7 +690,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const ScanParams* __restri
     extern __shared__ float sqr[];  // [Dp] raw query
     const int q = blockIdx.y;
     const int Dp = p.D4 * 4;
-    const uint32_t cnt = min(p.cand_cnt[q], p.cand_cap);
+    const uint32_t cnt = min(p.cand_cnt[q * kHot], p.cand_cap);
     if (blockIdx.x * 256u >= cnt) return;
     for (int i = threadIdx.x; i < Dp; i += 256) sqr[i] = p.qraw[(size_t)q * Dp + i];
     __syncthreads();
@@ -630,7 +698,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const ScanParams* __restri
     if (j >= cnt) return;
     // rows emitted while tau was still low: the final threshold already excludes most of them
     // (same rule as the scan: a row with s < tau - 2*eps cannot reach the final k-th best)
-    const float thr_final = key_f32(p.tau[q]) - p.margin[q];
+    const float thr_final = key_f32(p.tau[q * kHot]) - p.margin[q];
     if (p.cand_s[(size_t)q * p.cand_cap + j] < thr_final) {
         p.cand_score[(size_t)q * p.cand_cap + j] = __builtin_nan("");
         return;
@@ -678,7 +746,7 @@ __global__ __launch_bounds__(256) void rescore_coop_kernel(const ScanParams* __r
     __shared__ uint32_t nsurv;
     const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D4 = p.D4;
-    const uint32_t cnt = min(p.cand_cnt[q], p.cand_cap);
+    const uint32_t cnt = min(p.cand_cnt[q * kHot], p.cand_cap);
     const uint32_t base = blockIdx.x * 1024u;
     if (base >= cnt) return;
     float4* sq = lds4;
@@ -686,7 +754,7 @@ __global__ __launch_bounds__(256) void rescore_coop_kernel(const ScanParams* __r
     for (int i = tid; i < D4; i += 256) sq[i] = ((const float4*)(p.qraw + (size_t)q * D4 * 4))[i];
     if (tid == 0) nsurv = 0;
     __syncthreads();
-    const float thr_final = key_f32(p.tau[q]) - p.margin[q];
+    const float thr_final = key_f32(p.tau[q * kHot]) - p.margin[q];
     for (uint32_t j = base + tid; j < min(cnt, base + 1024u); j += 256) {
         if (p.cand_s[(size_t)q * p.cand_cap + j] < thr_final)
             p.cand_score[(size_t)q * p.cand_cap + j] = __builtin_nan("");
@@ -762,10 +830,13 @@ __global__ __launch_bounds__(256) void select_kernel(const ScanParams* __restric
     __shared__ uint32_t r_i[4];
     __shared__ uint32_t n_valid;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t cnt = min(p.cand_cnt[q], p.cand_cap);
+    const uint32_t cnt = min(p.cand_cnt[q * kHot], p.cand_cap);
     const uint64_t* cand = p.cand + (size_t)q * p.cand_cap;
     double* sc = p.cand_score + (size_t)q * p.cand_cap;
-    if (tid == 0) n_valid = 0;
+    if (tid == 0) {
+        n_valid = 0;
+        p.cand_cnt_out[q] = p.cand_cnt[q * kHot];  // uncapped: the host sizes a rerun from it
+    }
     __syncthreads();
     for (uint32_t i = tid; i < cnt; i += 256) {
         const double s = sc[i];

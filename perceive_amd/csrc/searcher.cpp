@@ -83,7 +83,7 @@ struct pcv_searcher {
     DevBuf<uint16_t> d_qbf16;
     DevBuf<double> d_qnorm2, d_cand_score;
     DevBuf<float> d_cand_s;
-    DevBuf<uint32_t> d_tau, d_slots, d_cnt, d_seed_part;
+    DevBuf<uint32_t> d_tau, d_slots, d_cnt, d_cnt_out, d_seed_part;
     DevBuf<uint64_t> d_cand;
     DevBuf<pcv_hit_dev> d_hits;
     DevBuf<ScanParams> d_params;
@@ -245,9 +245,10 @@ void ensure_workspace(pcv_searcher* s) {
     s->d_qbf16.ensure(Q * s->Dp);
     s->d_margin.ensure(Q);
     s->d_qnorm2.ensure(Q);
-    s->d_tau.ensure(Q);
+    s->d_tau.ensure(Q * kHot);
     s->d_slots.ensure(Q * kMaxK);
-    s->d_cnt.ensure(Q);
+    s->d_cnt.ensure(Q * kHot);
+    s->d_cnt_out.ensure(Q);
     s->d_cand.ensure(Q * s->cand_cap);
     s->d_cand_score.ensure(Q * s->cand_cap);
     s->d_cand_s.ensure(Q * s->cand_cap);
@@ -292,6 +293,7 @@ void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* s
         p.tau = s->d_tau.p;
         p.slots = s->d_slots.p;
         p.cand_cnt = s->d_cnt.p;
+        p.cand_cnt_out = s->d_cnt_out.p;
         p.cand = s->d_cand.p;
         p.cand_score = s->d_cand_score.p;
         p.cand_s = s->d_cand_s.p;
@@ -322,7 +324,7 @@ void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* s
         launch_select(st, p, dp, s->d_hits.p);
         PCV_HIP(hipEventRecord(s->ev[3], st));
         uint32_t* cnt = s->pin->cnt;
-        PCV_HIP(hipMemcpyAsync(cnt, s->d_cnt.p, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PCV_HIP(hipMemcpyAsync(cnt, s->d_cnt_out.p, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PCV_HIP(hipMemcpyAsync(s->pin->hits, s->d_hits.p, (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
         PCV_HIP(hipStreamSynchronize(st));
         PCV_HIP(hipGetLastError());
@@ -492,6 +494,7 @@ pcv_status pcv_searcher_destroy(pcv_searcher* s) {
         s->d_tau.release();
         s->d_slots.release();
         s->d_cnt.release();
+        s->d_cnt_out.release();
         s->d_cand.release();
         s->d_hits.release();
         s->d_params.release();
