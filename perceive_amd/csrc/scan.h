@@ -18,8 +18,8 @@ namespace pcv {
 constexpr int kBlockRows = 32;      // rows per corpus block
 constexpr int kMaxSeg = 8;          // corpus segments one scan launch can walk
 constexpr int kMaxK = 128;          // largest num_results the running top-k slots hold
-constexpr int kSeedPartRows = 1024;  // rows one seed workgroup ranks
-constexpr int kSeedParts = 16;       // seed workgroups per query -> up to 16384 seed rows
+constexpr int kSeedPartRows = 512;   // rows one seed workgroup ranks
+constexpr int kSeedParts = 32;       // seed workgroups per query group -> up to 16384 seed rows
 constexpr int kMaxWaveQueries = 4;  // wave-reduction kernel handles 1..4 queries per pass
 constexpr int kHot = 256;            // uint32 words between per-query hot words (tau, cand_cnt): 1 KB apart,
                                      // so the device-wide atomics on them do not queue on one HBM channel

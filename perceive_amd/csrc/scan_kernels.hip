@@ -22,19 +22,51 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Every pointer the kernels follow comes out of a struct in memory, so the compiler only knows it
+// as a generic ("flat") address.  flat_load/flat_atomic count on BOTH vmcnt and lgkmcnt and return
+// out of order: every LDS wait then has to drain the corpus prefetch as well.  All global traffic
+// therefore goes through these address-space(1) accessors (global_load / global_store / global_atomic).
+#define PCV_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ T gld(const T* p) {
+    return *(const PCV_GLOBAL T*)p;
+}
+template <class T>
+__device__ __forceinline__ void gst(T* p, T v) {
+    *(PCV_GLOBAL T*)p = v;
+}
+__device__ __forceinline__ float4 gld4(const float4* p) {
+    const f32x4 v = *(const PCV_GLOBAL f32x4*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 gld4(const float* p) { return gld4((const float4*)p); }
+__device__ __forceinline__ uint32_t g_atomic_add(uint32_t* p, uint32_t v) {
+    return __hip_atomic_fetch_add((PCV_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t g_atomic_max(uint32_t* p, uint32_t v) {
+    return __hip_atomic_fetch_max((PCV_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// returns the value found (== expected on success)
+__device__ __forceinline__ uint32_t g_atomic_cas(uint32_t* p, uint32_t expected, uint32_t desired) {
+    __hip_atomic_compare_exchange_strong((PCV_GLOBAL uint32_t*)p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    return expected;
+}
+
 // corpus rows are read exactly once per scan: optionally mark the loads non-temporal
 template <bool NTL>
 __device__ __forceinline__ float4 ld_row(const float4* p) {
     if constexpr (NTL) {
-        const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+        const f32x4 v = __builtin_nontemporal_load((const PCV_GLOBAL f32x4*)p);
         return make_float4(v.x, v.y, v.z, v.w);
     } else {
-        return *p;
+        return gld4(p);
     }
 }
 
 __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((const PCV_GLOBAL uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ int find_seg(const ScanParams& p, uint32_t gb) {
@@ -62,10 +94,10 @@ __device__ __forceinline__ void offer_slot(const ScanParams& p, int q, float s) 
             }
         }
         if (key <= mn) return;
-        if (atomicCAS(&sl[mi], mn, key) == mn) {
+        if (g_atomic_cas(&sl[mi], mn, key) == mn) {
             uint32_t nm = 0xffffffffu;
             for (int i = 0; i < p.k; ++i) nm = min(nm, ld_relaxed(&sl[i]));
-            atomicMax(&p.tau[q * kHot], nm);
+            g_atomic_max(&p.tau[q * kHot], nm);
             return;
         }
     }
@@ -107,14 +139,14 @@ __device__ __forceinline__ void offer_slots(const ScanParams& p, int c, const bo
         uint32_t old[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            old[t] = live[t] ? atomicCAS(&p.slots[(size_t)(32 * t + c) * kMaxK + mi[t]], mn[t], key[t]) : 0u;
+            old[t] = live[t] ? g_atomic_cas(&p.slots[(size_t)(32 * t + c) * kMaxK + mi[t]], mn[t], key[t]) : 0u;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (live[t] && old[t] == mn[t]) {
                 const uint32_t* sl = p.slots + (size_t)(32 * t + c) * kMaxK;
                 uint32_t nm = 0xffffffffu;
                 for (int i = 0; i < p.k; ++i) nm = min(nm, ld_relaxed(&sl[i]));
-                atomicMax(&p.tau[(32 * t + c) * kHot], nm);
+                g_atomic_max(&p.tau[(32 * t + c) * kHot], nm);
                 live[t] = false;
             }
     }
@@ -124,10 +156,10 @@ __device__ __forceinline__ void offer_slots(const ScanParams& p, int c, const bo
 // already ranked by the seed kernel, try to raise the running k-th best.
 __device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint32_t row, float s,
                                       bool feeds_slots) {
-    uint32_t idx = atomicAdd(&p.cand_cnt[q * kHot], 1u);
+    uint32_t idx = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
     if (idx < p.cand_cap) {
-        p.cand[(size_t)q * p.cand_cap + idx] = ((uint64_t)(uint32_t)seg << 32) | row;
-        p.cand_s[(size_t)q * p.cand_cap + idx] = s;
+        gst(&p.cand[(size_t)q * p.cand_cap + idx], ((uint64_t)(uint32_t)seg << 32) | row);
+        gst(&p.cand_s[(size_t)q * p.cand_cap + idx], s);
     }
     if (feeds_slots && isfinite(s)) offer_slot(p, q, s);
 }
@@ -340,55 +372,91 @@ __device__ __forceinline__ void topk_keys_lds(uint32_t* keys, uint32_t n, int k,
     }
 }
 
-// Seed, step 1: workgroup (part, query) ranks rows [part*1024, +1024) of segment 0 with an f32 FMA
-// chain and keeps its k best keys.  Gives the streaming kernels a useful threshold from the first
-// block on: with W waves in flight the first round screens 32*W rows against the seed threshold.
+// Seed, step 1: workgroup (part, query group) ranks rows [part*1024, +1024) of segment 0 against QG
+// queries with f32 FMA chains and keeps the k best keys per query.  Gives the streaming kernels a
+// useful threshold from the first block on: with W waves in flight the first round screens 32*W rows
+// against the seed threshold.  QG queries share every row load (one query per workgroup made the
+// 64-query seed L2-bandwidth-bound: 1.6 GB of row re-reads).
+template <int QG>
 __global__ __launch_bounds__(256) void seed_partial_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
     extern __shared__ float smem[];
     const int Dp = p.D4 * 4;
-    float* sq = smem;                         // [Dp]
-    uint32_t* keys = (uint32_t*)(smem + Dp);  // [kSeedPartRows]
-    __shared__ unsigned long long red4[4];
-    const int part = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;
+    float* sq = smem;                              // [QG][Dp]
+    uint32_t* keys = (uint32_t*)(smem + QG * Dp);  // [QG][kSeedPartRows]
+    const int part = blockIdx.x, q0 = blockIdx.y * QG, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SegDesc& sg = p.seg[0];
     const uint32_t nseed = min(sg.nrows, p.seed_blocks * 32u);
-    for (int i = tid; i < Dp; i += 256) sq[i] = p.qf32[(size_t)q * Dp + i];
+    for (int i = tid; i < QG * Dp; i += 256) {
+        const int q = q0 + i / Dp;
+        sq[i] = q < p.B ? gld(&p.qf32[(size_t)q * Dp + (i % Dp)]) : 0.0f;
+    }
     __syncthreads();
-    // thread t owns rows base + t + 256*u, u = 0..3: four independent FMA chains per thread
+    // thread t owns rows base + t + 256*u, u = 0..RPT-1
     const uint32_t row0 = part * kSeedPartRows + tid;
-    const float4* base[4];
-    float acc[4];
+    constexpr int RPT = kSeedPartRows / 256;
+    const float4* base[RPT];
+    float acc[RPT][QG];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < RPT; ++u) {
         const uint32_t row = min(row0 + 256u * u, nseed ? nseed - 1 : 0u);
         base[u] = sg.blk + (size_t)(row >> 5) * p.D4 * 32 + (row & 31);
-        acc[u] = 0.0f;
-    }
-    for (int f4 = 0; f4 < p.D4; ++f4) {
-        const float4 qv = *(const float4*)&sq[f4 * 4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 v = base[u][(size_t)f4 * 32];
-            acc[u] = fmaf(qv.x, v.x, acc[u]);
-            acc[u] = fmaf(qv.y, v.y, acc[u]);
-            acc[u] = fmaf(qv.z, v.z, acc[u]);
-            acc[u] = fmaf(qv.w, v.w, acc[u]);
+        for (int g = 0; g < QG; ++g) acc[u][g] = 0.0f;
+    }
+#pragma unroll 4
+    for (int f4 = 0; f4 < p.D4; ++f4) {  // D4 is a multiple of 16
+        float4 v[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) v[u] = gld4(base[u] + (size_t)f4 * 32);
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            const float4 qv = *(const float4*)&sq[g * Dp + f4 * 4];
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                acc[u][g] = fmaf(qv.x, v[u].x, acc[u][g]);
+                acc[u][g] = fmaf(qv.y, v[u].y, acc[u][g]);
+                acc[u][g] = fmaf(qv.z, v[u].z, acc[u][g]);
+                acc[u][g] = fmaf(qv.w, v[u].w, acc[u][g]);
+            }
         }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < RPT; ++u) {
         const uint32_t row = row0 + 256u * u;
-        uint32_t key = 0;  // 0 = absent (below every real key)
-        if (row < nseed) {
-            const float sc = sg.scale[row];
-            const float s = acc[u] * sc;
-            if (sc != 0.0f && isfinite(s)) key = f32_key(s);
+        const float sc = row < nseed ? gld(&sg.scale[row]) : 0.0f;
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            const float s = acc[u][g] * sc;
+            keys[g * kSeedPartRows + tid + 256 * u] = (sc != 0.0f && isfinite(s)) ? f32_key(s) : 0u;  // 0 = absent
         }
-        keys[tid + 256 * u] = key;
     }
     __syncthreads();
-    topk_keys_lds(keys, kSeedPartRows, p.k, red4, p.seed_part + ((size_t)q * kSeedParts + part) * kMaxK);
+    // selection: each wave ranks whole queries on its own (k rounds of a wave-wide max, no barriers)
+    for (int g = wave; g < QG; g += 4) {
+        const int q = q0 + g;
+        if (q >= p.B) continue;
+        uint32_t* kq = keys + g * kSeedPartRows;
+        uint32_t* out = p.seed_part + ((size_t)q * kSeedParts + part) * kMaxK;
+        for (int j = 0; j < p.k; ++j) {
+            unsigned long long best = 0;
+            for (uint32_t i = lane; i < (uint32_t)kSeedPartRows; i += 64) {
+                const unsigned long long cnd = ((unsigned long long)kq[i] << 32) | (0xffffffffu - i);
+                best = cnd > best ? cnd : best;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(best, off);
+                best = o > best ? o : best;
+            }
+            const uint32_t wkey = (uint32_t)(best >> 32);
+            if (lane == 0) {
+                gst(&out[j], wkey);
+                if (wkey) kq[0xffffffffu - (uint32_t)best] = 0;
+            }
+            __builtin_amdgcn_wave_barrier();  // LDS is in order within a wave: the next round sees the removal
+        }
+    }
 }
 
 // Seed, step 2: merge the per-part lists into the query's slots and threshold.
@@ -400,11 +468,11 @@ __global__ __launch_bounds__(256) void seed_merge_kernel(const ScanParams* __res
     const int q = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = (uint32_t)nparts * p.k;
     for (uint32_t i = tid; i < n; i += 256)
-        keys[i] = p.seed_part[((size_t)q * kSeedParts + i / p.k) * kMaxK + i % p.k];
+        keys[i] = gld(&p.seed_part[((size_t)q * kSeedParts + i / p.k) * kMaxK + i % p.k]);
     __syncthreads();
     topk_keys_lds(keys, n, p.k, red4, outk);
-    for (int j = tid; j < p.k; j += 256) p.slots[(size_t)q * kMaxK + j] = outk[j] ? outk[j] : kKeyNegInf;
-    if (tid == 0) p.tau[q * kHot] = outk[p.k - 1] ? outk[p.k - 1] : kKeyNegInf;  // k-th best seed row, -inf if fewer
+    for (int j = tid; j < p.k; j += 256) gst(&p.slots[(size_t)q * kMaxK + j], outk[j] ? outk[j] : kKeyNegInf);
+    if (tid == 0) gst(&p.tau[q * kHot], outk[p.k - 1] ? outk[p.k - 1] : kKeyNegInf);  // k-th best seed row, -inf if fewer
 }
 
 // Wave-reduction scan for 1..4 queries (BASELINE config "10M x 384, batch=1"): pure HBM streaming.
@@ -415,13 +483,13 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
     const ScanParams& p = *pp;
     extern __shared__ float sq[];  // [NB][Dp]
     const int Dp = p.D4 * 4;
-    for (int i = threadIdx.x; i < NB * Dp; i += 256) sq[i] = p.qf32[i];
+    for (int i = threadIdx.x; i < NB * Dp; i += 256) sq[i] = gld(&p.qf32[i]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     float mrg[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) mrg[b] = p.margin[b];
+    for (int b = 0; b < NB; ++b) mrg[b] = gld(&p.margin[b]);
     const uint32_t total_waves = gridDim.x * 4;
     const int half = p.D4 >> 1;
     for (uint32_t gb = blockIdx.x * 4 + wave; gb < p.total_blocks; gb += total_waves) {
@@ -432,7 +500,7 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
         const float* qb = sq + h * 4;
         // issued with the row loads so that their latency overlaps the streaming
         const uint32_t row = lb * 32 + r;
-        const float sc = sg.scale[row];
+        const float sc = gld(&sg.scale[row]);
         uint32_t tk[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) tk[b] = ld_relaxed(&p.tau[b * kHot]);
@@ -502,14 +570,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
     const int NCH = D4 >> 4;  // chunks of 64 features
     for (int i = threadIdx.x; i < NT * 32 * P8; i += WPB * 64) {
         const int q = i / P8, pc = i - q * P8;
-        lq[q * P8 + ((pc & ~15) | ((pc ^ q) & 15))] = ((const uint4*)p.qbf16)[i];
+        lq[q * P8 + ((pc & ~15) | ((pc ^ q) & 15))] = __builtin_bit_cast(uint4, gld4((const float4*)p.qbf16 + i));
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     float mrg[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) mrg[t] = (32 * t + c < p.B) ? p.margin[32 * t + c] : 0.0f;
+    for (int t = 0; t < NT; ++t) mrg[t] = (32 * t + c < p.B) ? gld(&p.margin[32 * t + c]) : 0.0f;
 
     const uint32_t total_waves = gridDim.x * WPB;
     if (blockIdx.x * WPB + wave >= p.total_blocks) return;
@@ -535,7 +603,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
     // scale of this lane's row (1/|x|, 1 or 0): multiplied into the A operand before the bf16
     // rounding, so the accumulators are final screening scores.  sc_next belongs to the block the
     // producer has entered but the consumer has not.
-    float sc_cur = p.seg[cons.si].scale[(size_t)cons.lb * 32 + c], sc_next = 0.0f;
+    float sc_cur = gld(&p.seg[cons.si].scale[(size_t)cons.lb * 32 + c]), sc_next = 0.0f;
 
     float4 buf[NBUF][8];
     // lane's pieces of k-step ks of a chunk: f4 = chunk*16 + ks*4 + 2h + e  (2h folded into base)
@@ -546,7 +614,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
             b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 16 + (i >> 1) * 4 + (i & 1)) * 32);
         if (++prod.ch == NCH) {
             enter_block(prod, prod.gb + total_waves);
-            if (prod.gb < p.total_blocks) sc_next = p.seg[prod.si].scale[(size_t)prod.lb * 32 + c];
+            if (prod.gb < p.total_blocks) sc_next = gld(&p.seg[prod.si].scale[(size_t)prod.lb * 32 + c]);
         }
     };
 
@@ -594,7 +662,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
                         if (!(s < thr[t])) {
                             // a zero / non-finite score may belong to a padding or invalid row (scale 0)
                             const bool suspect = (s == 0.0f) || !isfinite(s);
-                            if (!suspect || scp[(i & 3) + 8 * (i >> 2) + 4 * h] != 0.0f) {
+                            if (!suspect || gld(&scp[(i & 3) + 8 * (i >> 2) + 4 * h]) != 0.0f) {
                                 hitmask[t] |= 1u << i;
                                 if (isfinite(s)) best[t] = fmaxf(best[t], s);
                             }
@@ -604,7 +672,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                idx[t] = hitmask[t] ? atomicAdd(&p.cand_cnt[(32 * t + c) * kHot], (uint32_t)__builtin_popcount(hitmask[t])) : 0u;
+                idx[t] = hitmask[t] ? g_atomic_add(&p.cand_cnt[(32 * t + c) * kHot], (uint32_t)__builtin_popcount(hitmask[t])) : 0u;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int q = 32 * t + c;
@@ -614,8 +682,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
                     if (hitmask[t] & (1u << i)) {
                         if (at < p.cand_cap) {
                             const uint32_t row = elb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                            p.cand[(size_t)q * p.cand_cap + at] = ((uint64_t)(uint32_t)esi << 32) | row;
-                            p.cand_s[(size_t)q * p.cand_cap + at] = acc[t][i];
+                            gst(&p.cand[(size_t)q * p.cand_cap + at], ((uint64_t)(uint32_t)esi << 32) | row);
+                            gst(&p.cand_s[(size_t)q * p.cand_cap + at], acc[t][i]);
                         }
                         ++at;
                     }
@@ -1049,8 +1117,13 @@ void launch_prep_queries(hipStream_t st, const float* d_queries, int B, int D, i
 void launch_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
     if (p.seed_blocks == 0 || p.nseg == 0) return;
     const int nparts = (int)((p.seed_blocks * 32u + kSeedPartRows - 1) / kSeedPartRows);
-    const size_t lds = (size_t)p.D4 * 4 * sizeof(float) + kSeedPartRows * sizeof(uint32_t);
-    seed_partial_kernel<<<dim3(nparts, p.B), 256, lds, st>>>(dp);
+    if (p.B <= 2) {
+        const size_t lds = (size_t)p.D4 * 4 * sizeof(float) + kSeedPartRows * sizeof(uint32_t);
+        seed_partial_kernel<1><<<dim3(nparts, p.B), 256, lds, st>>>(dp);
+    } else {
+        const size_t lds = 8 * ((size_t)p.D4 * 4 * sizeof(float) + kSeedPartRows * sizeof(uint32_t));
+        seed_partial_kernel<8><<<dim3(nparts, (p.B + 7) / 8), 256, lds, st>>>(dp);
+    }
     seed_merge_kernel<<<p.B, 256, 0, st>>>(dp, nparts);
 }
 

@@ -300,8 +300,9 @@ void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* s
         p.seed_part = s->d_seed_part.p;
         p.cand_cap = s->cand_cap;
         p.flags = s->scan_flags;
+        const uint32_t seed_parts = ((s->scan_flags >> 16) & 0xff) ? ((s->scan_flags >> 16) & 0xff) : kSeedParts;  // tuning
         p.seed_blocks =
-            nseg > 0 ? std::min<uint32_t>(kSeedParts * kSeedPartRows / kBlockRows, segs[0].g->nblocks) : 0;
+            nseg > 0 ? std::min<uint32_t>(std::min<uint32_t>(seed_parts, kSeedParts) * kSeedPartRows / kBlockRows, segs[0].g->nblocks) : 0;
 
         // |s - c| bound of the screening score, relative to |q||x| (DESIGN.md §screening error)
         const float eps_f32 = (float)(s->Dp + 16) * 1.2e-7f;
