@@ -404,22 +404,28 @@ __global__ __launch_bounds__(256) void seed_partial_kernel(const ScanParams* __r
 #pragma unroll
         for (int g = 0; g < QG; ++g) acc[u][g] = 0.0f;
     }
-#pragma unroll 4
-    for (int f4 = 0; f4 < p.D4; ++f4) {  // D4 is a multiple of 16
-        float4 v[RPT];
+    for (int f0 = 0; f0 < p.D4; f0 += 4) {  // D4 is a multiple of 16
+        // all 4*RPT row loads of this step are issued before any of them is used (left to itself the
+        // compiler sinks each load next to its FMAs and the loop runs at one L2 latency per piece)
+        float4 v[4][RPT];
 #pragma unroll
-        for (int u = 0; u < RPT; ++u) v[u] = gld4(base[u] + (size_t)f4 * 32);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int g = 0; g < QG; ++g) {
-            const float4 qv = *(const float4*)&sq[g * Dp + f4 * 4];
+            for (int u = 0; u < RPT; ++u) v[j][u] = gld4(base[u] + (size_t)(f0 + j) * 32);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < RPT; ++u) {
-                acc[u][g] = fmaf(qv.x, v[u].x, acc[u][g]);
-                acc[u][g] = fmaf(qv.y, v[u].y, acc[u][g]);
-                acc[u][g] = fmaf(qv.z, v[u].z, acc[u][g]);
-                acc[u][g] = fmaf(qv.w, v[u].w, acc[u][g]);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                const float4 qv = *(const float4*)&sq[g * Dp + (f0 + j) * 4];
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) {
+                    acc[u][g] = fmaf(qv.x, v[j][u].x, acc[u][g]);
+                    acc[u][g] = fmaf(qv.y, v[j][u].y, acc[u][g]);
+                    acc[u][g] = fmaf(qv.z, v[j][u].z, acc[u][g]);
+                    acc[u][g] = fmaf(qv.w, v[j][u].w, acc[u][g]);
+                }
             }
-        }
     }
 #pragma unroll
     for (int u = 0; u < RPT; ++u) {

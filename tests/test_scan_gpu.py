@@ -404,3 +404,37 @@ def test_create_destroy_does_not_leak(ctx):
     free1 = C.c_size_t()
     hip.hipMemGetInfo(C.byref(free1), C.byref(total))
     assert free0.value - free1.value < 64 << 20, (free0.value, free1.value)
+
+
+@pytest.mark.parametrize("D", [1, 3, 50, 65, 200, 1000])
+def test_awkward_dimensions(ctx, oracle, D):
+    # any dim works: features are zero-padded to a multiple of 64 in HBM
+    rng = np.random.default_rng(D)
+    m = rng.standard_normal((777, D)).astype(np.float32)
+    q = rng.standard_normal((7, D)).astype(np.float32)
+    for kernel in ("wave", "mfma"):
+        s = build(ctx, m, kernel=kernel)
+        ids, sc, cnt = s.search_vectors(None, 9, q)
+        opos, osc, ocnt = oracle.topk(q, m, 9)
+        if D == 1:  # cosine of scalars is +-1: everything ties, order = position among equal signs
+            np.testing.assert_allclose(sc, osc.astype(np.float32), atol=1e-7)
+        np.testing.assert_array_equal(ids, opos)
+        rows, _ = s.get_rows(np.arange(5))
+        np.testing.assert_array_equal(rows, m[:5])
+        s.close()
+
+
+def test_large_dim_falls_back_to_wave_kernel(ctx, oracle):
+    # 4096-d: the bf16 query tile no longer fits the LDS -> auto picks the wave kernel, forcing mfma fails loudly
+    rng = np.random.default_rng(5)
+    m = rng.standard_normal((300, 4096)).astype(np.float32)
+    q = rng.standard_normal((6, 4096)).astype(np.float32)
+    s = build(ctx, m)
+    ids, sc, _ = s.search_vectors(None, 5, q)
+    np.testing.assert_array_equal(ids, oracle.topk(q, m, 5)[0])
+    assert s.last_stats()["kernel_used"] == 1
+    s.set_kernel("mfma")
+    with pytest.raises(pa.PcvError) as e:
+        s.search_vectors(None, 5, q)
+    assert e.value.status == 3
+    s.close()
