@@ -54,12 +54,11 @@ def cpu_baseline(args):
     rows = orc.synth_rows(0x5EED, 0, n, args.dim, args.normalized)
     q = orc.synth_rows(0x5EED + 1, 0, args.batch, args.dim)
     orc.baseline_scan(q, rows[: max(10_000, n // 10)], args.k, threads)  # warm the thread pool / caches
-    first, _, _ = orc.baseline_scan(q, rows, args.k, threads)
-    reps = int(min(400, max(1, round(12.0 / max(first, 1e-6)))))  # ~12 s of CPU work in all
-    total = first
-    for _ in range(reps - 1):
+    total, reps = 0.0, 0
+    while total < 12.0 and reps < 2000:  # ~12 s of CPU work in all
         secs, _, _ = orc.baseline_scan(q, rows, args.k, threads)
         total += secs
+        reps += 1
     return {
         "value": n * reps / total,
         "unit": "vectors/s",
