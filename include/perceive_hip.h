@@ -209,9 +209,11 @@ typedef struct pcv_model_desc {
 } pcv_model_desc;
 enum { PCV_POOL_MEAN = 0, PCV_POOL_CLS = 1, PCV_POOL_MAX = 2, PCV_POOL_MEAN_SQRT_LEN = 3 };
 enum { PCV_ACT_IDENTITY = 0, PCV_ACT_TANH = 1 };
-/* F32: every GEMM on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), the reference's dtype.
- * BF16: GEMM operands rounded to bf16, f32 accumulate (faster, ~1e-2 relative on activations). */
-enum { PCV_COMPUTE_F32 = 0, PCV_COMPUTE_BF16 = 1 };
+/* F32   : every GEMM on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), the reference's dtype.
+ * BF16X3: each f32 operand is split into three bf16 terms (hi + mid + lo = 24 significand bits) and
+ *         a product is six bf16 MFMAs accumulated in f32 (the lo*mid, mid*lo, lo*lo terms, < 2^-24
+ *         relative, are dropped): f32-level accuracy at 6/16 of the f32-MFMA cost. */
+enum { PCV_COMPUTE_F32 = 0, PCV_COMPUTE_BF16X3 = 1 };
 
 /* Fill `d` with the all-MiniLM-L6-v2 shape. */
 void pcv_model_desc_minilm_l6(pcv_model_desc* d);

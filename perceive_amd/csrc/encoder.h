@@ -15,6 +15,14 @@ enum GemmEpilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
 void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float* bias, const float* resid, float* C,
                      int M, int N, int K, int epilogue);
 
+// Same contraction with every f32 operand split into three bf16 terms (x = hi + mid + lo): six
+// v_mfma_f32_32x32x16_bf16 per product, f32 accumulate.  Wp = the three pre-split weight planes,
+// each [N][K] bf16; A is split on the fly while it is staged into LDS.
+void launch_gemm_bf16x3(hipStream_t st, const float* A, const uint16_t* Wh, const uint16_t* Wm, const uint16_t* Wl,
+                        const float* bias, const float* resid, float* C, int M, int N, int K, int epilogue);
+// f32 [n] -> three bf16 planes
+void launch_split_planes(hipStream_t st, const float* src, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo);
+
 // tokens -> embeddings + LayerNorm; also converts the int64 mask to the additive float mask
 // (1-m)*-10000 used by the attention kernel and to a float 0/1 mask for pooling.
 void launch_embed_ln(hipStream_t st, const int64_t* ids, const int64_t* mask, int B, int L, int H, int vocab,

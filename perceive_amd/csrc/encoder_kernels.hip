@@ -130,6 +130,149 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-precision GEMM: C = A W^T with x = hi + mid + lo (three bf16 terms, 24 significand bits).
+//   a*b ~ ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh        (dropped: am*bl, al*bm, al*bl < 2^-24)
+// Six v_mfma_f32_32x32x16_bf16 per 16-deep step instead of eight v_mfma_f32_32x32x2_f32 at 1/16 the
+// rate: 6/16 of the matrix-core time of the exact-f32 kernel at f32-level accuracy.
+// Same 128x128x32 tiling as gemm_f32_kernel.  LDS holds three bf16 planes per operand, rows padded
+// to 40 elements (80 B: the 16-lane ds_read_b128 groups cover all 64 banks).  W arrives pre-split
+// (model load), A is split by the staging threads between its global load and the LDS store.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDB = 40;
+
+__device__ __forceinline__ void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+    hi = __builtin_convertvector(x, bf16x4);
+    const f32x4 r1 = x - __builtin_convertvector(hi, f32x4);
+    mid = __builtin_convertvector(r1, bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
+    lo = __builtin_convertvector(r2, bf16x4);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restrict__ A, const uint16_t* __restrict__ Wh,
+                                                          const uint16_t* __restrict__ Wm,
+                                                          const uint16_t* __restrict__ Wl,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ resid, float* __restrict__ C,
+                                                          int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * LDB];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[3][BN * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // A staging: float4 (row = (t>>3) + 32u, k = 4*(t&7)), u = 0..3
+    const int arow = tid >> 3, ac4 = tid & 7;
+    const float* ag[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ag[u] = A + (size_t)min(m0 + arow + 32 * u, M - 1) * K + ac4 * 4;
+    // W staging: 8 bf16 (row = (t>>2) + 64u, k = 8*(t&3)) of each plane, u = 0..1
+    const int wrow = tid >> 2, wc8 = tid & 3;
+    const size_t woff0 = (size_t)(n0 + wrow) * K + wc8 * 8;
+    const size_t woff1 = woff0 + (size_t)64 * K;
+
+    f32x4 ra[4];
+    f32x4 rw[3][2];  // 8 bf16 = 16 bytes, moved as f32x4
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ra[u] = *(const f32x4*)(ag[u]);
+    rw[0][0] = *(const f32x4*)(Wh + woff0); rw[0][1] = *(const f32x4*)(Wh + woff1);
+    rw[1][0] = *(const f32x4*)(Wm + woff0); rw[1][1] = *(const f32x4*)(Wm + woff1);
+    rw[2][0] = *(const f32x4*)(Wl + woff0); rw[2][1] = *(const f32x4*)(Wl + woff1);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bf16x4 ph, pm, pl;
+            split3(ra[u], ph, pm, pl);
+            const int o = (arow + 32 * u) * LDB + ac4 * 4;
+            *(bf16x4*)&As[0][o] = ph;
+            *(bf16x4*)&As[1][o] = pm;
+            *(bf16x4*)&As[2][o] = pl;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            *(f32x4*)&Ws[pl][wrow * LDB + wc8 * 8] = rw[pl][0];
+            *(f32x4*)&Ws[pl][(wrow + 64) * LDB + wc8 * 8] = rw[pl][1];
+        }
+        __syncthreads();
+        {
+            const size_t koff = (size_t)min(kt + 1, nk - 1) * BK;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ra[u] = *(const f32x4*)(ag[u] + koff);
+            rw[0][0] = *(const f32x4*)(Wh + woff0 + koff); rw[0][1] = *(const f32x4*)(Wh + woff1 + koff);
+            rw[1][0] = *(const f32x4*)(Wm + woff0 + koff); rw[1][1] = *(const f32x4*)(Wm + woff1 + koff);
+            rw[2][0] = *(const f32x4*)(Wl + woff0 + koff); rw[2][1] = *(const f32x4*)(Wl + woff1 + koff);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {  // two 16-deep steps per 32-wide K tile
+            bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    af[t][pl] = *(const bf16x8*)&As[pl][(wr * 64 + t * 32 + i) * LDB + s * 16 + 8 * h];
+                    bf[t][pl] = *(const bf16x8*)&Ws[pl][(wc * 64 + t * 32 + i) * LDB + s * 16 + 8 * h];
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    // smallest terms first
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wc * 64 + b * 32 + i;
+            const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + a * 32 + acc_row(r, h);
+                if (row < M) {
+                    float v = acc[a][b][r] + bv;
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
+                    C[(size_t)row * N + col] = v;
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t n,
+                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ mid,
+                                                           uint16_t* __restrict__ lo) {
+    const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= n) return;  // n is a multiple of 4 for every weight matrix
+    bf16x4 ph, pm, pl;
+    split3(*(const f32x4*)(src + p), ph, pm, pl);
+    *(bf16x4*)(hi + p) = ph;
+    *(bf16x4*)(mid + p) = pm;
+    *(bf16x4*)(lo + p) = pl;
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm helpers: one wave per token row, H/64 values per lane (H <= 1024)
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxPerLane = 16;
@@ -430,6 +573,26 @@ void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float
             break;
         default: gemm_f32_kernel<EPI_BIAS><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K); break;
     }
+}
+
+void launch_gemm_bf16x3(hipStream_t st, const float* A, const uint16_t* Wh, const uint16_t* Wm, const uint16_t* Wl,
+                        const float* bias, const float* resid, float* C, int M, int N, int K, int epilogue) {
+    if (M <= 0) return;
+    dim3 grid(N / BN, (M + BM - 1) / BM);
+    switch (epilogue) {
+        case EPI_BIAS_GELU:
+            gemm_bf16x3_kernel<EPI_BIAS_GELU><<<grid, 256, 0, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K);
+            break;
+        case EPI_BIAS_RESIDUAL:
+            gemm_bf16x3_kernel<EPI_BIAS_RESIDUAL><<<grid, 256, 0, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K);
+            break;
+        default: gemm_bf16x3_kernel<EPI_BIAS><<<grid, 256, 0, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;
+    }
+}
+
+void launch_split_planes(hipStream_t st, const float* src, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo) {
+    if (n <= 0) return;
+    split_planes_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(src, n, hi, mid, lo);
 }
 
 void launch_embed_ln(hipStream_t st, const int64_t* ids, const int64_t* mask, int B, int L, int H, int vocab,

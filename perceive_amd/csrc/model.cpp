@@ -20,10 +20,15 @@ struct Tensor {
     int64_t n = 0;
 };
 
+struct Planes {  // hi / mid / lo bf16 terms of an f32 weight matrix (PCV_COMPUTE_BF16X3)
+    uint16_t* p[3] = {nullptr, nullptr, nullptr};
+};
+
 struct Layer {
     Tensor qkv_w, qkv_b;  // fused [3H][H], [3H]: rows 0..H = query, H..2H = key, 2H..3H = value
     Tensor ao_w, ao_b, ln1_w, ln1_b;
     Tensor i_w, i_b, f_w, f_b, ln2_w, ln2_b;
+    Planes qkv_p, ao_p, i_p, f_p;
 };
 
 }  // namespace
@@ -36,6 +41,8 @@ struct pcv_model {
     // name -> (device pointer, element count): HF / rust-bert tensor names
     std::map<std::string, Tensor> table;
     std::vector<float*> owned;
+    std::vector<void*> owned_planes;
+    bool planes_dirty = true;  // weights changed since the bf16 planes were derived
     std::mutex mu;
     pcv_encode_stats stats{};
 
@@ -65,6 +72,34 @@ Tensor alloc_tensor(pcv_model* m, int64_t n) {
 
 void reg(pcv_model* m, const std::string& name, float* p, int64_t n) { m->table[name] = Tensor{p, n}; }
 
+void alloc_planes(pcv_model* m, Planes& pl, int64_t n) {
+    for (int i = 0; i < 3; ++i) {
+        PCV_HIP(hipMalloc((void**)&pl.p[i], (size_t)n * sizeof(uint16_t)));
+        m->owned_planes.push_back(pl.p[i]);
+    }
+}
+
+void refresh_planes(pcv_model* m) {
+    if (m->d.compute != PCV_COMPUTE_BF16X3 || !m->planes_dirty) return;
+    hipStream_t st = m->ctx->stream;
+    for (Layer& L : m->layers) {
+        launch_split_planes(st, L.qkv_w.p, L.qkv_w.n, L.qkv_p.p[0], L.qkv_p.p[1], L.qkv_p.p[2]);
+        launch_split_planes(st, L.ao_w.p, L.ao_w.n, L.ao_p.p[0], L.ao_p.p[1], L.ao_p.p[2]);
+        launch_split_planes(st, L.i_w.p, L.i_w.n, L.i_p.p[0], L.i_p.p[1], L.i_p.p[2]);
+        launch_split_planes(st, L.f_w.p, L.f_w.n, L.f_p.p[0], L.f_p.p[1], L.f_p.p[2]);
+    }
+    m->planes_dirty = false;
+}
+
+// one Linear layer of the encoder in the model's compute mode
+void gemm(pcv_model* m, const float* A, const Tensor& W, const Planes& P, const float* bias, const float* resid, float* C,
+          int M, int N, int K, int epi) {
+    if (m->d.compute == PCV_COMPUTE_BF16X3)
+        launch_gemm_bf16x3(m->ctx->stream, A, P.p[0], P.p[1], P.p[2], bias, resid, C, M, N, K, epi);
+    else
+        launch_gemm_f32(m->ctx->stream, A, W.p, bias, resid, C, M, N, K, epi);
+}
+
 void build_tensors(pcv_model* m) {
     const pcv_model_desc& d = m->d;
     const int64_t H = d.hidden, F = d.intermediate;
@@ -93,6 +128,12 @@ void build_tensors(pcv_model* m) {
         L.f_b = alloc_tensor(m, H);
         L.ln2_w = alloc_tensor(m, H);
         L.ln2_b = alloc_tensor(m, H);
+        if (d.compute == PCV_COMPUTE_BF16X3) {
+            alloc_planes(m, L.qkv_p, 3 * H * H);
+            alloc_planes(m, L.ao_p, H * H);
+            alloc_planes(m, L.i_p, F * H);
+            alloc_planes(m, L.f_p, H * F);
+        }
         const std::string p = "encoder.layer." + std::to_string(i) + ".";
         reg(m, p + "attention.self.query.weight", L.qkv_w.p, H * H);
         reg(m, p + "attention.self.key.weight", L.qkv_w.p + H * H, H * H);
@@ -220,6 +261,7 @@ void forward(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L
     const int T = B * L;
     hipStream_t st = m->ctx->stream;
     ensure_workspace(m, B, L);
+    refresh_planes(m);
     // Tensor::stack(ids/masks).to(device), worker.rs:82-83
     PCV_HIP(hipMemcpyAsync(m->d_ids, ids, (size_t)T * 8, hipMemcpyHostToDevice, st));
     PCV_HIP(hipMemcpyAsync(m->d_mask, mask, (size_t)T * 8, hipMemcpyHostToDevice, st));
@@ -235,12 +277,12 @@ void forward(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L
     snap(0);
     for (int ly = 0; ly < d.layers; ++ly) {
         const Layer& W = m->layers[ly];
-        launch_gemm_f32(st, m->hidden, W.qkv_w.p, W.qkv_b.p, nullptr, m->qkv, T, 3 * H, H, EPI_BIAS);
+        gemm(m, m->hidden, W.qkv_w, W.qkv_p, W.qkv_b.p, nullptr, m->qkv, T, 3 * H, H, EPI_BIAS);
         launch_attention(st, m->qkv, m->mask_add, m->ctxbuf, B, L, H, d.heads);
-        launch_gemm_f32(st, m->ctxbuf, W.ao_w.p, W.ao_b.p, m->hidden, m->tmp, T, H, H, EPI_BIAS_RESIDUAL);
+        gemm(m, m->ctxbuf, W.ao_w, W.ao_p, W.ao_b.p, m->hidden, m->tmp, T, H, H, EPI_BIAS_RESIDUAL);
         launch_layer_norm(st, m->tmp, T, H, W.ln1_w.p, W.ln1_b.p, d.layer_norm_eps);
-        launch_gemm_f32(st, m->tmp, W.i_w.p, W.i_b.p, nullptr, m->ff, T, F, H, EPI_BIAS_GELU);
-        launch_gemm_f32(st, m->ff, W.f_w.p, W.f_b.p, m->tmp, m->hidden, T, H, F, EPI_BIAS_RESIDUAL);
+        gemm(m, m->tmp, W.i_w, W.i_p, W.i_b.p, nullptr, m->ff, T, F, H, EPI_BIAS_GELU);
+        gemm(m, m->ff, W.f_w, W.f_p, W.f_b.p, m->tmp, m->hidden, T, H, F, EPI_BIAS_RESIDUAL);
         launch_layer_norm(st, m->hidden, T, H, W.ln2_w.p, W.ln2_b.p, d.layer_norm_eps);
         snap(ly + 1);
     }
@@ -315,8 +357,8 @@ pcv_status pcv_model_create(pcv_ctx* ctx, const pcv_model_desc* desc, const char
         PCV_REQUIRE(d.pooling >= PCV_POOL_MEAN && d.pooling <= PCV_POOL_MEAN_SQRT_LEN, "model_create: unknown pooling %d",
                     d.pooling);
         PCV_REQUIRE(d.dense_out >= 0 && d.dense_out <= 1024, "model_create: dense_out %d outside [0,1024]", d.dense_out);
-        if (d.compute != PCV_COMPUTE_F32)
-            PCV_FAIL(PCV_ERR_UNSUPPORTED, "model_create: only PCV_COMPUTE_F32 is implemented");
+        PCV_REQUIRE(d.compute == PCV_COMPUTE_F32 || d.compute == PCV_COMPUTE_BF16X3, "model_create: unknown compute mode %d",
+                    d.compute);
         PCV_HIP(hipSetDevice(ctx->device));
         auto* m = new pcv_model();
         m->ctx = ctx;
@@ -344,6 +386,7 @@ pcv_status pcv_model_destroy(pcv_model* m) {
         hipStreamSynchronize(m->ctx->stream);
         free_workspace(m);
         for (float* p : m->owned) hipFree(p);
+        for (void* p : m->owned_planes) hipFree(p);
         if (m->ev0) hipEventDestroy(m->ev0);
         if (m->ev1) hipEventDestroy(m->ev1);
         delete m;
@@ -368,6 +411,7 @@ pcv_status pcv_model_set_tensor(pcv_model* m, const char* name, const float* dat
         PCV_HIP(hipSetDevice(m->ctx->device));
         PCV_HIP(hipStreamSynchronize(m->ctx->stream));
         PCV_HIP(hipMemcpy(it->second.p, data, (size_t)n * 4, hipMemcpyHostToDevice));
+        m->planes_dirty = true;
     });
 }
 

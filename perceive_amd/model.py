@@ -38,19 +38,21 @@ class ModelError(RuntimeError):
     """model.rs:29-42 (`ModelError`): any failure of the device forward surfaces here."""
 
 
-def minilm_l6_desc():
+def minilm_l6_desc(compute="f32"):
     d = _ffi.ModelDesc()
     _ffi.lib().pcv_model_desc_minilm_l6(C.byref(d))
+    d.compute = {"f32": _ffi.COMPUTE_F32, "bf16x3": _ffi.COMPUTE_BF16X3}[compute]
     return d
 
 
 def make_desc(vocab_size, hidden, layers, heads, intermediate, max_positions, type_vocab=2, layer_norm_eps=1e-12,
-              pooling="mean", normalize=True, dense_out=0, dense_activation="identity", max_seq_length=256):
+              pooling="mean", normalize=True, dense_out=0, dense_activation="identity", max_seq_length=256,
+              compute="f32"):
     pools = {"mean": _ffi.POOL_MEAN, "cls": _ffi.POOL_CLS, "max": _ffi.POOL_MAX, "mean_sqrt_len": _ffi.POOL_MEAN_SQRT_LEN}
     acts = {"identity": _ffi.ACT_IDENTITY, "tanh": _ffi.ACT_TANH}
     return _ffi.ModelDesc(vocab_size, hidden, layers, heads, intermediate, max_positions, type_vocab, layer_norm_eps,
                           pools[pooling], 1 if normalize else 0, dense_out, acts[dense_activation], max_seq_length,
-                          _ffi.COMPUTE_F32)
+                          {"f32": _ffi.COMPUTE_F32, "bf16x3": _ffi.COMPUTE_BF16X3}[compute])
 
 
 def save_weights(path, tensors):

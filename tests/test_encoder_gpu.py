@@ -152,3 +152,35 @@ def test_weight_file_roundtrip_and_errors(ctx, golden_dir, tmp_path):
     with pytest.raises(pa.PcvError) as e:
         pa.Model(ctx, bad)
     assert e.value.status == 3
+
+
+@pytest.mark.parametrize("shape", ["tiny", "minilm"])
+def test_bf16x3_mode_is_f32_accurate(ctx, oracle, golden_dir, shape):
+    # PCV_COMPUTE_BF16X3: operands split into three bf16 terms, six bf16 MFMAs per product.  Same bar
+    # as the exact-f32 mode (1e-4 on unit-norm embeddings); observed error stays at the 1e-6 level.
+    if shape == "tiny":
+        g, desc, weights = load_tiny(golden_dir)
+        m = make_model(ctx, desc, weights, compute="bf16x3")
+        out = m.encode_tokens(g["ids"], g["mask"])
+        assert np.abs(out - g["normed"]).max() < TOL
+        oout, _ = oracle.encode_tokens(desc, weights, g["ids"], g["mask"])
+        assert np.abs(out - oout).max() < 2e-5
+        # weights replaced after creation are re-split
+        w2 = {k: (v * 1.5 if k.endswith("intermediate.dense.weight") else v) for k, v in weights.items()}
+        m.load_state_dict(w2)
+        o2, _ = oracle.encode_tokens(desc, w2, g["ids"], g["mask"])
+        assert np.abs(m.encode_tokens(g["ids"], g["mask"]) - o2).max() < 2e-5
+        m.close()
+    else:
+        m = pa.Model(ctx, pa.minilm_l6_desc("bf16x3"), synthetic_seed=7)
+        mf = pa.Model(ctx, pa.minilm_l6_desc("f32"), synthetic_seed=7)
+        rng = np.random.default_rng(2)
+        toks = [list(rng.integers(1000, 30000, n)) for n in (48, 7, 31, 20, 64)]
+        ids, mask = m.generate_token_tensors(toks)
+        a, b = m.encode_tokens(ids, mask), mf.encode_tokens(ids, mask)
+        assert np.abs(a - b).max() < 2e-5
+        desc = dict(vocab=30522, hidden=384, layers=6, heads=12, inter=1536, max_pos=512, eps=1e-12, pooling=0, normalize=1)
+        oout, _ = oracle.encode_tokens(desc, m.state_dict(), ids, mask)
+        assert np.abs(a - oout).max() < TOL
+        m.close()
+        mf.close()

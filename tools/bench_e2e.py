@@ -23,9 +23,10 @@ def main():
     ap.add_argument("--seq", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--compute", default="f32", choices=["f32", "bf16x3"])
     a = ap.parse_args()
     ctx = pa.Context(0)
-    m = pa.Model(ctx, synthetic_seed=1)
+    m = pa.Model(ctx, pa.minilm_l6_desc(a.compute), synthetic_seed=1)
     s = pa.Searcher(ctx, 384, "cosine")
     s.add_synthetic(1, a.rows, 0x5EED, normalize=True)  # MiniLM embeddings are unit-norm
     s.finalize()

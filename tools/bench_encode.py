@@ -24,9 +24,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ragged", action="store_true", help="lengths U[32, seq] instead of all-ones masks")
+    ap.add_argument("--compute", default="f32", choices=["f32", "bf16x3"])
     a = ap.parse_args()
     ctx = pa.Context(0)
-    m = pa.Model(ctx, synthetic_seed=1)
+    m = pa.Model(ctx, pa.minilm_l6_desc(a.compute), synthetic_seed=1)
     rng = np.random.default_rng(0)
     ids = rng.integers(1000, 30000, (a.batch, a.seq)).astype(np.int64)
     mask = np.ones((a.batch, a.seq), np.int64)
@@ -48,7 +49,7 @@ def main():
     print(json.dumps({
         "metric": "encoder tokens/sec (all-MiniLM-L6-v2 shape, f32)", "value": a.batch * a.seq * a.steps / wall,
         "unit": "tokens/s", "ms_per_step": 1e3 * wall / a.steps, "device_ms": dev_ms, "dtype": "f32",
-        "config": {"workload": f"encode batch={a.batch} seq_len={a.seq}" + (" ragged" if a.ragged else "")},
+        "config": {"workload": f"encode batch={a.batch} seq_len={a.seq}" + (" ragged" if a.ragged else ""), "compute": a.compute},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / F32_MFMA_PEAK_TFLOPS, "flops_per_step": st["flops"]},
         "docs_per_s": a.batch * a.steps / wall,
