@@ -352,17 +352,35 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(float* __restrict__ x, 
 // registers: row max / sum are in-register reductions plus one cross-half exchange, and the
 // probabilities are, as they stand, the A operand of the P V product (k index = key).
 // ------------------------------------------------------------------------------------------------
-template <int HD>
+// STAGED: the four waves of a workgroup are four query blocks of the same (batch, head), so the
+// workgroup first copies that head's K and V for the whole sequence into LDS (rows padded by 4 floats:
+// conflict-free ds_read_b128 for the K fragments, ds_read_b32 for V) and the inner loops never wait
+// on global memory.  Used whenever 2 * L * (HD+4) * 4 bytes fit the LDS.
+template <int HD, bool STAGED>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv,
                                                         const float* __restrict__ mask_add, float* __restrict__ ctx,
                                                         int B, int L, int Lp, int H) {
     constexpr int KS = HD / 2;   // k-steps of the QK^T product; also floats of a row held per lane
     constexpr int CT = HD / 32;  // 32-wide column tiles of the output
+    constexpr int LDK = HD + 4;  // padded LDS row (floats)
+    extern __shared__ float kv_lds[];  // [L][LDK] keys, then [L][LDK] values
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int qb = blockIdx.x * 4 + wave, head = blockIdx.y, b = blockIdx.z;
-    if (qb * 32 >= L) return;
     const int H3 = 3 * H;
+    float* Ks = kv_lds;
+    float* Vs = kv_lds + (size_t)L * LDK;
+    if (STAGED) {
+        constexpr int C4 = HD / 4;  // float4 pieces per row
+        for (int e = threadIdx.x; e < L * C4; e += 256) {
+            const int key = e / C4, c4 = e - key * C4;
+            const float* src = qkv + (size_t)(b * L + key) * H3 + H + head * HD + c4 * 4;
+            *(f32x4*)&Ks[key * LDK + c4 * 4] = *(const f32x4*)src;
+            *(f32x4*)&Vs[key * LDK + c4 * 4] = *(const f32x4*)(src + H);
+        }
+        __syncthreads();
+    }
+    if (qb * 32 >= L) return;
     const float scale = 1.0f / sqrtf((float)HD);
     const float ninf = -__builtin_inff();
 
@@ -394,7 +412,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                 continue;
             }
             const int krow = min(kt + i, L - 1);
-            const float* kp = qkv + (size_t)(b * L + krow) * H3 + H + head * HD + KS * h;
+            const float* kp = STAGED ? &Ks[krow * LDK + KS * h]
+                                     : qkv + (size_t)(b * L + krow) * H3 + H + head * HD + KS * h;
             float kf[KS];
 #pragma unroll
             for (int v = 0; v < KS / 4; ++v) {
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = min(kt + acc_row(r, h), L - 1);  // clamped keys carry p = 0
-                const float* vp = qkv + (size_t)(b * L + key) * H3 + 2 * H + head * HD + i;
+                const float* vp = STAGED ? &Vs[key * LDK + i] : qkv + (size_t)(b * L + key) * H3 + 2 * H + head * HD + i;
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
                     o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[t][r], vp[32 * c], o[c], 0, 0, 0);
@@ -611,10 +630,27 @@ void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, f
                       int heads) {
     const int Lp = (L + 31) / 32 * 32;
     dim3 grid((Lp / 32 + 3) / 4, heads, B);
-    if (H / heads == 32)
-        attention_kernel<32><<<grid, 256, 0, st>>>(qkv, mask_add, ctx, B, L, Lp, H);
-    else
-        attention_kernel<64><<<grid, 256, 0, st>>>(qkv, mask_add, ctx, B, L, Lp, H);
+    const int HD = H / heads;
+    const size_t lds = (size_t)2 * L * (HD + 4) * sizeof(float);
+    const bool staged = lds <= 150 * 1024;
+#define PCV_ATT(HD_)                                                                                         \
+    if (staged) {                                                                                            \
+        static bool attr = false;                                                                            \
+        if (!attr && lds > 64 * 1024) {                                                                      \
+            hipFuncSetAttribute((const void*)attention_kernel<HD_, true>,                                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+            attr = true;                                                                                     \
+        }                                                                                                    \
+        attention_kernel<HD_, true><<<grid, 256, lds, st>>>(qkv, mask_add, ctx, B, L, Lp, H);                \
+    } else {                                                                                                 \
+        attention_kernel<HD_, false><<<grid, 256, 0, st>>>(qkv, mask_add, ctx, B, L, Lp, H);                 \
+    }
+    if (HD == 32) {
+        PCV_ATT(32)
+    } else {
+        PCV_ATT(64)
+    }
+#undef PCV_ATT
 }
 
 void launch_pool(hipStream_t st, const float* hidden, const float* mask01, int B, int L, int H, int mode,
