@@ -130,6 +130,67 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Skinny GEMM for M <= 128 (a single query, a few highlight chunks): the 128x128 tiling would run
+// N/128 workgroups through K/32 barrier-separated steps each (30-115 us per layer GEMM, launch- and
+// latency-bound).  Here a workgroup owns a 32-column strip of the output for ALL rows, its 8 waves
+// split K, every lane loads its MFMA operands straight from global memory (all loads of a wave in
+// flight at once, no LDS staging), and the 8 partial accumulators meet in LDS.  Same exact-f32
+// v_mfma_f32_32x32x2_f32 arithmetic; only the summation order over K differs (8 partial sums).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ resid, float* __restrict__ C,
+                                                              int M, int N, int K) {
+    __shared__ float red[NW][MT][16][64];  // [wave][row tile][acc reg][lane]; NW waves split K
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int kper = K / NW;  // K is a multiple of 128: kper is a multiple of 16
+    const int kbeg = wave * kper;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const float* wp = W + (size_t)(n0 + i) * K + kbeg + 8 * kk;
+    const float* ap[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ap[t] = A + (size_t)min(32 * t + i, M - 1) * K + kbeg + 8 * kk;
+    for (int k0 = 0; k0 < kper; k0 += 16) {  // lane (i, kk) holds k = k0 + 8*kk + s, s = 0..7, of row i
+        const f32x4 b0 = *(const f32x4*)(wp + k0), b1 = *(const f32x4*)(wp + k0 + 4);
+        const float bf[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const f32x4 a0 = *(const f32x4*)(ap[t] + k0), a1 = *(const f32x4*)(ap[t] + k0 + 4);
+            const float af[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2], bf[s2], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][t][r][lane] = acc[t][r];
+    __syncthreads();
+    // all threads sum the NW partials of MT*16*64 values in wave order and finish the epilogue
+    for (int e = tid; e < MT * 16 * 64; e += NW * 64) {
+        const int l = e & 63, r = (e >> 6) & 15, t = e >> 10;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][t][r][l];
+        const int row = 32 * t + acc_row(r, l >> 5), col = n0 + (l & 31);
+        if (row < M) {
+            v += bias ? bias[col] : 0.0f;
+            if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
+            C[(size_t)row * N + col] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Split-precision GEMM: C = A W^T with x = hi + mid + lo (three bf16 terms, 24 significand bits).
 //   a*b ~ ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh        (dropped: am*bl, al*bm, al*bl < 2^-24)
 // Six v_mfma_f32_32x32x16_bf16 per 16-deep step instead of eight v_mfma_f32_32x32x2_f32 at 1/16 the
@@ -581,9 +642,33 @@ __global__ __launch_bounds__(256) void synth_weights_kernel(float* __restrict__ 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+template <int MT, int NW>
+static void launch_skinny(hipStream_t st, const float* A, const float* W, const float* bias, const float* resid,
+                          float* C, int M, int N, int K, int epilogue) {
+    const dim3 grid(N / 32);
+    switch (epilogue) {
+        case EPI_BIAS_GELU:
+            gemm_skinny_f32_kernel<EPI_BIAS_GELU, MT, NW><<<grid, NW * 64, 0, st>>>(A, W, bias, resid, C, M, N, K);
+            break;
+        case EPI_BIAS_RESIDUAL:
+            gemm_skinny_f32_kernel<EPI_BIAS_RESIDUAL, MT, NW><<<grid, NW * 64, 0, st>>>(A, W, bias, resid, C, M, N, K);
+            break;
+        default: gemm_skinny_f32_kernel<EPI_BIAS, MT, NW><<<grid, NW * 64, 0, st>>>(A, W, bias, resid, C, M, N, K); break;
+    }
+}
+
 void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float* bias, const float* resid, float* C,
                      int M, int N, int K, int epilogue) {
     if (M <= 0) return;
+    if (M <= 128 && K % 128 == 0) {  // single queries / a few short chunks
+        if (M <= 32)
+            launch_skinny<1, 8>(st, A, W, bias, resid, C, M, N, K, epilogue);
+        else if (M <= 64)
+            launch_skinny<2, 8>(st, A, W, bias, resid, C, M, N, K, epilogue);
+        else
+            launch_skinny<4, 4>(st, A, W, bias, resid, C, M, N, K, epilogue);
+        return;
+    }
     dim3 grid(N / BN, (M + BM - 1) / BM);
     switch (epilogue) {
         case EPI_BIAS_GELU: gemm_f32_kernel<EPI_BIAS_GELU><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K); break;

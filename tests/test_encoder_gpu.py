@@ -184,3 +184,20 @@ def test_bf16x3_mode_is_f32_accurate(ctx, oracle, golden_dir, shape):
         assert np.abs(a - oout).max() < TOL
         m.close()
         mf.close()
+
+
+@pytest.mark.parametrize("tokens", [(1, 5), (1, 32), (2, 20), (3, 33), (8, 16), (5, 40)])
+def test_small_batches_take_the_skinny_gemm_path(ctx, oracle, tokens):
+    # T = B*L <= 128 tokens runs the K-split skinny GEMM (1, 2 or 4 row tiles); T = 200 the tiled one
+    B, L = tokens
+    desc = dict(vocab=400, hidden=256, layers=2, heads=8, inter=512, max_pos=64, eps=1e-12, pooling=0, normalize=1)
+    m = make_model(ctx, desc, seed=9)
+    rng = np.random.default_rng(B * 100 + L)
+    ids = rng.integers(1, 400, (B, L)).astype(np.int64)
+    mask = np.ones_like(ids)
+    mask[-1, max(1, L // 2):] = 0
+    ids *= mask
+    out = m.encode_tokens(ids, mask)
+    oout, _ = oracle.encode_tokens(desc, m.state_dict(), ids, mask)
+    assert np.abs(out - oout).max() < 2e-5
+    m.close()
