@@ -438,3 +438,46 @@ def test_large_dim_falls_back_to_wave_kernel(ctx, oracle):
         s.search_vectors(None, 5, q)
     assert e.value.status == 3
     s.close()
+
+
+def test_empty_and_degenerate_indexes(ctx):
+    s = pa.Searcher(ctx, 32, "cosine")
+    s.finalize()  # nothing added
+    q = np.ones((2, 32), np.float32)
+    ids, sc, cnt = s.search_vectors(None, 5, q)
+    assert cnt.sum() == 0 and (ids == -1).all() and np.isnan(sc).all()
+    assert s.num_rows == 0 and s.source_ids == []
+    s.add_rows(3, np.zeros((0, 32), np.float32))  # empty batch creates nothing searchable
+    s.finalize()
+    s.finalize()  # idempotent
+    assert s.search_vectors(None, 5, q)[2].sum() == 0
+    s.add_rows(3, np.eye(32, dtype=np.float32)[:1])  # one row, k larger than the corpus
+    s.finalize()
+    ids, sc, cnt = s.search_vectors([3], 5, q)
+    assert cnt.tolist() == [1, 1] and ids[:, 0].tolist() == [0, 0]
+    np.testing.assert_allclose(sc[:, 0], 1 / np.sqrt(32), atol=1e-7)
+    from perceive_amd import _ffi
+    _ffi.check(_ffi.lib().pcv_searcher_clear_source(s._handle, 12345))  # unknown source: no-op (search.rs:58-79)
+    s.finalize()
+    assert s.num_rows == 1
+    s.close()
+    s.close()  # double close is harmless
+
+
+def test_incremental_adds_make_several_segments(ctx, oracle):
+    # add -> finalize -> add -> finalize on one source: two segments, one logical source
+    rng = np.random.default_rng(77)
+    a = rng.standard_normal((1000, 96)).astype(np.float32)
+    b = rng.standard_normal((500, 96)).astype(np.float32)
+    s = pa.Searcher(ctx, 96, "cosine")
+    s.add_rows(1, a, np.arange(1000))
+    s.finalize()
+    s.add_rows(1, b, 5000 + np.arange(500))
+    s.finalize()
+    assert s.num_rows == 1500
+    q = rng.standard_normal((9, 96)).astype(np.float32)
+    ids, sc, _ = s.search_vectors([1], 10, q)
+    allm = np.concatenate([a, b])
+    allids = np.concatenate([np.arange(1000), 5000 + np.arange(500)])
+    np.testing.assert_array_equal(ids, allids[oracle.topk(q, allm, 10)[0]])
+    s.close()
