@@ -211,6 +211,8 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, b
     lo = __builtin_convertvector(r2, bf16x4);
 }
 
+// (Variant tried and dropped: activations pre-split into planes by the producing kernels.  6 B/element
+// of staging traffic instead of 4, 2-byte plane stores in every producer: slower end to end.)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restrict__ A, const uint16_t* __restrict__ Wh,
                                                           const uint16_t* __restrict__ Wm,
@@ -225,23 +227,35 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    // A staging: float4 (row = (t>>3) + 32u, k = 4*(t&7)), u = 0..3
-    const int arow = tid >> 3, ac4 = tid & 7;
+    // Staging maps.  LDS rows are 80 bytes; a group of lanes that one ds_write services together must
+    // touch rows r and r+4 (80*4 = 64 mod 128) to cover all 32 banks exactly once.
+    //   A: float4 -> three 8-byte plane pieces; 8 lanes cover a row's 32 k, lane pairs of groups
+    //      (2j, 2j+1) take rows r, r+4.  Row of group g: 8*((g>>1)>>2) + ((g>>1)&3) + 4*(g&1), +32u.
+    //   W: 16-byte pieces of each pre-split plane; lanes 0-3 of an 8-lane group take row r, 4-7 row r+4.
+    const int ag_ = tid >> 3, ac4 = tid & 7;
+    const int arow = 8 * ((ag_ >> 1) >> 2) + ((ag_ >> 1) & 3) + 4 * (ag_ & 1);
     const float* ag[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) ag[u] = A + (size_t)min(m0 + arow + 32 * u, M - 1) * K + ac4 * 4;
-    // W staging: 8 bf16 (row = (t>>2) + 64u, k = 8*(t&3)) of each plane, u = 0..1
-    const int wrow = tid >> 2, wc8 = tid & 3;
+    const int wg_ = tid >> 3, wsub = tid & 7;
+    const int wc8 = wsub & 3;
+    const int wrow = (wg_ >> 2) * 8 + (wg_ & 3) + 4 * (wsub >> 2);  // 0..63, second piece +64
     const size_t woff0 = (size_t)(n0 + wrow) * K + wc8 * 8;
     const size_t woff1 = woff0 + (size_t)64 * K;
 
-    f32x4 ra[4];
-    f32x4 rw[3][2];  // 8 bf16 = 16 bytes, moved as f32x4
+    // two register sets: the loads of K tile kt+2 are issued while tile kt is multiplied, so a tile has
+    // two MFMA phases (~1.5 us) to arrive — one phase (0.75 us at six bf16 MFMAs per product) does not
+    // cover the memory latency and left the matrix pipe 41 % busy
+    f32x4 ra[2][4];
+    f32x4 rw[2][3][2];  // 8 bf16 = 16 bytes, moved as f32x4
+    auto load_tile = [&](int set, int kt) {
+        const size_t koff = (size_t)kt * BK;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ra[u] = *(const f32x4*)(ag[u]);
-    rw[0][0] = *(const f32x4*)(Wh + woff0); rw[0][1] = *(const f32x4*)(Wh + woff1);
-    rw[1][0] = *(const f32x4*)(Wm + woff0); rw[1][1] = *(const f32x4*)(Wm + woff1);
-    rw[2][0] = *(const f32x4*)(Wl + woff0); rw[2][1] = *(const f32x4*)(Wl + woff1);
+        for (int u = 0; u < 4; ++u) ra[set][u] = *(const f32x4*)(ag[u] + koff);
+        rw[set][0][0] = *(const f32x4*)(Wh + woff0 + koff); rw[set][0][1] = *(const f32x4*)(Wh + woff1 + koff);
+        rw[set][1][0] = *(const f32x4*)(Wm + woff0 + koff); rw[set][1][1] = *(const f32x4*)(Wm + woff1 + koff);
+        rw[set][2][0] = *(const f32x4*)(Wl + woff0 + koff); rw[set][2][1] = *(const f32x4*)(Wl + woff1 + koff);
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -251,13 +265,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    const int nk = K / BK;
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk = K / BK;  // even: K is a multiple of 128
+    auto step = [&](int set, int kt) {
         __syncthreads();  // previous step's fragment reads are done
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             bf16x4 ph, pm, pl;
-            split3(ra[u], ph, pm, pl);
+            split3(ra[set][u], ph, pm, pl);
             const int o = (arow + 32 * u) * LDB + ac4 * 4;
             *(bf16x4*)&As[0][o] = ph;
             *(bf16x4*)&As[1][o] = pm;
@@ -265,18 +279,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
         }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            *(f32x4*)&Ws[pl][wrow * LDB + wc8 * 8] = rw[pl][0];
-            *(f32x4*)&Ws[pl][(wrow + 64) * LDB + wc8 * 8] = rw[pl][1];
+            *(f32x4*)&Ws[pl][wrow * LDB + wc8 * 8] = rw[set][pl][0];
+            *(f32x4*)&Ws[pl][(wrow + 64) * LDB + wc8 * 8] = rw[set][pl][1];
         }
         __syncthreads();
-        {
-            const size_t koff = (size_t)min(kt + 1, nk - 1) * BK;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ra[u] = *(const f32x4*)(ag[u] + koff);
-            rw[0][0] = *(const f32x4*)(Wh + woff0 + koff); rw[0][1] = *(const f32x4*)(Wh + woff1 + koff);
-            rw[1][0] = *(const f32x4*)(Wm + woff0 + koff); rw[1][1] = *(const f32x4*)(Wm + woff1 + koff);
-            rw[2][0] = *(const f32x4*)(Wl + woff0 + koff); rw[2][1] = *(const f32x4*)(Wl + woff1 + koff);
-        }
+        load_tile(set, min(kt + 2, nk - 1));  // refill this set for tile kt+2 (clamped re-read at the end)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {  // two 16-deep steps per 32-wide K tile
             bf16x8 af[2][3], bf[2][3];
@@ -300,6 +307,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], acc[a][b], 0, 0, 0);
                 }
         }
+    };
+    load_tile(0, 0);
+    load_tile(1, min(1, nk - 1));
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(0, kt);
+        if (kt + 1 < nk) step(1, kt + 1);
     }
 
 #pragma unroll
