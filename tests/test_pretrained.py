@@ -1,0 +1,102 @@
+"""Model::new_pretrained over a local sentence-transformers model directory (model.rs:68-174): config
+parsing on the CPU, and — on the GPU — text in / embedding out against Hugging Face running the same
+checkpoint (BertModel + mean pooling + normalisation) on the CPU.  The directory is synthetic (random
+weights written by transformers' save_pretrained): no real checkpoint exists offline."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import perceive_amd as pa
+
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+
+
+def make_model_dir(tmp_path, golden_dir, with_dense=False, fmt="safetensors"):
+    import torch
+    from transformers import BertConfig, BertModel
+
+    torch.manual_seed(3)
+    d = tmp_path / "all-MiniLM-L6-v2"
+    d.mkdir(parents=True)
+    vocab = os.path.join(golden_dir, "tokenizer_vocab.txt")
+    nvocab = sum(1 for _ in open(vocab, encoding="utf-8"))
+    cfg = BertConfig(vocab_size=nvocab, hidden_size=128, num_hidden_layers=2, num_attention_heads=4,
+                     intermediate_size=256, max_position_embeddings=64, layer_norm_eps=1e-12, hidden_act="gelu")
+    model = BertModel(cfg, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if v.dim() == 2:
+                v.mul_(4.0)
+    model.save_pretrained(d, safe_serialization=(fmt == "safetensors"))
+    shutil.copy(vocab, d / "vocab.txt")
+    mods = [{"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+            {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]
+    (d / "1_Pooling").mkdir()
+    (d / "1_Pooling" / "config.json").write_text(json.dumps({
+        "word_embedding_dimension": 128, "pooling_mode_cls_token": False, "pooling_mode_mean_tokens": True,
+        "pooling_mode_max_tokens": False, "pooling_mode_mean_sqrt_len_tokens": False}))
+    dense_w = None
+    if with_dense:
+        from safetensors.numpy import save_file
+
+        (d / "2_Dense").mkdir()
+        rng = np.random.default_rng(0)
+        dense_w = ((rng.standard_normal((64, 128)) * 0.2).astype(np.float32), (rng.standard_normal(64) * 0.1).astype(np.float32))
+        save_file({"linear.weight": dense_w[0], "linear.bias": dense_w[1]}, str(d / "2_Dense" / "model.safetensors"))
+        (d / "2_Dense" / "config.json").write_text(json.dumps({
+            "in_features": 128, "out_features": 64, "bias": True, "activation_function": "torch.nn.modules.activation.Tanh"}))
+        mods.append({"idx": 2, "name": "2", "path": "2_Dense", "type": "sentence_transformers.models.Dense"})
+    mods.append({"idx": len(mods), "name": str(len(mods)), "path": f"{len(mods)}_Normalize", "type": "sentence_transformers.models.Normalize"})
+    (d / "modules.json").write_text(json.dumps(mods))
+    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 32, "do_lower_case": False}))
+    (d / "tokenizer_config.json").write_text(json.dumps({"do_lower_case": True}))
+    return d, model, dense_w
+
+
+def test_parse_model_dir(tmp_path, golden_dir):
+    d, _, _ = make_model_dir(tmp_path, golden_dir, with_dense=True)
+    desc, tok, dense = pa.parse_model_dir(str(d))
+    assert desc["hidden"] == 128 and desc["layers"] == 2 and desc["heads"] == 4 and desc["intermediate"] == 256
+    assert desc["pooling"] == "mean" and desc["normalize"] is True and desc["max_seq_length"] == 32
+    assert desc["dense_out"] == 64 and desc["dense_activation"] == "tanh"
+    assert tok == {"lower_case": True, "strip_accents": None}  # tokenizer_config wins over sentence_bert_config
+    # unsupported architectures fail loudly
+    cfg = json.loads((d / "config.json").read_text())
+    cfg["model_type"] = "distilbert"
+    (d / "config.json").write_text(json.dumps(cfg))
+    with pytest.raises(pa.ModelError):
+        pa.parse_model_dir(str(d))
+    with pytest.raises(pa.ModelError):
+        pa.parse_model_dir(str(tmp_path / "nope"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,with_dense", [("safetensors", False), ("bin", False), ("safetensors", True)])
+def test_new_pretrained_matches_hf(ctx, tmp_path, golden_dir, fmt, with_dense):
+    import torch
+    from transformers import BertTokenizerFast
+
+    d, hf, dense_w = make_model_dir(tmp_path, golden_dir, with_dense=with_dense, fmt=fmt)
+    m = pa.new_pretrained(ctx, pa.SentenceEmbeddingsModelType.AllMiniLmL6V2, model_data_dir=str(tmp_path))
+    assert m.model_type.model_id == 0 and m.desc.max_seq_length == 32
+    texts = ["Hello world", "The search of embeddings, really?", "document " * 40, "Café naïve"]
+    out = m.encode(texts)
+    tok = BertTokenizerFast(str(d / "vocab.txt"), do_lower_case=True)
+    enc = tok(texts, padding=True, truncation=True, max_length=32, return_tensors="pt")
+    with torch.no_grad():
+        h = hf(**enc).last_hidden_state
+        msk = enc["attention_mask"].unsqueeze(-1).float()
+        pooled = (h * msk).sum(1) / msk.sum(1).clamp_min(1e-9)
+        if with_dense:
+            pooled = torch.tanh(pooled @ torch.from_numpy(dense_w[0]).T + torch.from_numpy(dense_w[1]))
+        ref = (pooled / pooled.norm(dim=1, keepdim=True).clamp_min(1e-12)).numpy()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() < 1e-4
+    q = pa.encode_query(m, "hello world")
+    np.testing.assert_allclose(q, out[0], atol=1e-6)
+    m.close()
+    with pytest.raises(pa.ModelError):
+        pa.new_pretrained(ctx, pa.SentenceEmbeddingsModelType.MsMarcoDistilbertDotV5, model_data_dir=str(tmp_path))
