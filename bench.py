@@ -59,6 +59,10 @@ def cpu_baseline(args):
         secs, _, _ = orc.baseline_scan(q, rows, args.k, threads)
         total += secs
         reps += 1
+    # the reference-shaped form (normalised copy of the corpus, full [B,N] score matrix, then select:
+    # what libtorch does for lib.rs:73-77) on a slice small enough for its 4*B*N-byte score matrix
+    ns = min(n, 250_000)
+    shaped_s, _, _ = orc.baseline_scan(q, rows[:ns], args.k, threads, shaped=True)
     return {
         "value": n * reps / total,
         "unit": "vectors/s",
@@ -67,6 +71,7 @@ def cpu_baseline(args):
         "sample": f"{reps} x fused f32 cosine+top-{args.k} scan of {n} x {args.dim} synthetic rows, batch={args.batch}, "
                   f"{total:.1f} s on {threads} threads (oracle/baseline.c)",
         "queries_per_s": args.batch * reps / total,
+        "reference_shaped_vectors_per_s": ns / shaped_s,
     }
 
 
@@ -206,6 +211,8 @@ def main():
                 "kernel": kname,
                 "bytes_per_launch": per_launch_bytes,
                 "kernel_ms": mean_scan_ms,
+                "kernel_ms_median": float(np.median(scan_ms)),
+                "kernel_ms_min": float(np.min(scan_ms)),
             },
             "candidates_per_query": float(np.mean(cands)) / B,
             "overflow_reruns": reruns,
