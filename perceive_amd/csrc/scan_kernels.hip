@@ -497,49 +497,93 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
 #pragma unroll
     for (int b = 0; b < NB; ++b) mrg[b] = gld(&p.margin[b]);
     const uint32_t total_waves = gridDim.x * 4;
-    const int half = p.D4 >> 1;
-    for (uint32_t gb = blockIdx.x * 4 + wave; gb < p.total_blocks; gb += total_waves) {
-        const int si = find_seg(p, gb);
-        const SegDesc& sg = p.seg[si];
-        const uint32_t lb = gb - sg.blk0;
-        const float4* base = sg.blk + (size_t)lb * p.D4 * 32 + h * 32 + r;
-        const float* qb = sq + h * 4;
-        // issued with the row loads so that their latency overlaps the streaming
-        const uint32_t row = lb * 32 + r;
-        const float sc = gld(&sg.scale[row]);
-        uint32_t tk[NB];
+    const int NCH = p.D4 >> 4;  // chunks of 8 pieces per lane (64 features of the row, both halves)
+    if (blockIdx.x * 4 + wave >= p.total_blocks) return;
+
+    // Same flat (block, chunk) stream with register chunk buffers as the MFMA kernel: the loads of the
+    // next chunk — also across block boundaries — are in flight while the current one is multiplied.
+    struct Cur {
+        uint32_t gb;
+        int si;
+        uint32_t lb;
+        const float4* base;
+        int ch;
+    } cons, prod;
+    auto enter = [&](Cur& k, uint32_t gb) {
+        k.gb = gb;
+        k.ch = 0;
+        if (gb < p.total_blocks) {
+            k.si = find_seg(p, gb);
+            k.lb = gb - p.seg[k.si].blk0;
+            k.base = p.seg[k.si].blk + (size_t)k.lb * p.D4 * 32 + h * 32 + r;
+        }
+    };
+    enter(cons, blockIdx.x * 4 + wave);
+    prod = cons;
+    float sc_cur = gld(&p.seg[cons.si].scale[(size_t)cons.lb * 32 + r]), sc_next = 0.0f;
+    uint32_t tk[NB];
+    float acc[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) tk[b] = ld_relaxed(&p.tau[b * kHot]);
-        float acc[NB];
+    for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
+
+    float4 buf[2][8];
+    auto produce = [&](float4 (&bf)[8]) {
+        if (prod.gb >= p.total_blocks) return;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = 0.0f;
-#pragma unroll 8
-        for (int j = 0; j < half; ++j) {
-            const float4 v = ld_row<NTL>(base + (size_t)j * 64);
+        for (int i = 0; i < 8; ++i) bf[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 8 + i) * 64);
+        if (++prod.ch == NCH) {
+            enter(prod, prod.gb + total_waves);
+            if (prod.gb < p.total_blocks) sc_next = gld(&p.seg[prod.si].scale[(size_t)prod.lb * 32 + r]);
+        }
+    };
+    auto consume = [&](const float4 (&bf)[8]) {
+        if (cons.ch == (NCH >= 2 ? NCH - 2 : 0)) {  // thresholds one chunk ahead of the epilogue
+#pragma unroll
+            for (int b = 0; b < NB; ++b) tk[b] = ld_relaxed(&p.tau[b * kHot]);
+        }
+        const float* qb = sq + h * 4 + cons.ch * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = bf[i];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const float4 qv = *(const float4*)&qb[b * Dp + j * 8];
+                const float4 qv = *(const float4*)&qb[b * Dp + i * 8];
                 acc[b] = fmaf(qv.x, v.x, acc[b]);
                 acc[b] = fmaf(qv.y, v.y, acc[b]);
                 acc[b] = fmaf(qv.z, v.z, acc[b]);
                 acc[b] = fmaf(qv.w, v.w, acc[b]);
             }
         }
-        bool any = false;
-        float s[NB], thr[NB];
+        if (++cons.ch == NCH) {  // block done: lane r (h = 0) owns row r
+            const uint32_t row = cons.lb * 32 + r;
+            bool any = false;
+            float s[NB], thr[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            acc[b] += __shfl_xor(acc[b], 32);
-            s[b] = acc[b] * sc;
-            thr[b] = key_f32(tk[b]) - mrg[b];
-            any |= (h == 0) && (sc != 0.0f) && !(s[b] < thr[b]);
-        }
-        if (__any(any)) {
-            const bool feeds = !(si == 0 && lb < p.seed_blocks);
+            for (int b = 0; b < NB; ++b) {
+                acc[b] += __shfl_xor(acc[b], 32);
+                s[b] = acc[b] * sc_cur;
+                thr[b] = key_f32(tk[b]) - mrg[b];
+                any |= (h == 0) && (sc_cur != 0.0f) && !(s[b] < thr[b]);
+                acc[b] = 0.0f;
+            }
+            if (__any(any)) {
+                const bool feeds = !(cons.si == 0 && cons.lb < p.seed_blocks);
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-                if ((h == 0) && (sc != 0.0f) && !(s[b] < thr[b])) emit_hit(p, b, si, row, s[b], feeds);
+                for (int b = 0; b < NB; ++b)
+                    if ((h == 0) && (sc_cur != 0.0f) && !(s[b] < thr[b])) emit_hit(p, b, cons.si, row, s[b], feeds);
+            }
+            enter(cons, cons.gb + total_waves);
+            sc_cur = sc_next;
         }
+    };
+    produce(buf[0]);
+    while (true) {
+        produce(buf[1]);
+        consume(buf[0]);
+        if (cons.gb >= p.total_blocks) return;
+        produce(buf[0]);
+        consume(buf[1]);
+        if (cons.gb >= p.total_blocks) return;
     }
 }
 
