@@ -2,6 +2,7 @@
 // (replaces model.rs:56-191 + model/worker.rs:78-106 of the reference; kernels: encoder_kernels.hip).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -56,11 +57,22 @@ struct pcv_model {
     int64_t dbg_tokens = 0;
     int last_B = 0, last_L = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // hipGraph replay of small forwards, keyed by (B, L)
+    std::map<std::pair<int, int>, hipGraphExec_t> graphs;
+    std::map<std::pair<int, int>, int> shape_seen;
+    bool use_graphs = true;
 };
 
 namespace {
 
 constexpr int64_t kDebugTokenLimit = 16384;
+constexpr int kGraphTokens = 128;  // forwards up to this many tokens are replayed as hipGraphs
+
+void drop_graphs(pcv_model* m) {
+    for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+    m->graphs.clear();
+    m->shape_seen.clear();
+}
 
 Tensor alloc_tensor(pcv_model* m, int64_t n) {
     Tensor t;
@@ -235,6 +247,7 @@ void ensure_workspace(pcv_model* m, int B, int L) {
     const int64_t T = (int64_t)B * L;
     const int64_t Tp = (int64_t)B * ((L + 31) / 32 * 32);
     if (Tp <= m->cap_tokens && B <= m->cap_batch) return;
+    drop_graphs(m);  // they hold the old workspace pointers
     free_workspace(m);
     const int64_t H = m->d.hidden, F = m->d.intermediate;
     const int64_t OD = m->d.dense_out > 0 ? m->d.dense_out : H;
@@ -255,17 +268,12 @@ void ensure_workspace(pcv_model* m, int B, int L) {
 }
 
 // worker.rs:78-106 on the device.  Leaves [B][out_dim] in m->out.
-void forward(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L) {
+// The kernel sequence of one forward (no allocation, no synchronisation: capturable in a hipGraph).
+void launch_forward(pcv_model* m, int B, int L) {
     const pcv_model_desc& d = m->d;
     const int H = d.hidden, F = d.intermediate;
     const int T = B * L;
     hipStream_t st = m->ctx->stream;
-    ensure_workspace(m, B, L);
-    refresh_planes(m);
-    // Tensor::stack(ids/masks).to(device), worker.rs:82-83
-    PCV_HIP(hipMemcpyAsync(m->d_ids, ids, (size_t)T * 8, hipMemcpyHostToDevice, st));
-    PCV_HIP(hipMemcpyAsync(m->d_mask, mask, (size_t)T * 8, hipMemcpyHostToDevice, st));
-    PCV_HIP(hipEventRecord(m->ev0, st));
     launch_embed_ln(st, m->d_ids, m->d_mask, B, L, H, d.vocab_size, m->word.p, m->pos.p, m->type.p, m->eln_w.p,
                     m->eln_b.p, d.layer_norm_eps, m->hidden, m->mask_add, m->mask01);
     const bool dbg = m->dbg != nullptr && T <= kDebugTokenLimit;
@@ -293,11 +301,56 @@ void forward(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L
     } else {
         launch_pool(st, m->hidden, m->mask01, B, L, H, d.pooling, d.normalize, m->out);
     }
-    PCV_HIP(hipEventRecord(m->ev1, st));
     m->dbg_tokens = dbg ? T : 0;
+}
+
+// worker.rs:78-106 on the device.  Leaves [B][out_dim] in m->out.
+// Up to kGraphTokens tokens (a query, a few highlight chunks) the forward is ~45 kernels of a few
+// microseconds each: launch-bound.  The second time a (B, L) shape is seen its launch sequence is
+// captured into a hipGraph and replayed from then on (workspace and weight pointers are stable; a
+// workspace reallocation drops the cached graphs).
+void forward(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L) {
+    const int T = B * L;
+    hipStream_t st = m->ctx->stream;
+    ensure_workspace(m, B, L);
+    refresh_planes(m);
+    // Tensor::stack(ids/masks).to(device), worker.rs:82-83
+    PCV_HIP(hipMemcpyAsync(m->d_ids, ids, (size_t)T * 8, hipMemcpyHostToDevice, st));
+    PCV_HIP(hipMemcpyAsync(m->d_mask, mask, (size_t)T * 8, hipMemcpyHostToDevice, st));
+    PCV_HIP(hipEventRecord(m->ev0, st));
+    const std::pair<int, int> key{B, L};
+    auto it = m->graphs.find(key);
+    if (T <= kGraphTokens && m->use_graphs && it != m->graphs.end()) {
+        PCV_HIP(hipGraphLaunch(it->second, st));
+        m->dbg_tokens = (m->dbg != nullptr && T <= kDebugTokenLimit) ? T : 0;
+    } else if (T <= kGraphTokens && m->use_graphs && ++m->shape_seen[key] >= 2) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        PCV_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        bool ok = true;
+        try {
+            launch_forward(m, B, L);
+        } catch (...) {
+            ok = false;
+        }
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (ok && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            m->graphs[key] = exec;
+            PCV_HIP(hipGraphLaunch(exec, st));
+        } else {  // capture not possible here: stay eager for good
+            (void)hipGetLastError();
+            m->use_graphs = false;
+            launch_forward(m, B, L);
+        }
+        if (graph) hipGraphDestroy(graph);
+    } else {
+        launch_forward(m, B, L);
+    }
+    PCV_HIP(hipEventRecord(m->ev1, st));
     m->last_B = B;
     m->last_L = L;
 }
+
 
 void check_tokens(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L) {
     PCV_REQUIRE(m != nullptr && ids != nullptr && mask != nullptr, "encode_tokens: NULL argument");
@@ -363,6 +416,7 @@ pcv_status pcv_model_create(pcv_ctx* ctx, const pcv_model_desc* desc, const char
         auto* m = new pcv_model();
         m->ctx = ctx;
         m->d = d;
+        if (getenv("PCV_NO_GRAPHS")) m->use_graphs = false;  // diagnostics: always launch eagerly
         try {
             build_tensors(m);
             PCV_HIP(hipEventCreate(&m->ev0));
@@ -384,6 +438,7 @@ pcv_status pcv_model_destroy(pcv_model* m) {
         if (!m) return;
         hipSetDevice(m->ctx->device);
         hipStreamSynchronize(m->ctx->stream);
+        drop_graphs(m);
         free_workspace(m);
         for (float* p : m->owned) hipFree(p);
         for (void* p : m->owned_planes) hipFree(p);

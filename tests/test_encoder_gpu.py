@@ -201,3 +201,33 @@ def test_small_batches_take_the_skinny_gemm_path(ctx, oracle, tokens):
     oout, _ = oracle.encode_tokens(desc, m.state_dict(), ids, mask)
     assert np.abs(out - oout).max() < 2e-5
     m.close()
+
+
+def test_graph_replay_matches_eager(ctx, oracle):
+    # small forwards are captured into a hipGraph on their second occurrence and replayed afterwards:
+    # same bits as the eager launches, also after the inputs (and the batch shape) change
+    desc = dict(vocab=400, hidden=256, layers=2, heads=8, inter=512, max_pos=64, eps=1e-12, pooling=0, normalize=1)
+    m = make_model(ctx, desc, seed=21)
+    sd = m.state_dict()
+    rng = np.random.default_rng(0)
+    for shape in [(1, 12), (2, 7), (1, 12)]:
+        outs = []
+        for rep in range(4):  # eager, capture+launch, replay, replay
+            ids = rng.integers(1, 400, shape).astype(np.int64)
+            mask = np.ones_like(ids)
+            out = m.encode_tokens(ids, mask)
+            oout, ohid = oracle.encode_tokens(desc, sd, ids, mask, want_hidden=True)
+            assert np.abs(out - oout).max() < 2e-5, (shape, rep)
+            np.testing.assert_allclose(m.debug_hidden(2, *shape), ohid[-1], atol=1e-4)
+            outs.append((ids, out))
+        again = m.encode_tokens(outs[0][0], np.ones_like(outs[0][0]))
+        np.testing.assert_array_equal(again, outs[0][1])  # replay == eager, bit for bit
+    # growing the workspace drops the graphs; the small shape still works afterwards
+    big = rng.integers(1, 400, (40, 60)).astype(np.int64)
+    m.encode_tokens(big, np.ones_like(big))
+    ids = rng.integers(1, 400, (1, 12)).astype(np.int64)
+    for _ in range(3):
+        out = m.encode_tokens(ids, np.ones_like(ids))
+    oout, _ = oracle.encode_tokens(desc, sd, ids, np.ones_like(ids))
+    assert np.abs(out - oout).max() < 2e-5
+    m.close()
