@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=int(os.environ.get("PCV_BENCH_CPU_ROWS", 1_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--normalized", action="store_true", help="store unit-norm rows (MiniLM-like)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1: strong = --rows is the whole corpus, sharded (BASELINE configs[3]); weak = --rows per GPU")
     return ap.parse_args()
 
 
@@ -109,8 +111,9 @@ def main():
     import perceive_amd as pa
 
     ctx = pa.Context(local_rank if use_dist else 0)
-    lo = args.rows * rank // world
-    hi = args.rows * (rank + 1) // world
+    total_rows = args.rows * world if args.scaling == "weak" else args.rows
+    lo = total_rows * rank // world
+    hi = total_rows * (rank + 1) // world
     searcher = pa.Searcher(ctx, args.dim, "cosine")
     t0 = time.time()
     searcher.add_synthetic(1, hi - lo, 0x5EED, first_row=lo, normalize=args.normalized)
@@ -173,7 +176,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        vectors_per_s = args.rows * args.steps / elapsed
+        vectors_per_s = total_rows * args.steps / elapsed
         per_launch_bytes = float(np.mean(scan_bytes))  # this rank's shard: rows * dim * 4
         achieved = per_launch_bytes / (mean_scan_ms * 1e-3) / 1e9
         ids, scores, counts = last
@@ -188,14 +191,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.rows} x {args.dim} f32 synthetic corpus, batch={B} queries, top-{k}, "
+                "workload": f"{total_rows} x {args.dim} f32 synthetic corpus, batch={B} queries, top-{k}, "
                             f"{world} MI355X" + (" (rows sharded, RCCL all-gather of per-shard top-k)" if world > 1 else ""),
-                "rows": args.rows, "dim": args.dim, "batch": B, "k": k,
+                "rows": total_rows, "dim": args.dim, "batch": B, "k": k,
                 "kernel": {1: "wave", 2: "mfma"}[searcher.last_stats()["kernel_used"]],
                 "rows_normalized": bool(args.normalized),
             },

@@ -261,7 +261,7 @@ void ensure_workspace(pcv_searcher* s) {
         if (!e) PCV_HIP(hipEventCreate(&e));
 }
 
-// One pass: <= 64 queries over <= kMaxSeg segments.  Leaves [B][k] hits in s->d_hits.
+// One pass: <= pass_queries() queries over <= kMaxSeg segments.  Leaves [B][k] hits in s->d_hits.
 void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel) {
     hipStream_t st = s->ctx->stream;
     ensure_workspace(s);
