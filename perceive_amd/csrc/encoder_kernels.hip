@@ -32,6 +32,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
 
+// Output tile of a workgroup.  Workgroups are dealt round-robin over the 8 XCDs, each with its own
+// L2: with the natural order the N/128 workgroups that share an A row-panel land on different XCDs
+// and every one of them pulls the panel from HBM again (3-8x the activation traffic; the
+// split-precision kernel was bound by exactly that).  The remap gives each XCD a contiguous run of
+// tiles in row-major order, so a row panel is fetched once per XCD and reused from its L2.
+__device__ __forceinline__ void tile_of_block(int ncols, int& tile_m, int& tile_n) {
+    const unsigned nwg = gridDim.x, wg = blockIdx.x;
+    unsigned logical = wg;
+    if ((nwg & 7u) == 0) logical = (wg & 7u) * (nwg >> 3) + (wg >> 3);
+    tile_m = (int)(logical / (unsigned)ncols);
+    tile_n = (int)(logical % (unsigned)ncols);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                        const float* __restrict__ bias,
@@ -42,7 +55,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kk = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int tile_m, tile_n;
+    tile_of_block(N / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // staging: thread t moves float4 (row = (t>>3) + 32*u, 16-byte column c4 = t&7), u = 0..3
     const int srow = tid >> 3, c4 = tid & 7;
@@ -225,7 +240,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int tile_m, tile_n;
+    tile_of_block(N / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // Staging maps.  LDS rows are 80 bytes; a group of lanes that one ds_write services together must
     // touch rows r and r+4 (80*4 = 64 mod 128) to cover all 32 banks exactly once.
@@ -682,7 +699,7 @@ void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float
             launch_skinny<4, 4>(st, A, W, bias, resid, C, M, N, K, epilogue);
         return;
     }
-    dim3 grid(N / BN, (M + BM - 1) / BM);
+    dim3 grid((N / BN) * ((M + BM - 1) / BM));
     switch (epilogue) {
         case EPI_BIAS_GELU: gemm_f32_kernel<EPI_BIAS_GELU><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K); break;
         case EPI_BIAS_RESIDUAL:
@@ -695,7 +712,7 @@ void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float
 void launch_gemm_bf16x3(hipStream_t st, const float* A, const uint16_t* Wh, const uint16_t* Wm, const uint16_t* Wl,
                         const float* bias, const float* resid, float* C, int M, int N, int K, int epilogue) {
     if (M <= 0) return;
-    dim3 grid(N / BN, (M + BM - 1) / BM);
+    dim3 grid((N / BN) * ((M + BM - 1) / BM));
     switch (epilogue) {
         case EPI_BIAS_GELU:
             gemm_bf16x3_kernel<EPI_BIAS_GELU><<<grid, 256, 0, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K);
