@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--kernel", default="auto", choices=["auto", "wave", "mfma"])
     ap.add_argument("--cpu-rows", type=int, default=int(os.environ.get("PCV_BENCH_CPU_ROWS", 1_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective", default=os.environ.get("PCV_BENCH_COLLECTIVE", "torch"), choices=["torch", "native"],
+                    help="N>1 hit-list exchange: torch.distributed's RCCL group, or the library's own RCCL communicator")
     ap.add_argument("--normalized", action="store_true", help="store unit-norm rows (MiniLM-like)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = --rows is the whole corpus, sharded (BASELINE configs[3]); weak = --rows per GPU")
@@ -129,7 +131,10 @@ def main():
 
     B, k = args.batch, args.k
     if use_dist:
-        sharded = pa.ShardedSearcher(dist, "cosine", args.dim, searcher=searcher, ctx=ctx, device=True)
+        # exchange of the [B][k] hit lists: torch.distributed's RCCL group (default), or the library's own
+        # persistent RCCL communicator (pcv_comm_*; torch then only bootstraps the id and times the job)
+        comm = pa.NativeComm.from_dist(ctx, dist) if args.collective == "native" else None
+        sharded = pa.ShardedSearcher(dist, "cosine", args.dim, searcher=searcher, ctx=ctx, device=True, comm=comm)
 
     def barrier():
         if use_dist:
@@ -201,6 +206,7 @@ def main():
                 "rows": total_rows, "dim": args.dim, "batch": B, "k": k,
                 "kernel": {1: "wave", 2: "mfma"}[searcher.last_stats()["kernel_used"]],
                 "rows_normalized": bool(args.normalized),
+                "collective": (args.collective if use_dist else None),
             },
             "queries_per_s": B * args.steps / elapsed,
             "roofline": {

@@ -164,6 +164,21 @@ pcv_status pcv_merge_topk(pcv_ctx* ctx, int metric, int dim, const void* d_lists
 pcv_status pcv_merge_topk_host(int metric, int dim, const pcv_hit* lists, int n_shards, int n_queries, int k,
                                int64_t* out_ids, float* out_scores, int* out_counts);
 
+/* ---- native RCCL exchange (no PyTorch in the data path) ----------------------------------------
+ * One communicator per process/GPU.  RCCL (librccl.so.1) is loaded on first use; PCV_ERR_UNSUPPORTED if
+ * it is not installed.  Bootstrap: rank 0 calls pcv_comm_unique_id and hands the 128 bytes to every rank
+ * by whatever channel the host has (torchrun's store, MPI, a file); all ranks then call pcv_comm_create. */
+typedef struct pcv_comm pcv_comm;
+pcv_status pcv_comm_unique_id(uint8_t out_id[128]);
+pcv_status pcv_comm_create(pcv_ctx* ctx, int world_size, int rank, const uint8_t id[128], pcv_comm** out);
+pcv_status pcv_comm_destroy(pcv_comm* c);
+/* Sharded Searcher::search_vector: local exact top-k on this rank's shard, ncclAllGather of the
+ * [n_queries][k] pcv_hit lists over xGMI (on the context stream), merge on every rank.  Collective: every
+ * rank of the communicator must call it with the same queries / k.  Outputs as pcv_searcher_search. */
+pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float* queries, int n_queries,
+                                       const int64_t* source_ids, int n_sources, int k, int64_t* out_ids,
+                                       float* out_scores, int* out_counts);
+
 /* Brute-force similarity matrices of lib.rs:63-77 for small inputs (tests, highlight.rs:109):
  *   out[b][n] = dot(a_b, m_n)                       pcv_dot_product            (lib.rs:63-65)
  *   out[b][n] = cos(a_b, m_n)                       pcv_cosine_similarity      (lib.rs:67-77)

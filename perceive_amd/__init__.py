@@ -14,7 +14,7 @@ from .search import (  # noqa: F401
     merge_topk,
     serialize_embedding,
 )
-from .sharded import HIT_DTYPE, ShardedSearcher, merge_topk_host, shard_bounds  # noqa: F401,E402
+from .sharded import HIT_DTYPE, NativeComm, ShardedSearcher, merge_topk_host, shard_bounds  # noqa: F401,E402
 from .model import (  # noqa: F401,E402
     Model,
     ModelError,

@@ -101,6 +101,10 @@ SYMBOLS = {
     "pcv_searcher_search_device": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _P, C.c_int]),
     "pcv_merge_topk": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
     "pcv_merge_topk_host": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
+    "pcv_comm_unique_id": (C.c_int, [_U8P]),
+    "pcv_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _U8P, C.POINTER(_P)]),
+    "pcv_comm_destroy": (C.c_int, [_P]),
+    "pcv_searcher_search_sharded": (C.c_int, [_P, _P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
     "pcv_dot_product": (C.c_int, [_P, _F32P, C.c_int, _F32P, C.c_int64, C.c_int, _F32P]),
     "pcv_cosine_similarity": (C.c_int, [_P, _F32P, C.c_int, _F32P, C.c_int64, C.c_int, _F32P]),
     "pcv_searcher_last_stats": (C.c_int, [_P, C.POINTER(ScanStats)]),

@@ -2,10 +2,13 @@
 //
 // A searcher owns, per source, a list of device-resident corpus segments in the blocked HBM layout
 // (scan.h).  Searching streams the selected segments once; see scan_kernels.hip for the pipeline.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -765,6 +768,133 @@ pcv_status pcv_merge_topk_host(int metric, int dim, const pcv_hit* lists, int n_
             for (int j = 0; j < k && j < (int)m.size(); ++j) out[(size_t)q * k + j] = m[j];  // search.rs:180
         }
         hits_to_outputs(metric, dim, out.data(), n_queries, k, out_ids, out_scores, out_counts);
+    });
+}
+
+// ---- native RCCL exchange ------------------------------------------------------------------------
+extern "C++" {
+struct NcclId {  // ncclUniqueId of rccl.h: 128 opaque bytes, passed by value
+    char internal[128];
+};
+namespace {
+// the handful of RCCL entry points used, resolved from librccl.so.1 at first use (rccl.h signatures)
+struct Rccl {
+    int (*GetUniqueId)(void* id) = nullptr;
+    int (*CommInitRank)(void** comm, int nranks, NcclId id, int rank) = nullptr;
+    int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t st) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            r.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+            r.CommInitRank = (int (*)(void**, int, NcclId, int))dlsym(h, "ncclCommInitRank");
+            r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+            r.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+            r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+            r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
+        }
+    }
+    return r;
+}
+void rccl_check(int rc, const char* what) {
+    if (rc != 0) {
+        Rccl& r = rccl();
+        PCV_FAIL(PCV_ERR_DEVICE, "%s failed: %s", what, r.GetErrorString ? r.GetErrorString(rc) : "RCCL error");
+    }
+}
+}  // namespace
+
+struct pcv_comm {
+    pcv_ctx* ctx = nullptr;
+    void* comm = nullptr;
+    int world = 1, rank = 0;
+    DevBuf<pcv_hit_dev> d_local, d_gathered, d_merged;
+    pcv_hit_dev* pin_hits = nullptr;
+    size_t pin_cap = 0;
+};
+}  // extern "C++"
+
+pcv_status pcv_comm_unique_id(uint8_t out_id[128]) {
+    return guarded([&] {
+        PCV_REQUIRE(out_id != nullptr, "comm_unique_id: NULL argument");
+        if (!rccl().ok) PCV_FAIL(PCV_ERR_UNSUPPORTED, "RCCL (librccl.so.1) is not available: %s", dlerror() ? dlerror() : "");
+        NcclId id;
+        rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(out_id, id.internal, 128);
+    });
+}
+
+pcv_status pcv_comm_create(pcv_ctx* ctx, int world_size, int rank, const uint8_t id_bytes[128], pcv_comm** out) {
+    return guarded([&] {
+        PCV_REQUIRE(ctx != nullptr && id_bytes != nullptr && out != nullptr, "comm_create: NULL argument");
+        *out = nullptr;
+        PCV_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "comm_create: rank %d / world %d", rank, world_size);
+        if (!rccl().ok) PCV_FAIL(PCV_ERR_UNSUPPORTED, "RCCL (librccl.so.1) is not available");
+        PCV_HIP(hipSetDevice(ctx->device));
+        auto c = std::make_unique<pcv_comm>();
+        c->ctx = ctx;
+        c->world = world_size;
+        c->rank = rank;
+        NcclId id;
+        std::memcpy(id.internal, id_bytes, 128);
+        rccl_check(rccl().CommInitRank(&c->comm, world_size, id, rank), "ncclCommInitRank");
+        *out = c.release();
+    });
+}
+
+pcv_status pcv_comm_destroy(pcv_comm* c) {
+    return guarded([&] {
+        if (!c) return;
+        hipSetDevice(c->ctx->device);
+        hipStreamSynchronize(c->ctx->stream);
+        if (c->comm) rccl().CommDestroy(c->comm);
+        c->d_local.release();
+        c->d_gathered.release();
+        c->d_merged.release();
+        if (c->pin_hits) hipHostFree(c->pin_hits);
+        delete c;
+    });
+}
+
+pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float* queries, int n_queries,
+                                       const int64_t* source_ids, int n_sources, int k, int64_t* out_ids,
+                                       float* out_scores, int* out_counts) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && c != nullptr, "search_sharded: NULL argument");
+        PCV_REQUIRE(s->ctx == c->ctx, "search_sharded: searcher and communicator live on different contexts");
+        PCV_REQUIRE(queries != nullptr && n_queries > 0, "search_sharded: no queries");
+        PCV_REQUIRE(k > 0 && k <= kMaxK, "search_sharded: num_results %d outside [1,%d]", k, kMaxK);
+        const size_t n = (size_t)n_queries * k;
+        hipStream_t st = s->ctx->stream;
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        c->d_local.ensure(n);
+        c->d_gathered.ensure(n * c->world);
+        c->d_merged.ensure(n);
+        if (c->pin_cap < n) {
+            if (c->pin_hits) hipHostFree(c->pin_hits);
+            c->pin_hits = nullptr;
+            PCV_HIP(hipHostMalloc((void**)&c->pin_hits, n * sizeof(pcv_hit_dev), hipHostMallocDefault));
+            c->pin_cap = n;
+        }
+        // local exact top-k (device resident, returns with the stream drained)
+        pcv_status st_local = pcv_searcher_search_device(s, queries, n_queries, source_ids, n_sources, k, c->d_local.p, 0);
+        if (st_local != PCV_OK) throw Error{st_local};
+        // exchange + merge + download, all queued on the context stream
+        rccl_check(rccl().AllGather(c->d_local.p, c->d_gathered.p, n * sizeof(pcv_hit_dev), /*ncclInt8*/ 0, c->comm, st),
+                   "ncclAllGather");
+        launch_merge(st, c->d_gathered.p, c->world, n_queries, k, c->d_merged.p);
+        PCV_HIP(hipMemcpyAsync(c->pin_hits, c->d_merged.p, n * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
+        PCV_HIP(hipStreamSynchronize(st));
+        PCV_HIP(hipGetLastError());
+        hits_to_outputs(s->metric, s->D, c->pin_hits, n_queries, k, out_ids, out_scores, out_counts);
     });
 }
 

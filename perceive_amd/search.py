@@ -169,6 +169,26 @@ class Searcher:
             )
         )
 
+    def search_sharded(self, comm, sources, num_results, vectors):
+        """Collective exact top-k over every rank's shard (pcv_searcher_search_sharded): local pass,
+        RCCL all-gather of the hit lists, merge.  Returns (ids[B,k], scores[B,k], counts[B])."""
+        q = np.ascontiguousarray(vectors, dtype=np.float32)
+        B, k = q.shape[0], int(num_results)
+        src, nsrc = None, 0
+        if sources is not None:
+            sa = np.ascontiguousarray(list(sources), dtype=np.int64)
+            src, nsrc = _ffi.i64p(sa), sa.size
+        ids = np.full((B, k), -1, dtype=np.int64)
+        scores = np.full((B, k), np.nan, dtype=np.float32)
+        counts = np.zeros(B, dtype=np.int32)
+        _ffi.check(
+            _ffi.lib().pcv_searcher_search_sharded(
+                self._handle, comm._handle, _ffi.f32p(q), B, src, nsrc, k, _ffi.i64p(ids), _ffi.f32p(scores),
+                counts.ctypes.data_as(C.POINTER(C.c_int)),
+            )
+        )
+        return ids, scores, counts
+
     # ---- introspection ------------------------------------------------------------------------
     def set_kernel(self, kernel="auto"):
         _ffi.check(_ffi.lib().pcv_searcher_set_kernel(self._handle, _KERNELS[kernel]))

@@ -38,20 +38,60 @@ def merge_topk_host(metric, dim, lists, n_shards, n_queries, k):
     return ids, scores, counts
 
 
+class NativeComm:
+    """A persistent RCCL communicator owned by libperceive_hip.so (pcv_comm_*): the exchange then runs
+    on the library's own stream with no PyTorch in the data path.  `unique_id` is the 128-byte id rank 0
+    obtained from `NativeComm.unique_id()` and handed to every rank (see `NativeComm.from_dist`)."""
+
+    def __init__(self, ctx, world, rank, unique_id):
+        idb = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().pcv_comm_create(ctx.handle, int(world), int(rank), idb, C.byref(h)))
+        self._handle, self.ctx, self.world, self.rank = h, ctx, int(world), int(rank)
+
+    @staticmethod
+    def unique_id():
+        idb = (C.c_uint8 * 128)()
+        _ffi.check(_ffi.lib().pcv_comm_unique_id(idb))
+        return bytes(idb)
+
+    @classmethod
+    def from_dist(cls, ctx, dist):
+        """Bootstrap over an initialised torch.distributed group (any backend): rank 0's id is
+        broadcast as a Python object; torch is used for nothing else."""
+        box = [cls.unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(ctx, dist.get_world_size(), dist.get_rank(), box[0])
+
+    def close(self):
+        if self._handle:
+            _ffi.check(_ffi.lib().pcv_comm_destroy(self._handle))
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedSearcher:
     """Wraps this rank's local Searcher.  `dist` is an initialised torch.distributed module.
 
     device=True : hit lists stay in HBM (torch CUDA byte tensors as the exchange buffers), RCCL
                   all-gather, device merge kernel.
+    comm=NativeComm: the same exchange done by the library itself (ncclAllGather on its stream + merge
+                  kernel, pcv_searcher_search_sharded); `dist` may then be None.
     device=False: lists are gathered on the host (gloo) and merged by pcv_merge_topk_host;
                   `local_search` may then be any callable (queries, k) -> [B,k] HIT_DTYPE array,
                   which is how the CPU tests drive the protocol without a GPU.
     """
 
-    def __init__(self, dist, metric, dim, searcher=None, ctx=None, device=True, local_search=None):
+    def __init__(self, dist, metric, dim, searcher=None, ctx=None, device=True, local_search=None, comm=None):
         self.dist = dist
-        self.world = dist.get_world_size()
-        self.rank = dist.get_rank()
+        self.comm = comm  # NativeComm: exchange inside the library (pcv_searcher_search_sharded)
+        self.world = comm.world if comm is not None else dist.get_world_size()
+        self.rank = comm.rank if comm is not None else dist.get_rank()
         self.metric, self.dim = metric, int(dim)
         self.searcher, self.ctx = searcher, ctx
         self.device = device
@@ -71,10 +111,12 @@ class ShardedSearcher:
         return self._bufs[key]
 
     def search_vectors(self, sources, num_results, vectors):
-        import torch
-
         q = np.ascontiguousarray(vectors, dtype=np.float32)
         B, k = q.shape[0], int(num_results)
+        if self.comm is not None:
+            return self.searcher.search_sharded(self.comm, sources, k, q)
+        import torch  # only the torch.distributed exchange needs it (and it must then be imported first)
+
         local, gathered = self._buffers(B, k)
         if self.device:
             self.searcher.search_device(sources, k, q, local.data_ptr())  # returns after its stream drained

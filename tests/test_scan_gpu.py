@@ -315,6 +315,33 @@ def test_sharded_search_and_merge(ctx, oracle):
         s.close()
 
 
+def test_native_rccl_exchange_single_rank(ctx, oracle):
+    # pcv_comm_* + pcv_searcher_search_sharded at world=1 (the box has one GPU): RCCL is loaded by the
+    # library, the all-gather runs on its stream, and the result equals the plain search and the oracle
+    N, B, k = 40_000, 5, 10
+    ref = oracle.synth_rows(91, 0, N, 384)
+    q = oracle.synth_rows(92, 0, B, 384)
+    s = pa.Searcher(ctx, 384, "cosine")
+    s.add_synthetic(1, N, 91)
+    s.finalize()
+    comm = pa.NativeComm(ctx, 1, 0, pa.NativeComm.unique_id())
+    for _ in range(2):  # second call reuses the communicator's buffers
+        ids, scores, counts = s.search_sharded(comm, None, k, q)
+    opos, osc, _ = oracle.topk(q, ref, k)
+    np.testing.assert_array_equal(ids, opos)
+    np.testing.assert_allclose(scores, osc.astype(np.float32), atol=1e-7)
+    assert (counts == k).all()
+    ids2, scores2, _ = s.search_vectors(None, k, q)
+    np.testing.assert_array_equal(ids, ids2)
+    np.testing.assert_array_equal(scores, scores2)
+    sh = pa.ShardedSearcher(None, "cosine", 384, searcher=s, ctx=ctx, comm=comm)
+    np.testing.assert_array_equal(sh.search_vectors(None, k, q)[0], opos)
+    with pytest.raises(pa.PcvError):
+        pa.NativeComm(ctx, 2, 2, bytes(128))  # rank outside the world: refused before RCCL is touched
+    comm.close()
+    s.close()
+
+
 def test_error_paths(ctx):
     s = pa.Searcher(ctx, 16, "cosine")
     s.add_rows(1, np.ones((4, 16), np.float32))
