@@ -232,6 +232,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
 
+    if use_dist and comm is not None:
+        comm.close()
     searcher.close()
     ctx.close()
     if use_dist:

@@ -9,6 +9,7 @@
 // throws perceive::Error carrying pcv_last_error().
 #pragma once
 #include <cstdint>
+#include <array>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -75,6 +76,28 @@ struct EmbeddingRow {
 
 enum class Metric { Cosine = PCV_METRIC_COSINE, Dot = PCV_METRIC_DOT };
 
+// A persistent RCCL communicator for the row-sharded Searcher (one process per GPU).  Rank 0 makes the
+// id and the host ships its 128 bytes to every rank by its own means; no reference counterpart (the
+// reference is one process), it is the multi-GPU form of search.rs:163-181.
+class Comm {
+public:
+    static std::array<uint8_t, 128> unique_id() {
+        std::array<uint8_t, 128> id{};
+        check(pcv_comm_unique_id(id.data()));
+        return id;
+    }
+    Comm(Context& ctx, int world_size, int rank, const std::array<uint8_t, 128>& id) {
+        check(pcv_comm_create(ctx.handle(), world_size, rank, id.data(), &h_));
+    }
+    ~Comm() { pcv_comm_destroy(h_); }  // before its Context
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    pcv_comm* handle() const { return h_; }
+
+private:
+    pcv_comm* h_ = nullptr;
+};
+
 // search.rs:29-260.  Metric::Dot reproduces the reference Searcher's scores exactly
 // (max(0, 1 - dot/len), ascending); Metric::Cosine is lib.rs:67-77.
 class Searcher {
@@ -113,6 +136,21 @@ public:
         int count = 0;
         check(pcv_searcher_search(h_, vector.data(), 1, sources.data(), (int)sources.size(), (int)num_results,
                                   ids.data(), scores.data(), &count));
+        std::vector<SearchItem> out;
+        for (int i = 0; i < count; ++i) out.push_back({ids[i], scores[i]});
+        return out;
+    }
+    // search_vector over every rank's shard: a collective, same arguments on all ranks; this rank's rows
+    // start at global position `set_shard_offset`
+    void set_shard_offset(int64_t first_global_pos) { check(pcv_searcher_set_shard_offset(h_, first_global_pos)); }
+    std::vector<SearchItem> search_vector_sharded(Comm& comm, const std::vector<int64_t>& sources, size_t num_results,
+                                                  const std::vector<float>& vector) const {
+        if (sources.empty()) return {};
+        std::vector<int64_t> ids(num_results);
+        std::vector<float> scores(num_results);
+        int count = 0;
+        check(pcv_searcher_search_sharded(h_, comm.handle(), vector.data(), 1, sources.data(), (int)sources.size(),
+                                          (int)num_results, ids.data(), scores.data(), &count));
         std::vector<SearchItem> out;
         for (int i = 0; i < count; ++i) out.push_back({ids[i], scores[i]});
         return out;

@@ -65,6 +65,10 @@ pcv_status pcv_shutdown(pcv_ctx* ctx);
 pcv_status pcv_synchronize(pcv_ctx* ctx);
 /* The context's hipStream_t (as void*), for callers that order their own work against it. */
 void* pcv_stream(pcv_ctx* ctx);
+/* Queue all further work of this context on a caller-owned hipStream_t (e.g. the stream a host framework
+ * runs its collectives against), so that both are ordered without host synchronisation; NULL returns to
+ * the context's own stream.  Drains the stream in use before switching. */
+pcv_status pcv_set_stream(pcv_ctx* ctx, void* hip_stream);
 
 /* Plain device buffers for hosts that have no HIP binding of their own (the per-shard hit lists that
  * an RCCL all-gather exchanges live in such buffers). */
@@ -152,11 +156,29 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
                                       const int64_t* source_ids, int n_sources, int k, void* d_out,
                                       int async);
 
+/* The same per-shard search split in two so that the exchange can be queued behind it without a host
+ * round trip.  `begin` queues the whole pass on the context stream and returns at once; `d_out` then
+ * holds n_queries*k hits followed by ONE extra pcv_hit whose `pos` is 1 if a candidate list of this
+ * pass overflowed (the results are then incomplete and the pass must be repeated), else 0.  `end` waits
+ * for the stream, books the statistics and, after an overflow, enlarges the lists for the repeat.
+ * No other call may use the searcher between the two.  PCV_ERR_UNSUPPORTED when the request needs more
+ * than one pass (use pcv_searcher_search_device then).  Typical step:
+ *   begin -> all-gather of (n*k+1)*24 bytes -> pcv_merge_topk_flagged -> end -> repeat if any_overflow. */
+pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* queries, int n_queries,
+                                            const int64_t* source_ids, int n_sources, int k, void* d_out);
+pcv_status pcv_searcher_search_device_end(pcv_searcher* s, int* out_overflowed);
+
 /* Cross-shard merge (replaces the rayon flat_map + sort + truncate of search.rs:163-181):
  * `d_lists` is a DEVICE pointer to [n_shards][n_queries][k] pcv_hit (the all-gather result),
  * written to host arrays shaped like pcv_searcher_search's outputs. */
 pcv_status pcv_merge_topk(pcv_ctx* ctx, int metric, int dim, const void* d_lists, int n_shards, int n_queries,
                           int k, int64_t* out_ids, float* out_scores, int* out_counts);
+
+/* pcv_merge_topk for lists produced by pcv_searcher_search_device_begin: shards are n_queries*k+1
+ * records apart; *out_any_overflow = OR of the shards' overflow records (identical on every rank). */
+pcv_status pcv_merge_topk_flagged(pcv_ctx* ctx, int metric, int dim, const void* d_lists, int n_shards,
+                                  int n_queries, int k, int64_t* out_ids, float* out_scores, int* out_counts,
+                                  int* out_any_overflow);
 
 /* The same merge on host memory (`lists` = host pointer, same shape): the reference's own merge is
  * host code (search.rs:179-180 sort + truncate); used when the lists were gathered on the host and

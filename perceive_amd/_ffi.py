@@ -78,6 +78,7 @@ SYMBOLS = {
     "pcv_shutdown": (C.c_int, [_P]),
     "pcv_synchronize": (C.c_int, [_P]),
     "pcv_stream": (_P, [_P]),
+    "pcv_set_stream": (C.c_int, [_P, _P]),
     "pcv_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "pcv_device_free": (C.c_int, [_P, _P]),
     "pcv_copy_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -99,6 +100,9 @@ SYMBOLS = {
     "pcv_searcher_search": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
     "pcv_searcher_set_shard_offset": (C.c_int, [_P, C.c_int64]),
     "pcv_searcher_search_device": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _P, C.c_int]),
+    "pcv_searcher_search_device_begin": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _P]),
+    "pcv_searcher_search_device_end": (C.c_int, [_P, _INTP]),
+    "pcv_merge_topk_flagged": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP, _INTP]),
     "pcv_merge_topk": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
     "pcv_merge_topk_host": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
     "pcv_comm_unique_id": (C.c_int, [_U8P]),

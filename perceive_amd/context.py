@@ -27,6 +27,11 @@ class Context:
     def stream(self):
         return _ffi.lib().pcv_stream(self.handle)
 
+    def set_stream(self, hip_stream):
+        """Queue all further work on a caller-owned hipStream_t (int / None = the context's own), e.g.
+        `torch.cuda.current_stream().cuda_stream` so that torch collectives order against it."""
+        _ffi.check(_ffi.lib().pcv_set_stream(self.handle, C.c_void_p(hip_stream or None)))
+
     def alloc(self, n_bytes):
         """Device buffer (returns the device pointer as int)."""
         p = C.c_void_p()

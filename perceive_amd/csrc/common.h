@@ -59,7 +59,12 @@ static inline pcv_status guarded(F&& f) {
 
 struct pcv_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // where every handle of this context queues its work
+    hipStream_t own_stream = nullptr;  // the stream pcv_init created (stream == own_stream unless adopted)
     hipDeviceProp_t props;
     int num_cus = 0;
+    // scratch of pcv_merge_topk*: device output + pinned host copy, grown on demand
+    void* merge_dev = nullptr;
+    void* merge_pin = nullptr;
+    size_t merge_cap = 0;
 };

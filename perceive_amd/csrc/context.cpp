@@ -49,7 +49,8 @@ pcv_status pcv_init(int device_index, pcv_ctx** out_ctx) {
         ctx->device = device_index;
         PCV_HIP(hipGetDeviceProperties(&ctx->props, device_index));
         ctx->num_cus = ctx->props.multiProcessorCount;
-        PCV_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        PCV_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+        ctx->stream = ctx->own_stream;
         *out_ctx = ctx;
     });
 }
@@ -58,10 +59,13 @@ pcv_status pcv_shutdown(pcv_ctx* ctx) {
     return guarded([&] {
         if (!ctx) return;
         hipSetDevice(ctx->device);
-        if (ctx->stream) {
-            hipStreamSynchronize(ctx->stream);
-            hipStreamDestroy(ctx->stream);
+        if (ctx->stream) hipStreamSynchronize(ctx->stream);
+        if (ctx->own_stream) {
+            hipStreamSynchronize(ctx->own_stream);
+            hipStreamDestroy(ctx->own_stream);
         }
+        if (ctx->merge_dev) hipFree(ctx->merge_dev);
+        if (ctx->merge_pin) hipHostFree(ctx->merge_pin);
         delete ctx;
     });
 }
@@ -75,6 +79,15 @@ pcv_status pcv_synchronize(pcv_ctx* ctx) {
 }
 
 void* pcv_stream(pcv_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+pcv_status pcv_set_stream(pcv_ctx* ctx, void* hip_stream) {
+    return guarded([&] {
+        PCV_REQUIRE(ctx != nullptr, "pcv_set_stream: ctx is NULL");
+        PCV_HIP(hipSetDevice(ctx->device));
+        PCV_HIP(hipStreamSynchronize(ctx->stream));  // nothing of ours is left behind on the old stream
+        ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    });
+}
 
 pcv_status pcv_device_alloc(pcv_ctx* ctx, size_t n_bytes, void** out_dptr) {
     return guarded([&] {

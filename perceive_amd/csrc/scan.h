@@ -101,7 +101,9 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
 int mfma_pass_queries(int Dp);  // queries one MFMA pass can take at this padded dim (LDS-limited), 0 = none
 void launch_rescore(hipStream_t st, const ScanParams& p, const ScanParams* dp);
 void launch_select(hipStream_t st, const ScanParams& p, const ScanParams* dp, pcv_hit_dev* out);
-void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out);
+void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out,
+                  int flagged = 0);
+void launch_overflow_flag(hipStream_t st, const uint32_t* cnt, int B, uint32_t cap, pcv_hit_dev* rec);
 void launch_similarity_matrix(hipStream_t st, const float* a, int B, const float* m, int64_t N, int D, int cosine,
                               float* out);
 

@@ -1041,12 +1041,37 @@ __global__ __launch_bounds__(256) void select_kernel(const ScanParams* __restric
     }
 }
 
-// merge of per-shard top-k lists after the all-gather: [n_shards][B][k] -> [B][k]
-__global__ __launch_bounds__(64) void merge_kernel(const pcv_hit_dev* __restrict__ lists, int n_shards, int B, int k,
-                                                   pcv_hit_dev* __restrict__ out) {
+// One record after a shard's [B][k] hits says whether any of its candidate lists overflowed (the
+// pass then has to be repeated with larger lists): pos = 1 | 0.  It travels with the hits through the
+// all-gather so that every rank takes the same decision without a second collective.
+__global__ __launch_bounds__(64) void overflow_flag_kernel(const uint32_t* __restrict__ cnt, int B, uint32_t cap,
+                                                           pcv_hit_dev* __restrict__ rec) {
+    bool over = false;
+    for (int q = threadIdx.x; q < B; q += 64) over |= cnt[q] > cap;
+    over = __any(over);
+    if (threadIdx.x == 0) {
+        rec->score = 0.0;
+        rec->pos = over ? 1 : 0;
+        rec->id = 0;
+    }
+}
+
+// merge of per-shard top-k lists after the all-gather: [n_shards][B][k] -> [B][k]; shards are `stride`
+// records apart (B*k, or B*k+1 with the overflow record, whose OR then lands in out[B*k])
+__global__ __launch_bounds__(64) void merge_kernel(const pcv_hit_dev* __restrict__ lists_all, int n_shards, int B, int k,
+                                                   size_t stride, int flagged, pcv_hit_dev* __restrict__ out) {
     extern __shared__ unsigned char taken[];  // [n_shards*k]
     const int q = blockIdx.x, lane = threadIdx.x;
     const int total = n_shards * k;
+    if (flagged && q == 0 && lane == 0) {
+        int64_t any = 0;
+        for (int sh = 0; sh < n_shards; ++sh) any |= lists_all[sh * stride + (size_t)B * k].pos;
+        pcv_hit_dev f;
+        f.score = 0.0;
+        f.pos = any ? 1 : 0;
+        f.id = 0;
+        out[(size_t)B * k] = f;
+    }
     for (int i = lane; i < total; i += 64) taken[i] = 0;
     __syncthreads();
     for (int j = 0; j < k; ++j) {
@@ -1055,7 +1080,7 @@ __global__ __launch_bounds__(64) void merge_kernel(const pcv_hit_dev* __restrict
         int bi = -1;
         for (int i = lane; i < total; i += 64) {
             if (taken[i]) continue;
-            const pcv_hit_dev& e = lists[((size_t)(i / k) * B + q) * k + (i % k)];
+            const pcv_hit_dev& e = lists_all[(size_t)(i / k) * stride + (size_t)q * k + (i % k)];
             if (e.pos < 0 || !(e.score == e.score)) continue;
             if (bi < 0 || better(e.score, e.pos, bs, bp)) {
                 bs = e.score;
@@ -1076,7 +1101,7 @@ __global__ __launch_bounds__(64) void merge_kernel(const pcv_hit_dev* __restrict
         if (lane == 0) {
             pcv_hit_dev hit;
             if (bi >= 0) {
-                hit = lists[((size_t)(bi / k) * B + q) * k + (bi % k)];
+                hit = lists_all[(size_t)(bi / k) * stride + (size_t)q * k + (bi % k)];
                 taken[bi] = 1;
             } else {
                 hit.score = __builtin_nan("");
@@ -1265,8 +1290,13 @@ void launch_select(hipStream_t st, const ScanParams& p, const ScanParams* dp, pc
     select_kernel<<<p.B, 256, 0, st>>>(dp, out);
 }
 
-void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out) {
-    merge_kernel<<<B, 64, (size_t)n_shards * k, st>>>(lists, n_shards, B, k, out);
+void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out, int flagged) {
+    const size_t stride = (size_t)B * k + (flagged ? 1 : 0);
+    merge_kernel<<<B, 64, (size_t)n_shards * k, st>>>(lists, n_shards, B, k, stride, flagged, out);
+}
+
+void launch_overflow_flag(hipStream_t st, const uint32_t* cnt, int B, uint32_t cap, pcv_hit_dev* rec) {
+    overflow_flag_kernel<<<1, 64, 0, st>>>(cnt, B, cap, rec);
 }
 
 void launch_similarity_matrix(hipStream_t st, const float* a, int B, const float* m, int64_t N, int D, int cosine,

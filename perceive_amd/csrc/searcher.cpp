@@ -102,6 +102,12 @@ struct pcv_searcher {
     uint32_t cand_cap = 8192;
     uint32_t scan_flags = 0;  // tuning knobs, PCV_SCAN_FLAGS
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // a pass queued by enqueue_pass and not yet collected by finish_pass
+    struct Pending {
+        bool active = false;
+        int B = 0;
+        int64_t rows = 0;
+    } pending;
 
     Source* find_source(int64_t id) {
         for (auto& s : sources)
@@ -264,105 +270,130 @@ void ensure_workspace(pcv_searcher* s) {
         if (!e) PCV_HIP(hipEventCreate(&e));
 }
 
-// One pass: <= pass_queries() queries over <= kMaxSeg segments.  Leaves [B][k] hits in s->d_hits.
-void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel) {
+// Queue one pass (<= pass_queries() queries over <= kMaxSeg segments) on the context stream without
+// waiting for it: H2D of the queries and parameters, prep, seed, scan, rescore, select into `d_out`
+// ([B][k] hits; nullptr = s->d_hits), the candidate counts' way back into pinned memory and, if
+// `download`, the hits' too.  `d_flag` != nullptr receives the overflow record (scan.h).
+void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel,
+                  pcv_hit_dev* d_out, bool download, pcv_hit_dev* d_flag) {
     hipStream_t st = s->ctx->stream;
     ensure_workspace(s);
-    std::memcpy(s->pin_queries, queries_host, (size_t)B * s->D * sizeof(float));
-    PCV_HIP(hipMemcpyAsync(s->d_queries.p, s->pin_queries, (size_t)B * s->D * sizeof(float), hipMemcpyHostToDevice, st));
+    if (queries_host) {  // nullptr: the queries of the previous attempt are still on the device
+        std::memcpy(s->pin_queries, queries_host, (size_t)B * s->D * sizeof(float));
+        PCV_HIP(hipMemcpyAsync(s->d_queries.p, s->pin_queries, (size_t)B * s->D * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    ScanParams& p = s->pin->params;
+    p = ScanParams{};
+    uint32_t blk0 = 0;
+    int64_t rows = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const Segment& g = *segs[i].g;
+        p.seg[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks, blk0, 0};
+        blk0 += g.nblocks;
+        rows += g.nrows;
+    }
+    p.nseg = nseg;
+    p.total_blocks = blk0;
+    p.D4 = s->D4;
+    p.B = B;
+    p.k = k;
+    p.metric = s->metric;
+    p.qf32 = s->d_qf32.p;
+    p.qbf16 = s->d_qbf16.p;
+    p.qraw = s->d_qraw.p;
+    p.qnorm2 = s->d_qnorm2.p;
+    p.margin = s->d_margin.p;
+    p.tau = s->d_tau.p;
+    p.slots = s->d_slots.p;
+    p.cand_cnt = s->d_cnt.p;
+    p.cand_cnt_out = s->d_cnt_out.p;
+    p.cand = s->d_cand.p;
+    p.cand_score = s->d_cand_score.p;
+    p.cand_s = s->d_cand_s.p;
+    p.seed_part = s->d_seed_part.p;
+    p.cand_cap = s->cand_cap;
+    p.flags = s->scan_flags;
+    const uint32_t seed_parts = ((s->scan_flags >> 16) & 0xff) ? ((s->scan_flags >> 16) & 0xff) : kSeedParts;  // tuning
+    p.seed_blocks =
+        nseg > 0 ? std::min<uint32_t>(std::min<uint32_t>(seed_parts, kSeedParts) * kSeedPartRows / kBlockRows, segs[0].g->nblocks) : 0;
 
+    // |s - c| bound of the screening score, relative to |q||x| (DESIGN.md §screening error)
+    const float eps_f32 = (float)(s->Dp + 16) * 1.2e-7f;
+    const float eps_rel = (kernel == PCV_KERNEL_MFMA) ? 0.0039101f + 2.0f * eps_f32 : eps_f32;
+
+    const ScanParams* dp = s->d_params.p;
+    pcv_hit_dev* out = d_out ? d_out : s->d_hits.p;
+    PCV_HIP(hipMemcpyAsync(s->d_params.p, &p, sizeof(ScanParams), hipMemcpyHostToDevice, st));
+    PCV_HIP(hipEventRecord(s->ev[0], st));
+    launch_prep_queries(st, s->d_queries.p, B, s->D, s->Dp, s->metric, eps_rel, s->max_norm, k, s->d_qf32.p,
+                        s->d_qbf16.p, s->d_qraw.p, s->d_qnorm2.p, s->d_margin.p, s->d_tau.p, s->d_slots.p,
+                        s->d_cnt.p);
+    launch_seed(st, p, dp);
+    PCV_HIP(hipEventRecord(s->ev[1], st));
+    if (kernel == PCV_KERNEL_MFMA)
+        launch_scan_mfma(st, p, dp, s->ctx->num_cus);
+    else
+        launch_scan_wave(st, p, dp, s->ctx->num_cus);
+    PCV_HIP(hipEventRecord(s->ev[2], st));
+    launch_rescore(st, p, dp);
+    launch_select(st, p, dp, out);
+    PCV_HIP(hipEventRecord(s->ev[3], st));
+    if (d_flag) launch_overflow_flag(st, s->d_cnt_out.p, B, s->cand_cap, d_flag);
+    PCV_HIP(hipMemcpyAsync(s->pin->cnt, s->d_cnt_out.p, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (download)
+        PCV_HIP(hipMemcpyAsync(s->pin->hits, out, (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
+    s->pending.active = true;
+    s->pending.B = B;
+    s->pending.rows = rows;
+}
+
+// Collect a queued pass: wait for the stream, book the statistics, and report whether a candidate list
+// overflowed — nothing was lost then but the stored prefix is incomplete, so the lists are grown to what
+// the pass needed and the caller repeats it (tau restarts, so the need can only be met or shrink on
+// data that is not adversarially ordered; bounded by the row count).
+bool finish_pass(pcv_searcher* s) {
+    PCV_REQUIRE(s->pending.active, "no pass is pending");
+    s->pending.active = false;
+    PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+    PCV_HIP(hipGetLastError());
+    const int B = s->pending.B;
+    const int64_t rows = s->pending.rows;
+    float ms_scan = 0, ms_total = 0;
+    hipEventElapsedTime(&ms_scan, s->ev[1], s->ev[2]);
+    hipEventElapsedTime(&ms_total, s->ev[0], s->ev[3]);
+    s->stats.scan_ms += ms_scan;
+    s->stats.total_ms += ms_total;
+    s->stats.scan_launches += 1;
+    s->stats.rows_scanned += rows;
+    s->stats.bytes_algorithmic += rows * (int64_t)s->D * 4;
+
+    const uint32_t* cnt = s->pin->cnt;
+    uint32_t mx = 0;
+    int64_t sum = 0;
+    for (int b = 0; b < B; ++b) {
+        mx = std::max(mx, cnt[b]);
+        sum += cnt[b];
+    }
+    if (mx <= s->cand_cap) {
+        s->stats.candidates += sum;
+        return false;
+    }
+    s->stats.overflow_reruns += 1;
+    uint64_t want = (uint64_t)mx + mx / 4 + 1024;
+    want = std::min<uint64_t>(want, (uint64_t)rows + 1024);
+    s->cand_cap = (uint32_t)std::max<uint64_t>(want, s->cand_cap * 2ull);
+    s->d_cand.ensure((size_t)kMfmaQueries * s->cand_cap);
+    s->d_cand_score.ensure((size_t)kMfmaQueries * s->cand_cap);
+    s->d_cand_s.ensure((size_t)kMfmaQueries * s->cand_cap);
+    return true;
+}
+
+// One pass, synchronously.  Leaves [B][k] hits in s->d_hits and in s->pin->hits.
+void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel) {
     for (int attempt = 0;; ++attempt) {
-        ScanParams& p = s->pin->params;
-        p = ScanParams{};
-        uint32_t blk0 = 0;
-        int64_t rows = 0;
-        for (int i = 0; i < nseg; ++i) {
-            const Segment& g = *segs[i].g;
-            p.seg[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks, blk0, 0};
-            blk0 += g.nblocks;
-            rows += g.nrows;
-        }
-        p.nseg = nseg;
-        p.total_blocks = blk0;
-        p.D4 = s->D4;
-        p.B = B;
-        p.k = k;
-        p.metric = s->metric;
-        p.qf32 = s->d_qf32.p;
-        p.qbf16 = s->d_qbf16.p;
-        p.qraw = s->d_qraw.p;
-        p.qnorm2 = s->d_qnorm2.p;
-        p.margin = s->d_margin.p;
-        p.tau = s->d_tau.p;
-        p.slots = s->d_slots.p;
-        p.cand_cnt = s->d_cnt.p;
-        p.cand_cnt_out = s->d_cnt_out.p;
-        p.cand = s->d_cand.p;
-        p.cand_score = s->d_cand_score.p;
-        p.cand_s = s->d_cand_s.p;
-        p.seed_part = s->d_seed_part.p;
-        p.cand_cap = s->cand_cap;
-        p.flags = s->scan_flags;
-        const uint32_t seed_parts = ((s->scan_flags >> 16) & 0xff) ? ((s->scan_flags >> 16) & 0xff) : kSeedParts;  // tuning
-        p.seed_blocks =
-            nseg > 0 ? std::min<uint32_t>(std::min<uint32_t>(seed_parts, kSeedParts) * kSeedPartRows / kBlockRows, segs[0].g->nblocks) : 0;
-
-        // |s - c| bound of the screening score, relative to |q||x| (DESIGN.md §screening error)
-        const float eps_f32 = (float)(s->Dp + 16) * 1.2e-7f;
-        const float eps_rel = (kernel == PCV_KERNEL_MFMA) ? 0.0039101f + 2.0f * eps_f32 : eps_f32;
-
-        const ScanParams* dp = s->d_params.p;
-        PCV_HIP(hipMemcpyAsync(s->d_params.p, &p, sizeof(ScanParams), hipMemcpyHostToDevice, st));
-        PCV_HIP(hipEventRecord(s->ev[0], st));
-        launch_prep_queries(st, s->d_queries.p, B, s->D, s->Dp, s->metric, eps_rel, s->max_norm, k, s->d_qf32.p,
-                            s->d_qbf16.p, s->d_qraw.p, s->d_qnorm2.p, s->d_margin.p, s->d_tau.p, s->d_slots.p,
-                            s->d_cnt.p);
-        launch_seed(st, p, dp);
-        PCV_HIP(hipEventRecord(s->ev[1], st));
-        if (kernel == PCV_KERNEL_MFMA)
-            launch_scan_mfma(st, p, dp, s->ctx->num_cus);
-        else
-            launch_scan_wave(st, p, dp, s->ctx->num_cus);
-        PCV_HIP(hipEventRecord(s->ev[2], st));
-        launch_rescore(st, p, dp);
-        launch_select(st, p, dp, s->d_hits.p);
-        PCV_HIP(hipEventRecord(s->ev[3], st));
-        uint32_t* cnt = s->pin->cnt;
-        PCV_HIP(hipMemcpyAsync(cnt, s->d_cnt_out.p, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        PCV_HIP(hipMemcpyAsync(s->pin->hits, s->d_hits.p, (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
-        PCV_HIP(hipStreamSynchronize(st));
-        PCV_HIP(hipGetLastError());
-
-        float ms_scan = 0, ms_total = 0;
-        hipEventElapsedTime(&ms_scan, s->ev[1], s->ev[2]);
-        hipEventElapsedTime(&ms_total, s->ev[0], s->ev[3]);
-        s->stats.scan_ms += ms_scan;
-        s->stats.total_ms += ms_total;
-        s->stats.scan_launches += 1;
-        s->stats.rows_scanned += rows;
-        s->stats.bytes_algorithmic += rows * (int64_t)s->D * 4;
-
-        uint32_t mx = 0;
-        int64_t sum = 0;
-        for (int b = 0; b < B; ++b) {
-            mx = std::max(mx, cnt[b]);
-            sum += cnt[b];
-        }
-        if (mx <= s->cand_cap) {
-            s->stats.candidates += sum;
-            return;
-        }
-        // a candidate list overflowed: nothing was lost but the stored prefix is incomplete.
-        // Grow the lists to what this pass needed and repeat it (tau restarts, so the need can
-        // only be met or shrink on data that is not adversarially ordered; bounded by the row count).
-        PCV_REQUIRE(attempt < 6, "candidate lists still overflow after %d reruns (need %u)", attempt, mx);
-        s->stats.overflow_reruns += 1;
-        uint64_t want = (uint64_t)mx + mx / 4 + 1024;
-        want = std::min<uint64_t>(want, (uint64_t)rows + 1024);
-        s->cand_cap = (uint32_t)std::max<uint64_t>(want, s->cand_cap * 2ull);
-        s->d_cand.ensure((size_t)kMfmaQueries * s->cand_cap);
-        s->d_cand_score.ensure((size_t)kMfmaQueries * s->cand_cap);
-        s->d_cand_s.ensure((size_t)kMfmaQueries * s->cand_cap);
+        enqueue_pass(s, attempt == 0 ? queries_host : nullptr, B, segs, nseg, k, kernel, nullptr, true, nullptr);
+        if (!finish_pass(s)) return;
+        PCV_REQUIRE(attempt < 6, "candidate lists still overflow after %d reruns", attempt + 1);
     }
 }
 
@@ -724,27 +755,85 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
     });
 }
 
+pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* queries, int n_queries,
+                                            const int64_t* source_ids, int n_sources, int k, void* d_out) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && d_out != nullptr, "search_device_begin: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->dirty, "search_device_begin: rows were added or cleared without pcv_searcher_finalize");
+        PCV_REQUIRE(!s->pending.active, "search_device_begin: the previous pass was not collected (search_device_end)");
+        PCV_REQUIRE(queries != nullptr && n_queries > 0, "search_device_begin: no queries");
+        PCV_REQUIRE(k > 0 && k <= kMaxK, "search_device_begin: num_results %d outside [1,%d]", k, kMaxK);
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
+        const int kernel = pick_kernel(s, n_queries);
+        if (segs.empty() || segs.size() > (size_t)kMaxSeg || n_queries > pass_queries(s, kernel))
+            PCV_FAIL(PCV_ERR_UNSUPPORTED, "search_device_begin: %d queries over %zu segments need more than one pass",
+                     n_queries, segs.size());
+        s->stats = pcv_scan_stats{};
+        s->stats.kernel_used = kernel;
+        pcv_hit_dev* out = (pcv_hit_dev*)d_out;
+        enqueue_pass(s, queries, n_queries, segs.data(), (int)segs.size(), k, kernel, out, false, out + (size_t)n_queries * k);
+    });
+}
+
+pcv_status pcv_searcher_search_device_end(pcv_searcher* s, int* out_overflowed) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "search_device_end: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        const bool over = finish_pass(s);
+        if (out_overflowed) *out_overflowed = over ? 1 : 0;
+    });
+}
+
+namespace {
+// merge scratch of a context: device output and its pinned host copy for `n` records
+void ensure_merge_scratch(pcv_ctx* ctx, size_t n) {
+    if (ctx->merge_cap >= n) return;
+    PCV_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->merge_dev) hipFree(ctx->merge_dev);
+    if (ctx->merge_pin) hipHostFree(ctx->merge_pin);
+    ctx->merge_dev = ctx->merge_pin = nullptr;
+    ctx->merge_cap = 0;
+    PCV_HIP(hipMalloc(&ctx->merge_dev, n * sizeof(pcv_hit_dev)));
+    PCV_HIP(hipHostMalloc(&ctx->merge_pin, n * sizeof(pcv_hit_dev), hipHostMallocDefault));
+    ctx->merge_cap = n;
+}
+
+void merge_lists(pcv_ctx* ctx, int metric, int dim, const void* d_lists, int n_shards, int n_queries, int k,
+                 int64_t* out_ids, float* out_scores, int* out_counts, int* out_any_overflow) {
+    PCV_REQUIRE(ctx != nullptr && d_lists != nullptr, "merge_topk: NULL argument");
+    PCV_REQUIRE(n_shards > 0 && n_queries > 0 && k > 0 && k <= kMaxK, "merge_topk: bad shape");
+    PCV_HIP(hipSetDevice(ctx->device));
+    const int flagged = out_any_overflow != nullptr;
+    const size_t n = (size_t)n_queries * k;
+    ensure_merge_scratch(ctx, n + 1);
+    pcv_hit_dev* d_out = (pcv_hit_dev*)ctx->merge_dev;
+    pcv_hit_dev* h_out = (pcv_hit_dev*)ctx->merge_pin;
+    launch_merge(ctx->stream, (const pcv_hit_dev*)d_lists, n_shards, n_queries, k, d_out, flagged);
+    PCV_HIP(hipMemcpyAsync(h_out, d_out, (n + flagged) * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, ctx->stream));
+    PCV_HIP(hipStreamSynchronize(ctx->stream));
+    PCV_HIP(hipGetLastError());
+    if (flagged) *out_any_overflow = h_out[n].pos != 0;
+    hits_to_outputs(metric, dim, h_out, n_queries, k, out_ids, out_scores, out_counts);
+}
+}  // namespace
+
 pcv_status pcv_merge_topk(pcv_ctx* ctx, int metric, int dim, const void* d_lists, int n_shards, int n_queries,
                           int k, int64_t* out_ids, float* out_scores, int* out_counts) {
     return guarded([&] {
-        PCV_REQUIRE(ctx != nullptr && d_lists != nullptr, "merge_topk: NULL argument");
-        PCV_REQUIRE(n_shards > 0 && n_queries > 0 && k > 0 && k <= kMaxK, "merge_topk: bad shape");
-        PCV_HIP(hipSetDevice(ctx->device));
-        DevBuf<pcv_hit_dev> d_out;
-        std::vector<pcv_hit_dev> hits((size_t)n_queries * k);
-        try {
-            d_out.ensure(hits.size());
-            launch_merge(ctx->stream, (const pcv_hit_dev*)d_lists, n_shards, n_queries, k, d_out.p);
-            PCV_HIP(hipMemcpyAsync(hits.data(), d_out.p, hits.size() * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost,
-                                   ctx->stream));
-            PCV_HIP(hipStreamSynchronize(ctx->stream));
-            PCV_HIP(hipGetLastError());
-        } catch (...) {
-            d_out.release();
-            throw;
-        }
-        d_out.release();
-        hits_to_outputs(metric, dim, hits.data(), n_queries, k, out_ids, out_scores, out_counts);
+        merge_lists(ctx, metric, dim, d_lists, n_shards, n_queries, k, out_ids, out_scores, out_counts, nullptr);
+    });
+}
+
+pcv_status pcv_merge_topk_flagged(pcv_ctx* ctx, int metric, int dim, const void* d_lists, int n_shards,
+                                  int n_queries, int k, int64_t* out_ids, float* out_scores, int* out_counts,
+                                  int* out_any_overflow) {
+    return guarded([&] {
+        PCV_REQUIRE(out_any_overflow != nullptr, "merge_topk_flagged: NULL argument");
+        merge_lists(ctx, metric, dim, d_lists, n_shards, n_queries, k, out_ids, out_scores, out_counts,
+                    out_any_overflow);
     });
 }
 
@@ -791,8 +880,22 @@ Rccl& rccl() {
     static bool tried = false;
     if (!tried) {
         tried = true;
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        // RCCL must sit on the HIP runtime this library is bound to.  A process may hold a second
+        // runtime + RCCL pair (PyTorch bundles its own, with the same sonames), so RCCL is looked up by
+        // path next to our libamdhip64 first and by soname only after that.
+        void* h = nullptr;
+        Dl_info info;
+        if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char* name : {"librccl.so.1", "librccl.so"})
+                    if (!h) h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+            }
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (h) {
             r.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
             r.CommInitRank = (int (*)(void**, int, NcclId, int))dlsym(h, "ncclCommInitRank");
@@ -875,23 +978,46 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
         const size_t n = (size_t)n_queries * k;
         hipStream_t st = s->ctx->stream;
         PCV_HIP(hipSetDevice(s->ctx->device));
-        c->d_local.ensure(n);
-        c->d_gathered.ensure(n * c->world);
-        c->d_merged.ensure(n);
-        if (c->pin_cap < n) {
+        c->d_local.ensure(n + 1);
+        c->d_gathered.ensure((n + 1) * c->world);
+        c->d_merged.ensure(n + 1);
+        if (c->pin_cap < n + 1) {
             if (c->pin_hits) hipHostFree(c->pin_hits);
             c->pin_hits = nullptr;
-            PCV_HIP(hipHostMalloc((void**)&c->pin_hits, n * sizeof(pcv_hit_dev), hipHostMallocDefault));
-            c->pin_cap = n;
+            c->pin_cap = 0;
+            PCV_HIP(hipHostMalloc((void**)&c->pin_hits, (n + 1) * sizeof(pcv_hit_dev), hipHostMallocDefault));
+            c->pin_cap = n + 1;
         }
-        // local exact top-k (device resident, returns with the stream drained)
-        pcv_status st_local = pcv_searcher_search_device(s, queries, n_queries, source_ids, n_sources, k, c->d_local.p, 0);
-        if (st_local != PCV_OK) throw Error{st_local};
-        // exchange + merge + download, all queued on the context stream
-        rccl_check(rccl().AllGather(c->d_local.p, c->d_gathered.p, n * sizeof(pcv_hit_dev), /*ncclInt8*/ 0, c->comm, st),
-                   "ncclAllGather");
-        launch_merge(st, c->d_gathered.p, c->world, n_queries, k, c->d_merged.p);
-        PCV_HIP(hipMemcpyAsync(c->pin_hits, c->d_merged.p, n * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
+        auto exchange = [&](int flagged) {  // all-gather + merge + download, queued behind the local pass
+            const size_t rec = n + flagged;
+            rccl_check(rccl().AllGather(c->d_local.p, c->d_gathered.p, rec * sizeof(pcv_hit_dev), /*ncclInt8*/ 0, c->comm, st),
+                       "ncclAllGather");
+            launch_merge(st, c->d_gathered.p, c->world, n_queries, k, c->d_merged.p, flagged);
+            PCV_HIP(hipMemcpyAsync(c->pin_hits, c->d_merged.p, rec * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
+        };
+        // One pass fits: everything is queued back to back and the host waits once.  Whether a list
+        // overflowed somewhere is part of the exchanged payload, so all ranks repeat (or not) together.
+        for (int attempt = 0;; ++attempt) {
+            pcv_status rc = pcv_searcher_search_device_begin(s, queries, n_queries, source_ids, n_sources, k, c->d_local.p);
+            if (rc == PCV_ERR_UNSUPPORTED && attempt == 0) break;  // several passes: the sequential form below
+            if (rc != PCV_OK) throw Error{rc};
+            try {
+                exchange(1);
+            } catch (...) {
+                pcv_searcher_search_device_end(s, nullptr);  // collect the queued pass before reporting
+                throw;
+            }
+            rc = pcv_searcher_search_device_end(s, nullptr);  // waits for the stream; grows this rank's lists if needed
+            if (rc != PCV_OK) throw Error{rc};
+            if (c->pin_hits[n].pos == 0) {
+                hits_to_outputs(s->metric, s->D, c->pin_hits, n_queries, k, out_ids, out_scores, out_counts);
+                return;
+            }
+            PCV_REQUIRE(attempt < 6, "search_sharded: candidate lists still overflow after %d reruns", attempt + 1);
+        }
+        pcv_status rc = pcv_searcher_search_device(s, queries, n_queries, source_ids, n_sources, k, c->d_local.p, 0);
+        if (rc != PCV_OK) throw Error{rc};
+        exchange(0);
         PCV_HIP(hipStreamSynchronize(st));
         PCV_HIP(hipGetLastError());
         hits_to_outputs(s->metric, s->D, c->pin_hits, n_queries, k, out_ids, out_scores, out_counts);

@@ -169,6 +169,26 @@ class Searcher:
             )
         )
 
+    def search_device_begin(self, sources, num_results, vectors, d_out):
+        """Queue the per-shard pass without waiting (pcv_searcher_search_device_begin): d_out receives
+        B*k hits + one overflow record.  Raises PcvError(status 3) if it needs more than one pass."""
+        q = np.ascontiguousarray(vectors, dtype=np.float32)
+        src, nsrc = None, 0
+        if sources is not None:
+            sa = np.ascontiguousarray(list(sources), dtype=np.int64)
+            src, nsrc = _ffi.i64p(sa), sa.size
+        _ffi.check(
+            _ffi.lib().pcv_searcher_search_device_begin(
+                self._handle, _ffi.f32p(q), q.shape[0], src, nsrc, int(num_results), C.c_void_p(d_out)
+            )
+        )
+
+    def search_device_end(self):
+        """Wait for the queued pass and book its statistics; True if a candidate list overflowed."""
+        over = C.c_int()
+        _ffi.check(_ffi.lib().pcv_searcher_search_device_end(self._handle, C.byref(over)))
+        return bool(over.value)
+
     def search_sharded(self, comm, sources, num_results, vectors):
         """Collective exact top-k over every rank's shard (pcv_searcher_search_sharded): local pass,
         RCCL all-gather of the hit lists, merge.  Returns (ids[B,k], scores[B,k], counts[B])."""
@@ -245,17 +265,22 @@ def encode_query(model, query):
     return np.asarray(model.encode([query]))[0]
 
 
-def merge_topk(ctx, metric, dim, d_lists, n_shards, n_queries, k):
-    """Cross-shard merge of all-gathered per-shard lists (device pointer) -> (ids, scores, counts)."""
+def merge_topk(ctx, metric, dim, d_lists, n_shards, n_queries, k, flagged=False):
+    """Cross-shard merge of all-gathered per-shard lists (device pointer) -> (ids, scores, counts);
+    flagged=True: lists made by search_device_begin (one overflow record per shard), returns
+    (ids, scores, counts, any_overflow)."""
     ids = np.full((n_queries, k), -1, dtype=np.int64)
     scores = np.full((n_queries, k), np.nan, dtype=np.float32)
     counts = np.zeros(n_queries, dtype=np.int32)
-    _ffi.check(
-        _ffi.lib().pcv_merge_topk(
-            ctx.handle, _METRICS[metric], int(dim), C.c_void_p(d_lists), int(n_shards), int(n_queries), int(k),
-            _ffi.i64p(ids), _ffi.f32p(scores), counts.ctypes.data_as(C.POINTER(C.c_int)),
-        )
+    args = (
+        ctx.handle, _METRICS[metric], int(dim), C.c_void_p(d_lists), int(n_shards), int(n_queries), int(k),
+        _ffi.i64p(ids), _ffi.f32p(scores), counts.ctypes.data_as(C.POINTER(C.c_int)),
     )
+    if flagged:
+        over = C.c_int()
+        _ffi.check(_ffi.lib().pcv_merge_topk_flagged(*args, C.byref(over)))
+        return ids, scores, counts, bool(over.value)
+    _ffi.check(_ffi.lib().pcv_merge_topk(*args))
     return ids, scores, counts
 
 

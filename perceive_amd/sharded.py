@@ -64,9 +64,11 @@ class NativeComm:
         return cls(ctx, dist.get_world_size(), dist.get_rank(), box[0])
 
     def close(self):
-        if self._handle:
-            _ffi.check(_ffi.lib().pcv_comm_destroy(self._handle))
-            self._handle = None
+        """Destroy the communicator.  It lives on the context's device and stream, so it has to go
+        first; if the context is already closed the handle is dropped, not destroyed."""
+        h, self._handle = getattr(self, "_handle", None), None
+        if h and self.ctx._h:
+            _ffi.check(_ffi.lib().pcv_comm_destroy(h))
 
     def __del__(self):
         try:
@@ -97,6 +99,7 @@ class ShardedSearcher:
         self.device = device
         self.local_search = local_search
         self._bufs = {}
+        self._adopted = False
 
     def _buffers(self, B, k):
         import torch
@@ -104,9 +107,10 @@ class ShardedSearcher:
         key = (B, k)
         if key not in self._bufs:
             dev = "cuda" if self.device else "cpu"
+            rec = B * k + 1  # + the overflow record of search_device_begin
             self._bufs[key] = (
-                torch.empty(B * k * HIT_BYTES, dtype=torch.uint8, device=dev),
-                torch.empty(self.world * B * k * HIT_BYTES, dtype=torch.uint8, device=dev),
+                torch.empty(rec * HIT_BYTES, dtype=torch.uint8, device=dev),
+                torch.empty(self.world * rec * HIT_BYTES, dtype=torch.uint8, device=dev),
             )
         return self._bufs[key]
 
@@ -118,15 +122,36 @@ class ShardedSearcher:
         import torch  # only the torch.distributed exchange needs it (and it must then be imported first)
 
         local, gathered = self._buffers(B, k)
+        n = B * k * HIT_BYTES
         if self.device:
+            if not self._adopted:
+                # the library queues on torch's current stream from now on: pass -> all-gather -> merge
+                # are ordered on the device and the host waits once per step
+                self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                self._adopted = True
+            for _ in range(8):
+                try:
+                    self.searcher.search_device_begin(sources, k, q, local.data_ptr())
+                except _ffi.PcvError as e:
+                    if e.status != 3:  # PCV_ERR_UNSUPPORTED: needs several passes
+                        raise
+                    break
+                self.dist.all_gather_into_tensor(gathered, local)
+                ids, scores, counts, over = merge_topk(
+                    self.ctx, self.metric, self.dim, gathered.data_ptr(), self.world, B, k, flagged=True
+                )
+                self.searcher.search_device_end()
+                if not over:  # the same on every rank: it travelled with the hits
+                    return ids, scores, counts
+            else:
+                raise RuntimeError("candidate lists still overflow after 8 reruns")
             self.searcher.search_device(sources, k, q, local.data_ptr())  # returns after its stream drained
-            self.dist.all_gather_into_tensor(gathered, local)
-            torch.cuda.current_stream().synchronize()
+            self.dist.all_gather_into_tensor(gathered[: self.world * n], local[:n])
             return merge_topk(self.ctx, self.metric, self.dim, gathered.data_ptr(), self.world, B, k)
         hits = self.local_search(q, k) if self.local_search else self._local_hits_host(sources, q, k)
-        local.copy_(torch.from_numpy(np.ascontiguousarray(hits).view(np.uint8).reshape(-1)))
-        self.dist.all_gather_into_tensor(gathered, local)
-        return merge_topk_host(self.metric, self.dim, gathered.numpy(), self.world, B, k)
+        local[:n].copy_(torch.from_numpy(np.ascontiguousarray(hits).view(np.uint8).reshape(-1)))
+        self.dist.all_gather_into_tensor(gathered[: self.world * n], local[:n])
+        return merge_topk_host(self.metric, self.dim, gathered[: self.world * n].numpy(), self.world, B, k)
 
     def _local_hits_host(self, sources, q, k):
         d = self.ctx.alloc(q.shape[0] * k * HIT_BYTES)

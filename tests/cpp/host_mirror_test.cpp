@@ -60,6 +60,12 @@ int main() {
         }
     }
     EXPECT(s->search_vector({}, 10, q).empty());
+    {  // the sharded form at world size 1 (RCCL communicator owned by the library) gives the same items
+        Comm comm(ctx, 1, 0, Comm::unique_id());
+        auto a = s->search_vector({1}, 10, q), b = s->search_vector_sharded(comm, {1}, 10, q);
+        EXPECT(a.size() == b.size());
+        for (size_t j = 0; j < a.size() && j < b.size(); ++j) EXPECT(a[j].id == b[j].id && a[j].score == b[j].score);
+    }
     // rebuild_source: source 2 shrinks to 5 rows
     std::vector<EmbeddingRow> repl(rows.begin() + 1, rows.begin() + 11);
     s->rebuild_source(repl, 2);

@@ -315,6 +315,87 @@ def test_sharded_search_and_merge(ctx, oracle):
         s.close()
 
 
+def _two_shard_step(ctx, shards, q, k, dim):
+    """The multi-GPU step with both 'ranks' in this process: begin on each shard into one gathered
+    buffer (stride B*k+1), flagged merge, end; repeated while any shard reports an overflow."""
+    B = q.shape[0]
+    rec = B * k + 1
+    d_lists = ctx.alloc(len(shards) * rec * 24)
+    try:
+        for attempt in range(8):
+            overs = []
+            for r, s in enumerate(shards):
+                s.search_device_begin(None, k, q, d_lists + r * rec * 24)
+                overs.append(s.search_device_end())  # one stream: collect before the next shard reuses nothing shared
+            ids, scores, counts, any_over = pa.merge_topk(ctx, "cosine", dim, d_lists, len(shards), B, k, flagged=True)
+            assert any_over == any(overs)
+            if not any_over:
+                return ids, scores, counts, attempt
+        raise AssertionError("still overflowing")
+    finally:
+        ctx.free(d_lists)
+
+
+def test_begin_end_protocol_two_shards(ctx, oracle):
+    N, B, k = 30_000, 6, 10
+    ref = oracle.synth_rows(77, 0, N, 384)
+    q = oracle.synth_rows(78, 0, B, 384)
+    cut = 13_000
+    shards = []
+    for lo, hi in [(0, cut), (cut, N)]:
+        s = pa.Searcher(ctx, 384, "cosine")
+        s.add_synthetic(1, hi - lo, 77, first_row=lo)
+        s.finalize()
+        s.set_shard_offset(lo)
+        shards.append(s)
+    ids, scores, counts, attempts = _two_shard_step(ctx, shards, q, k, 384)
+    opos, osc, _ = oracle.topk(q, ref, k)
+    np.testing.assert_array_equal(ids, opos)
+    np.testing.assert_allclose(scores, osc.astype(np.float32), atol=1e-7)
+    assert attempts == 0 and (counts == k).all()
+    # protocol errors: a second begin without end, an end without begin, more queries than one pass holds
+    d = ctx.alloc((200 * k + 1) * 24)
+    shards[0].search_device_begin(None, k, q, d)
+    with pytest.raises(pa.PcvError):
+        shards[0].search_device_begin(None, k, q, d)
+    assert shards[0].search_device_end() is False
+    with pytest.raises(pa.PcvError):
+        shards[0].search_device_end()
+    with pytest.raises(pa.PcvError) as ei:
+        shards[0].search_device_begin(None, k, oracle.synth_rows(5, 0, 200, 384), d)
+    assert ei.value.status == 3
+    ctx.free(d)
+    for s in shards:
+        s.close()
+
+
+def test_begin_end_overflow_is_repeated_by_all_shards(ctx, oracle):
+    # adversarial order on shard 1 only (see test_candidate_overflow_reruns_and_stays_exact): its overflow
+    # record must reach the merged flag, the step is repeated, and the answer is exact
+    rng = np.random.default_rng(9)
+    N, D, k = 40_000, 64, 10
+    q = rng.standard_normal((1, D)).astype(np.float32)
+    noise = rng.standard_normal((N, D)).astype(np.float32)
+    t = np.linspace(-1, 1, N, dtype=np.float32)[:, None]
+    hard = (t * q + 0.01 * noise).astype(np.float32)
+    easy = rng.standard_normal((5_000, D)).astype(np.float32)
+    m = np.concatenate([easy, hard])
+    shards = []
+    for lo, part in [(0, easy), (easy.shape[0], hard)]:
+        s = pa.Searcher(ctx, D, "cosine")
+        s.add_rows(1, part, np.arange(lo, lo + part.shape[0]))
+        s.finalize()
+        s.set_shard_offset(lo)
+        shards.append(s)
+    ids, scores, counts, attempts = _two_shard_step(ctx, shards, q, k, D)
+    opos, osc, _ = oracle.topk(q, m, k)
+    np.testing.assert_array_equal(ids, opos)
+    assert attempts >= 1
+    assert shards[1].last_stats()["overflow_reruns"] == 0  # stats are per call; the rerun was a fresh begin
+    for s in shards:
+        s.close()
+
+
 def test_native_rccl_exchange_single_rank(ctx, oracle):
     # pcv_comm_* + pcv_searcher_search_sharded at world=1 (the box has one GPU): RCCL is loaded by the
     # library, the all-gather runs on its stream, and the result equals the plain search and the oracle
@@ -338,6 +419,16 @@ def test_native_rccl_exchange_single_rank(ctx, oracle):
     np.testing.assert_array_equal(sh.search_vectors(None, k, q)[0], opos)
     with pytest.raises(pa.PcvError):
         pa.NativeComm(ctx, 2, 2, bytes(128))  # rank outside the world: refused before RCCL is touched
+    # more queries than one pass holds -> the sequential form; and an overflowing pass is repeated
+    qm = oracle.synth_rows(93, 0, 150, 384)
+    np.testing.assert_array_equal(s.search_sharded(comm, None, k, qm)[0], oracle.topk(qm, ref, k)[0])
+    s.close()
+    rng = np.random.default_rng(9)
+    qa = rng.standard_normal((1, 64)).astype(np.float32)
+    t = np.linspace(-1, 1, 40_000, dtype=np.float32)[:, None]
+    hard = (t * qa + 0.01 * rng.standard_normal((40_000, 64)).astype(np.float32)).astype(np.float32)
+    s = build(ctx, hard)
+    np.testing.assert_array_equal(s.search_sharded(comm, None, k, qa)[0], oracle.topk(qa, hard, k)[0])
     comm.close()
     s.close()
 
