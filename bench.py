@@ -142,7 +142,7 @@ def main():
             torch.cuda.synchronize()
         ctx.synchronize()
 
-    scan_ms, scan_bytes, cands, reruns = [], [], [], 0
+    scan_ms, pass_ms, host_ms, scan_bytes, cands, reruns = [], [], [], [], [], 0
     last = None
 
     def step(i, timed):
@@ -154,6 +154,8 @@ def main():
             last = sharded.search_vectors(None, k, q)
         if timed:
             st = searcher.last_stats()
+            pass_ms.append(st["total_ms"])
+            host_ms.append((st["host_enqueue_ms"], st["host_wait_ms"]))
             scan_ms.append(st["scan_ms"])
             scan_bytes.append(st["bytes_algorithmic"])
             cands.append(st["candidates"])
@@ -222,6 +224,9 @@ def main():
                 "kernel_ms": mean_scan_ms,
                 "kernel_ms_median": float(np.median(scan_ms)),
                 "kernel_ms_min": float(np.min(scan_ms)),
+                "pass_ms": float(np.mean(pass_ms)),  # prep + seed + scan + rescore + select on the device
+                "host_enqueue_ms": float(np.mean([h[0] for h in host_ms])),
+                "host_wait_ms": float(np.mean([h[1] for h in host_ms])),
             },
             "candidates_per_query": float(np.mean(cands)) / B,
             "overflow_reruns": reruns,

@@ -65,10 +65,11 @@ pcv_status pcv_shutdown(pcv_ctx* ctx);
 pcv_status pcv_synchronize(pcv_ctx* ctx);
 /* The context's hipStream_t (as void*), for callers that order their own work against it. */
 void* pcv_stream(pcv_ctx* ctx);
-/* Queue all further work of this context on a caller-owned hipStream_t (e.g. the stream a host framework
- * runs its collectives against), so that both are ordered without host synchronisation; NULL returns to
- * the context's own stream.  Drains the stream in use before switching. */
-pcv_status pcv_set_stream(pcv_ctx* ctx, void* hip_stream);
+/* adopt != 0: queue all further work of this context on the caller's hipStream_t `hip_stream` (NULL = the
+ * device's default stream) — e.g. the stream a host framework runs its collectives against — so that
+ * both are ordered without host synchronisation.  adopt == 0: back to the context's own stream.  The
+ * handle must come from the HIP runtime this library is bound to.  Drains the stream in use first. */
+pcv_status pcv_set_stream(pcv_ctx* ctx, void* hip_stream, int adopt);
 
 /* Plain device buffers for hosts that have no HIP binding of their own (the per-shard hit lists that
  * an RCCL all-gather exchanges live in such buffers). */
@@ -221,6 +222,8 @@ typedef struct pcv_scan_stats {
     int32_t overflow_reruns;     /* passes repeated because a candidate list overflowed          */
     int32_t kernel_used;         /* PCV_KERNEL_WAVE or PCV_KERNEL_MFMA                           */
     int32_t reserved;
+    float host_enqueue_ms;       /* host time spent queueing the passes (copies + launches)      */
+    float host_wait_ms;          /* host time blocked until the stream had drained               */
 } pcv_scan_stats;
 pcv_status pcv_searcher_last_stats(pcv_searcher* s, pcv_scan_stats* out);
 

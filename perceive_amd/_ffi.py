@@ -38,6 +38,8 @@ class ScanStats(C.Structure):
         ("overflow_reruns", C.c_int32),
         ("kernel_used", C.c_int32),
         ("reserved", C.c_int32),
+        ("host_enqueue_ms", C.c_float),
+        ("host_wait_ms", C.c_float),
     ]
 
 
@@ -65,11 +67,14 @@ class EncodeStats(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/perceive_hip.h declares
+# Data pointers are declared void* and passed as plain addresses (`ndarray.ctypes.data`): building typed
+# ctypes pointers with `ndarray.ctypes.data_as` costs 2 us each and ~20-40 us each once torch has been
+# imported into the process, which was 150 us per search call.  The names keep the C types readable.
 _P = C.c_void_p
-_I64P = C.POINTER(C.c_int64)
-_F32P = C.POINTER(C.c_float)
-_U8P = C.POINTER(C.c_uint8)
-_INTP = C.POINTER(C.c_int)
+_I64P = C.c_void_p  # int64_t*
+_F32P = C.c_void_p  # float*
+_U8P = C.c_void_p  # uint8_t*
+_INTP = C.c_void_p  # int* / int32_t*
 SYMBOLS = {
     "pcv_last_error": (C.c_char_p, []),
     "pcv_version": (C.c_char_p, []),
@@ -78,7 +83,7 @@ SYMBOLS = {
     "pcv_shutdown": (C.c_int, [_P]),
     "pcv_synchronize": (C.c_int, [_P]),
     "pcv_stream": (_P, [_P]),
-    "pcv_set_stream": (C.c_int, [_P, _P]),
+    "pcv_set_stream": (C.c_int, [_P, _P, C.c_int]),
     "pcv_device_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "pcv_device_free": (C.c_int, [_P, _P]),
     "pcv_copy_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
@@ -126,8 +131,8 @@ SYMBOLS = {
     "pcv_tokenizer_destroy": (C.c_int, [_P]),
     "pcv_tokenizer_vocab_size": (C.c_int, [_P, _INTP]),
     "pcv_tokenizer_special_ids": (C.c_int, [_P, _I64P, _I64P, _I64P, _I64P]),
-    "pcv_tokenizer_encode": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_int, _I64P, C.POINTER(C.c_int32),
-                                       C.POINTER(C.c_int32), _U8P, C.c_int, _INTP]),
+    "pcv_tokenizer_encode": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_int, _I64P, _INTP,
+                                       _INTP, _U8P, C.c_int, _INTP]),
 }
 
 _lib = None
@@ -157,12 +162,16 @@ def check(status):
 
 
 def f32p(a):
-    return a.ctypes.data_as(_F32P)
+    return a.ctypes.data
 
 
 def i64p(a):
-    return a.ctypes.data_as(_I64P)
+    return a.ctypes.data
 
 
 def u8p(a):
-    return a.ctypes.data_as(_U8P)
+    return a.ctypes.data
+
+
+def i32p(a):
+    return a.ctypes.data

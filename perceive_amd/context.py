@@ -27,10 +27,11 @@ class Context:
     def stream(self):
         return _ffi.lib().pcv_stream(self.handle)
 
-    def set_stream(self, hip_stream):
-        """Queue all further work on a caller-owned hipStream_t (int / None = the context's own), e.g.
-        `torch.cuda.current_stream().cuda_stream` so that torch collectives order against it."""
-        _ffi.check(_ffi.lib().pcv_set_stream(self.handle, C.c_void_p(hip_stream or None)))
+    def set_stream(self, hip_stream, adopt=True):
+        """adopt=True: queue all further work on the caller's hipStream_t (int; 0 = the device's default
+        stream), e.g. `torch.cuda.current_stream().cuda_stream`, so that torch collectives order against
+        it.  adopt=False: back to the context's own stream."""
+        _ffi.check(_ffi.lib().pcv_set_stream(self.handle, C.c_void_p(hip_stream or None), 1 if adopt else 0))
 
     def alloc(self, n_bytes):
         """Device buffer (returns the device pointer as int)."""
@@ -45,14 +46,14 @@ class Context:
         import numpy as np
 
         out = np.empty(n_bytes, dtype=np.uint8)
-        _ffi.check(_ffi.lib().pcv_copy_to_host(self.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), n_bytes))
+        _ffi.check(_ffi.lib().pcv_copy_to_host(self.handle, out.ctypes.data, C.c_void_p(dptr), n_bytes))
         return out
 
     def to_device(self, dptr, array):
         import numpy as np
 
         a = np.ascontiguousarray(array)
-        _ffi.check(_ffi.lib().pcv_copy_to_device(self.handle, C.c_void_p(dptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        _ffi.check(_ffi.lib().pcv_copy_to_device(self.handle, C.c_void_p(dptr), a.ctypes.data, a.nbytes))
 
     def close(self):
         if self._h:

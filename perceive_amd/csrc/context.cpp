@@ -80,12 +80,17 @@ pcv_status pcv_synchronize(pcv_ctx* ctx) {
 
 void* pcv_stream(pcv_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-pcv_status pcv_set_stream(pcv_ctx* ctx, void* hip_stream) {
+pcv_status pcv_set_stream(pcv_ctx* ctx, void* hip_stream, int adopt) {
     return guarded([&] {
         PCV_REQUIRE(ctx != nullptr, "pcv_set_stream: ctx is NULL");
         PCV_HIP(hipSetDevice(ctx->device));
         PCV_HIP(hipStreamSynchronize(ctx->stream));  // nothing of ours is left behind on the old stream
-        ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+        ctx->stream = adopt ? (hipStream_t)hip_stream : ctx->own_stream;
+        const hipError_t q = hipStreamQuery(ctx->stream);  // a handle of another runtime fails here
+        if (q != hipSuccess && q != hipErrorNotReady) {
+            ctx->stream = ctx->own_stream;
+            PCV_HIP(q);
+        }
     });
 }
 

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -276,6 +277,7 @@ void ensure_workspace(pcv_searcher* s) {
 // `download`, the hits' too.  `d_flag` != nullptr receives the overflow record (scan.h).
 void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel,
                   pcv_hit_dev* d_out, bool download, pcv_hit_dev* d_flag) {
+    const auto t_begin = std::chrono::steady_clock::now();
     hipStream_t st = s->ctx->stream;
     ensure_workspace(s);
     if (queries_host) {  // nullptr: the queries of the previous attempt are still on the device
@@ -345,6 +347,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     s->pending.active = true;
     s->pending.B = B;
     s->pending.rows = rows;
+    s->stats.host_enqueue_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
 // Collect a queued pass: wait for the stream, book the statistics, and report whether a candidate list
@@ -354,7 +357,9 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
 bool finish_pass(pcv_searcher* s) {
     PCV_REQUIRE(s->pending.active, "no pass is pending");
     s->pending.active = false;
+    const auto t_begin = std::chrono::steady_clock::now();
     PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+    s->stats.host_wait_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     PCV_HIP(hipGetLastError());
     const int B = s->pending.B;
     const int64_t rows = s->pending.rows;

@@ -146,7 +146,7 @@ class Searcher:
         _ffi.check(
             _ffi.lib().pcv_searcher_search(
                 self._handle, _ffi.f32p(q), B, src, nsrc, k, _ffi.i64p(ids), _ffi.f32p(scores),
-                counts.ctypes.data_as(C.POINTER(C.c_int)),
+                _ffi.i32p(counts),
             )
         )
         return ids, scores, counts
@@ -204,7 +204,7 @@ class Searcher:
         _ffi.check(
             _ffi.lib().pcv_searcher_search_sharded(
                 self._handle, comm._handle, _ffi.f32p(q), B, src, nsrc, k, _ffi.i64p(ids), _ffi.f32p(scores),
-                counts.ctypes.data_as(C.POINTER(C.c_int)),
+                _ffi.i32p(counts),
             )
         )
         return ids, scores, counts
@@ -274,7 +274,7 @@ def merge_topk(ctx, metric, dim, d_lists, n_shards, n_queries, k, flagged=False)
     counts = np.zeros(n_queries, dtype=np.int32)
     args = (
         ctx.handle, _METRICS[metric], int(dim), C.c_void_p(d_lists), int(n_shards), int(n_queries), int(k),
-        _ffi.i64p(ids), _ffi.f32p(scores), counts.ctypes.data_as(C.POINTER(C.c_int)),
+        _ffi.i64p(ids), _ffi.f32p(scores), _ffi.i32p(counts),
     )
     if flagged:
         over = C.c_int()

@@ -31,11 +31,27 @@ def merge_topk_host(metric, dim, lists, n_shards, n_queries, k):
     counts = np.zeros(n_queries, dtype=np.int32)
     _ffi.check(
         _ffi.lib().pcv_merge_topk_host(
-            _METRICS[metric], int(dim), a.ctypes.data_as(C.c_void_p), n_shards, n_queries, k,
-            _ffi.i64p(ids), _ffi.f32p(scores), counts.ctypes.data_as(C.POINTER(C.c_int)),
+            _METRICS[metric], int(dim), a.ctypes.data, n_shards, n_queries, k,
+            _ffi.i64p(ids), _ffi.f32p(scores), _ffi.i32p(counts),
         )
     )
     return ids, scores, counts
+
+
+def hip_runtimes_loaded():
+    """Paths of the libamdhip64 copies mapped into this process.  More than one (PyTorch bundles its own
+    and is loaded beside the system one when it is imported after this library) means torch's streams
+    and this library's are unrelated objects: no device-side ordering between them is possible."""
+    seen = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                if "libamdhip64" in path:
+                    seen.add(path)
+    except OSError:
+        pass
+    return sorted(seen)
 
 
 class NativeComm:
@@ -124,16 +140,21 @@ class ShardedSearcher:
         local, gathered = self._buffers(B, k)
         n = B * k * HIT_BYTES
         if self.device:
-            if not self._adopted:
+            if self._adopted is False:
                 # the library queues on torch's current stream from now on: pass -> all-gather -> merge
-                # are ordered on the device and the host waits once per step
-                self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-                self._adopted = True
-            for _ in range(8):
+                # are ordered on the device and the host waits once per step.  Only sound when torch and
+                # the library share one HIP runtime (torch imported first); otherwise keep host syncs.
+                if len(hip_runtimes_loaded()) == 1:
+                    self.ctx.set_stream(torch.cuda.current_stream().cuda_stream, adopt=True)
+                    self._adopted = True
+                else:
+                    self._adopted = None
+            attempts = 8 if self._adopted else 0
+            while attempts > 0:
                 try:
                     self.searcher.search_device_begin(sources, k, q, local.data_ptr())
                 except _ffi.PcvError as e:
-                    if e.status != 3:  # PCV_ERR_UNSUPPORTED: needs several passes
+                    if e.status != 3:  # PCV_ERR_UNSUPPORTED: needs several passes -> sequential form below
                         raise
                     break
                 self.dist.all_gather_into_tensor(gathered, local)
@@ -143,10 +164,12 @@ class ShardedSearcher:
                 self.searcher.search_device_end()
                 if not over:  # the same on every rank: it travelled with the hits
                     return ids, scores, counts
-            else:
-                raise RuntimeError("candidate lists still overflow after 8 reruns")
+                attempts -= 1
+                if attempts == 0:
+                    raise RuntimeError("candidate lists still overflow after 8 reruns")
             self.searcher.search_device(sources, k, q, local.data_ptr())  # returns after its stream drained
             self.dist.all_gather_into_tensor(gathered[: self.world * n], local[:n])
+            torch.cuda.current_stream().synchronize()
             return merge_topk(self.ctx, self.metric, self.dim, gathered.data_ptr(), self.world, B, k)
         hits = self.local_search(q, k) if self.local_search else self._local_hits_host(sources, q, k)
         local[:n].copy_(torch.from_numpy(np.ascontiguousarray(hits).view(np.uint8).reshape(-1)))

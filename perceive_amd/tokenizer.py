@@ -49,8 +49,8 @@ class BertTokenizer:
             sp = np.empty(cap, np.uint8)
             n = C.c_int()
             st = _ffi.lib().pcv_tokenizer_encode(
-                self._h, b, len(b), int(max_len), _ffi.i64p(ids), beg.ctypes.data_as(C.POINTER(C.c_int32)),
-                end.ctypes.data_as(C.POINTER(C.c_int32)), _ffi.u8p(sp), cap, C.byref(n))
+                self._h, b, len(b), int(max_len), _ffi.i64p(ids), _ffi.i32p(beg),
+                _ffi.i32p(end), _ffi.u8p(sp), cap, C.byref(n))
             if st != 0 and n.value > cap:
                 cap = n.value
                 continue
