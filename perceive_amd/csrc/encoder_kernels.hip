@@ -4,6 +4,8 @@
 // Numerics: f32 end to end like the reference (tch default dtype, no autocast).  Every contraction
 // runs on the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain in k
 // order), so the result differs from a CPU f32 evaluation only by summation order.
+#include <cstdlib>
+
 #include "encoder.h"
 #include "synth.h"
 
@@ -43,6 +45,64 @@ __device__ __forceinline__ void tile_of_block(int ncols, int& tile_m, int& tile_
     if ((nwg & 7u) == 0) logical = (wg & 7u) * (nwg >> 3) + (wg >> 3);
     tile_m = (int)(logical / (unsigned)ncols);
     tile_n = (int)(logical % (unsigned)ncols);
+}
+
+// Epilogue of the 128x128 GEMMs: one wave's 64x64 quarter (2x2 MFMA tiles) -> +bias (+GELU | +residual) ->
+// C.  Full quarters take a branch-free path.  With a per-element `if (row < M)` every element became its
+// own basic block, the waitcnt pass lost track of the bias load across them and put `s_waitcnt vmcnt(0)` in
+// front of every single store (stores count in vmcnt on gfx9): 64 serialised HBM round trips per wave,
+// ~5 ms of the 13 ms encoder forward.
+template <int EPI>
+__device__ __forceinline__ void store_quarter(const f32x16 (&acc)[2][2], const float (&bv)[2],
+                                              const float* __restrict__ resid, float* __restrict__ C, int M, int N,
+                                              int row0, int col0, int i, int h) {
+    if (row0 + 64 <= M) {  // wave-uniform
+        const size_t base0 = (size_t)(row0 + 4 * h) * N + col0 + i;
+        float rv[2][2][16];
+        if (EPI == EPI_BIAS_RESIDUAL) {  // all 64 residual loads in flight together: one latency, not four
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rv[a][b][r] = resid[base0 + (size_t)(a * 32 + acc_row(r, 0)) * N + b * 32];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[a][b][r] + bv[b];
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += rv[a][b][r];
+                    C[base0 + (size_t)(a * 32 + acc_row(r, 0)) * N + b * 32] = v;
+                }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = col0 + b * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + a * 32 + acc_row(r, h);
+                if (row < M) {
+                    float v = acc[a][b][r] + bv[b];
+                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
+                    C[(size_t)row * N + col] = v;
+                }
+            }
+        }
+}
+
+// the bias values of a wave's two column tiles
+__device__ __forceinline__ void load_bias2(const float* __restrict__ bias, int col0, int i, float (&bv)[2]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bv[b] = bias ? bias[col0 + b * 32 + i] : 0.0f;
 }
 
 template <int EPI>
@@ -125,23 +185,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
     }
 
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + wc * 64 + b * 32 + i;
-            const float bv = bias ? bias[col] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + a * 32 + acc_row(r, kk);
-                if (row < M) {
-                    float v = acc[a][b][r] + bv;
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
-                    C[(size_t)row * N + col] = v;
-                }
-            }
-        }
+    float bv[2];
+    load_bias2(bias, n0 + wc * 64, i, bv);
+    store_quarter<EPI>(acc, bv, resid, C, M, N, m0 + wr * 64, n0 + wc * 64, i, kk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -217,6 +263,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(const float* _
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int LDB = 40;
+
+// Pins memory operations in program order: the asm is a compiler-level memory barrier (IR passes may
+// otherwise reorder the loads around it), sched_barrier stops the machine scheduler.
+#define PCV_PIN_ORDER()                     \
+    do {                                    \
+        asm volatile("" ::: "memory");      \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
 
 __device__ __forceinline__ void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
     hi = __builtin_convertvector(x, bf16x4);
@@ -300,7 +354,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
             *(f32x4*)&Ws[pl][(wrow + 64) * LDB + wc8 * 8] = rw[set][pl][1];
         }
         __syncthreads();
+        // The refill is pinned here: left to itself the scheduler sinks these loads to the end of the
+        // iteration (their registers are dead until then), which turns the s_waitcnt at the next use
+        // into vmcnt(0) on loads issued moments earlier — no prefetch distance at all.
+        __builtin_amdgcn_sched_barrier(0);
         load_tile(set, min(kt + 2, nk - 1));  // refill this set for tile kt+2 (clamped re-read at the end)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {  // two 16-deep steps per 32-wide K tile
             bf16x8 af[2][3], bf[2][3];
@@ -325,30 +384,206 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
                 }
         }
     };
+    // same issue order as inside the loop (set 0 before set 1), or the merged wait at the loop head
+    // degrades to vmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
     load_tile(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     load_tile(1, min(1, nk - 1));
-    for (int kt = 0; kt < nk; kt += 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk; kt += 2) {  // nk is even (K % 128 == 0): no branch between the two halves
         step(0, kt);
-        if (kt + 1 < nk) step(1, kt + 1);
+        step(1, kt + 1);
     }
 
+    float bv[2];
+    load_bias2(bias, n0 + wc * 64, i, bv);
+    store_quarter<EPI>(acc, bv, resid, C, M, N, m0 + wr * 64, n0 + wc * 64, i, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same GEMM as a PERSISTENT, WAVE-SPECIALISED kernel.  What the kernel above loses (measured with
+// diagnostic builds and PMC on the 256x256-token batch): every wave stages, waits at two barriers and
+// multiplies in turn, so the matrix pipe idles while it stages (bf16 pipe 39 % busy); and with K = 384 a
+// tile is only 12 K steps long, so the fill of the load pipeline at its start and the drain of its stores
+// before the workgroup can retire cost about as much as the steps in between.  Here
+//   * one 512-thread workgroup per CU walks over tiles (tile = f(blockIdx.x + n * gridDim.x));
+//   * waves 0-3 are consumers: fragment reads + 48 MFMAs per K step (a 64x64 quarter each), then the
+//     epilogue; waves 4-7 are producers: global loads (two register sets in flight), the 3-way split, LDS
+//     writes.  One of each per SIMD, so split VALU and MFMA interleave cycle by cycle;
+//   * LDS is double buffered (2 x 60 KB) and ONE barrier per K step orders both directions: barrier g
+//     tells the consumers buffer g&1 is full and tells the producers the consumers are done with buffer
+//     (g+1)&1 (read in step g-1, before they arrived).  The step counter g runs on across tiles: while
+//     the consumers store tile t the producers have already staged step 0 of tile t+1 and hold its next
+//     two K tiles in registers, and the stores of tile t drain under the MFMAs of tile t+1.
+// Same staging maps, fragment layout, product order and epilogue as above: results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence over
+// ALL address spaces, which on gfx9 means s_waitcnt vmcnt(0) whenever global stores are in flight: in
+// the persistent kernel the consumers would sit out the HBM write latency of tile t at the first barrier
+// of tile t+1.  LDS operations of a wave complete in order, so lgkmcnt(0) + s_barrier is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int WS_PLANE = BM * LDB;     // elements of one plane of one operand (BM == BN)
+constexpr int WS_BUF = 6 * WS_PLANE;   // A: 3 planes, W: 3 planes
+constexpr size_t kGemmWsLdsBytes = 2 * (size_t)WS_BUF * sizeof(__bf16);
+
+// tile visited by workgroup `wg` in its n-th round.  Workgroups go to XCDs round-robin (wg & 7); the 32
+// workgroups of one XCD take 32 consecutive logical tiles of the round, i.e. all column tiles of a few
+// row blocks, so a row block of A is fetched from HBM once and then served by that XCD's L2.
+__device__ __forceinline__ unsigned ws_slot(unsigned wg, unsigned nwg) {
+    return (nwg & 7u) == 0 ? (wg & 7u) * (nwg >> 3) + (wg >> 3) : wg;
+}
+__device__ __forceinline__ void ws_tile(unsigned slot, unsigned nwg, unsigned round, int ncols, int& tile_m, int& tile_n) {
+    const unsigned logical = round * nwg + slot;
+    tile_m = (int)(logical / (unsigned)ncols);
+    tile_n = (int)(logical % (unsigned)ncols);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16x3_ws_kernel(const float* __restrict__ A, const uint16_t* __restrict__ Wh,
+                                                             const uint16_t* __restrict__ Wm,
+                                                             const uint16_t* __restrict__ Wl,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ resid, float* __restrict__ C,
+                                                             int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_smem[];
+    __bf16* const sm = (__bf16*)ws_smem;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // scalar: the role branch is uniform
+    const int lane = threadIdx.x & 63;
+    const int ncols = N / BN;
+    const unsigned ntiles = (unsigned)ncols * (unsigned)((M + BM - 1) / BM);
+    const unsigned nwg = gridDim.x, wg = ws_slot(blockIdx.x, gridDim.x);
+    const unsigned rounds = (ntiles - wg + nwg - 1) / nwg;  // >= 1: the grid never exceeds the tile count
+    const int nk = K / BK;                                  // even: K is a multiple of 128
+
+    if (wave >= 4) {
+        // ---- producers (staging maps of gemm_bf16x3_kernel, thread index within the producer half)
+        const int pt = (int)threadIdx.x - 256;
+        const int ag_ = pt >> 3, ac4 = pt & 7;
+        const int arow = 8 * ((ag_ >> 1) >> 2) + ((ag_ >> 1) & 3) + 4 * (ag_ & 1);
+        const int wg_ = pt >> 3, wsub = pt & 7;
+        const int wc8 = wsub & 3;
+        const int wrow = (wg_ >> 2) * 8 + (wg_ & 3) + 4 * (wsub >> 2);
+        // source of the NEXT refill: K tile `lk` of round `lround`
+        const float* ag[4];
+        size_t woff0, woff1;
+        auto point_at = [&](unsigned round) {
+            int tm, tn;
+            ws_tile(wg, nwg, round, ncols, tm, tn);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+            for (int u = 0; u < 4; ++u) ag[u] = A + (size_t)min(tm * BM + arow + 32 * u, M - 1) * K + ac4 * 4;
+            woff0 = (size_t)(tn * BN + wrow) * K + wc8 * 8;
+            woff1 = woff0 + (size_t)64 * K;
+        };
+        unsigned lround = 0;
+        int lk = 0;
+        point_at(0);
+        f32x4 ra[2][4];
+        f32x4 rw[2][3][2];
+        auto load_next = [&](int set) {  // loads K tile (lround, lk) into register set `set`, then advances
+            const size_t koff = (size_t)lk * BK;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + wc * 64 + b * 32 + i;
-            const float bv = bias ? bias[col] : 0.0f;
+            for (int u = 0; u < 4; ++u) ra[set][u] = *(const f32x4*)(ag[u] + koff);
+            rw[set][0][0] = *(const f32x4*)(Wh + woff0 + koff); rw[set][0][1] = *(const f32x4*)(Wh + woff1 + koff);
+            rw[set][1][0] = *(const f32x4*)(Wm + woff0 + koff); rw[set][1][1] = *(const f32x4*)(Wm + woff1 + koff);
+            rw[set][2][0] = *(const f32x4*)(Wl + woff0 + koff); rw[set][2][1] = *(const f32x4*)(Wl + woff1 + koff);
+            if (++lk == nk) {  // uniform; address arithmetic only (past the last tile: stay on it, the data is unused)
+                lk = 0;
+                if (lround + 1 < rounds) ++lround;
+                point_at(lround);
+            }
+        };
+        auto produce = [&](int set) {  // set == step parity == buffer
+            __bf16* const As = sm + set * WS_BUF;
+            __bf16* const Ws = As + 3 * WS_PLANE;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + a * 32 + acc_row(r, h);
-                if (row < M) {
-                    float v = acc[a][b][r] + bv;
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
-                    C[(size_t)row * N + col] = v;
-                }
+            for (int u = 0; u < 4; ++u) {
+                bf16x4 ph, pm, pl;
+                split3(ra[set][u], ph, pm, pl);
+                const int o = (arow + 32 * u) * LDB + ac4 * 4;
+                *(bf16x4*)&As[o] = ph;
+                *(bf16x4*)&As[WS_PLANE + o] = pm;
+                *(bf16x4*)&As[2 * WS_PLANE + o] = pl;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *(f32x4*)&Ws[pl * WS_PLANE + wrow * LDB + wc8 * 8] = rw[set][pl][0];
+                *(f32x4*)&Ws[pl * WS_PLANE + (wrow + 64) * LDB + wc8 * 8] = rw[set][pl][1];
+            }
+            // The refill is pinned here.  Left alone the scheduler sinks these loads to the end of the
+            // iteration (their registers are dead until then) and the s_waitcnt at the next use becomes
+            // vmcnt(0) on loads issued moments earlier: no prefetch distance at all.
+            PCV_PIN_ORDER();
+            load_next(set);
+            PCV_PIN_ORDER();
+            lds_barrier();  // barrier g: buffer `set` is full
+        };
+        PCV_PIN_ORDER();
+        load_next(0);
+        PCV_PIN_ORDER();
+        load_next(1);
+        PCV_PIN_ORDER();
+        // First pair of steps outside the loop: the const __restrict__ prologue loads above may still be
+        // issued set 1 first (IR passes ignore both pins for invariant loads), and a loop header that
+        // merges that order with the steady-state order waits with vmcnt(0..9) for ever.  After this pair
+        // the only loads in flight are the two pinned refills, in loop order.
+        produce(0);
+        produce(1);
+        const unsigned pairs = rounds * (unsigned)(nk / 2);
+        for (unsigned g2 = 1; g2 < pairs; ++g2) {
+            produce(0);
+            produce(1);
+        }
+        return;
+    }
+
+    // ---- consumers
+    const int i = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int aoff = (wr * 64 + i) * LDB + 8 * h, woff = (wc * 64 + i) * LDB + 8 * h;
+    for (unsigned round = 0; round < rounds; ++round) {
+        int tile_m, tile_n;
+        ws_tile(wg, nwg, round, ncols, tile_m, tile_n);
+        float bv[2];  // fetched now, used after the K loop
+        load_bias2(bias, tile_n * BN + wc * 64, i, bv);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+        for (int kt = 0; kt < nk; ++kt) {
+            lds_barrier();  // barrier g
+            const __bf16* const As = sm + (kt & 1) * WS_BUF;
+            const __bf16* const Ws = As + 3 * WS_PLANE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        af[t][pl] = *(const bf16x8*)&As[pl * WS_PLANE + aoff + t * 32 * LDB + s * 16];
+                        bf[t][pl] = *(const bf16x8*)&Ws[pl * WS_PLANE + woff + t * 32 * LDB + s * 16];
+                    }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        // smallest terms first
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], acc[a][b], 0, 0, 0);
+                    }
             }
         }
+        store_quarter<EPI>(acc, bv, resid, C, M, N, tile_m * BM + wr * 64, tile_n * BN + wc * 64, i, h);
+    }
 }
 
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t n,
@@ -709,10 +944,38 @@ void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float
     }
 }
 
+template <int EPI>
+static void launch_gemm_bf16x3_ws(hipStream_t st, const float* A, const uint16_t* Wh, const uint16_t* Wm,
+                                  const uint16_t* Wl, const float* bias, const float* resid, float* C, int M, int N, int K) {
+    static bool configured = false;  // > 64 KB of dynamic LDS has to be allowed once per kernel
+    static int num_cus = 0;
+    if (!configured) {
+        hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kGemmWsLdsBytes);
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (num_cus <= 0) num_cus = 256;
+        configured = true;
+    }
+    const unsigned ntiles = (unsigned)(N / BN) * (unsigned)((M + BM - 1) / BM);
+    const unsigned grid = ntiles < (unsigned)num_cus ? ntiles : (unsigned)num_cus;  // one workgroup per CU (120 KB of LDS each)
+    gemm_bf16x3_ws_kernel<EPI><<<grid, 512, kGemmWsLdsBytes, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K);
+}
+
 void launch_gemm_bf16x3(hipStream_t st, const float* A, const uint16_t* Wh, const uint16_t* Wm, const uint16_t* Wl,
                         const float* bias, const float* resid, float* C, int M, int N, int K, int epilogue) {
     if (M <= 0) return;
     dim3 grid((N / BN) * ((M + BM - 1) / BM));
+    static const bool ws = !(getenv("PCV_GEMM_WS") && getenv("PCV_GEMM_WS")[0] == '0');
+    if (ws) {
+        switch (epilogue) {
+            case EPI_BIAS_GELU: launch_gemm_bf16x3_ws<EPI_BIAS_GELU>(st, A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;
+            case EPI_BIAS_RESIDUAL: launch_gemm_bf16x3_ws<EPI_BIAS_RESIDUAL>(st, A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;
+            default: launch_gemm_bf16x3_ws<EPI_BIAS>(st, A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;
+        }
+        return;
+    }
     switch (epilogue) {
         case EPI_BIAS_GELU:
             gemm_bf16x3_kernel<EPI_BIAS_GELU><<<grid, 256, 0, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K);
