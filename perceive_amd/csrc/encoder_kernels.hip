@@ -272,12 +272,31 @@ constexpr int LDB = 40;
         __builtin_amdgcn_sched_barrier(0);  \
     } while (0)
 
+// x = hi + mid + lo with round-to-nearest at every level, two elements at a time so that each level is one
+// v_cvt_pk_bf16_f32 + shift + and + (packed) subtraction: 5.5 VALU per element; the plain vector form
+// compiled to 11.  VALU is not free here: on gfx950 VALU work of ANY wave of a SIMD takes the cycles its
+// MFMAs would use (tools/ubench/coexec.hip: MFMA-only 1.31 ms, VALU-only 1.07 ms, both on one SIMD 2.37 ms).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    const bf16x2 p = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    return __builtin_bit_cast(uint32_t, p);
+}
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, mid << 16), s1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
+    lo = cvt_pk_bf16(s0, s1);
+}
 __device__ __forceinline__ void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
-    hi = __builtin_convertvector(x, bf16x4);
-    const f32x4 r1 = x - __builtin_convertvector(hi, f32x4);
-    mid = __builtin_convertvector(r1, bf16x4);
-    const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
-    lo = __builtin_convertvector(r2, bf16x4);
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split3_pair(x.x, x.y, h0, m0, l0);
+    split3_pair(x.z, x.w, h1, m1, l1);
+    hi = __builtin_bit_cast(bf16x4, u32x2{h0, h1});
+    mid = __builtin_bit_cast(bf16x4, u32x2{m0, m1});
+    lo = __builtin_bit_cast(bf16x4, u32x2{l0, l1});
 }
 
 // (Variant tried and dropped: activations pre-split into planes by the producing kernels.  6 B/element
@@ -967,7 +986,9 @@ void launch_gemm_bf16x3(hipStream_t st, const float* A, const uint16_t* Wh, cons
                         const float* bias, const float* resid, float* C, int M, int N, int K, int epilogue) {
     if (M <= 0) return;
     dim3 grid((N / BN) * ((M + BM - 1) / BM));
-    static const bool ws = !(getenv("PCV_GEMM_WS") && getenv("PCV_GEMM_WS")[0] == '0');
+    // the persistent wave-specialised form measures the same as the plain one (both are bound by LDS
+    // traffic); kept selectable as the skeleton for a wider-tile version
+    static const bool ws = getenv("PCV_GEMM_WS") && getenv("PCV_GEMM_WS")[0] == '1';
     if (ws) {
         switch (epilogue) {
             case EPI_BIAS_GELU: launch_gemm_bf16x3_ws<EPI_BIAS_GELU>(st, A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;

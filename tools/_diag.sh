@@ -6,5 +6,6 @@ print("$name device_ms", round(d["device_ms"],3), "TF/s", round(d["roofline"]["a
 PY
 }
 COMPUTE="--compute f32" run f32 X=1
+COMPUTE="--compute bf16x3" run x3 X=1
 COMPUTE="--compute bf16x3" run x3_ws PCV_GEMM_WS=1
-COMPUTE="--compute bf16x3" run x3_old PCV_GEMM_WS=0
+COMPUTE="--compute f32 --ragged" run f32_ragged X=1
