@@ -107,8 +107,16 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # PCV_BENCH_REHEARSE=1: every rank on GPU 0 over gloo — exercises the N>1 code path (sharding,
+        # exchange, merge, reporting) on a one-GPU box; the numbers it prints mean nothing
+        rehearse = os.environ.get("PCV_BENCH_REHEARSE") == "1"
+        if rehearse:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import perceive_amd as pa
 
@@ -134,7 +142,15 @@ def main():
         # exchange of the [B][k] hit lists: torch.distributed's RCCL group (default), or the library's own
         # persistent RCCL communicator (pcv_comm_*; torch then only bootstraps the id and times the job)
         comm = pa.NativeComm.from_dist(ctx, dist) if args.collective == "native" else None
-        sharded = pa.ShardedSearcher(dist, "cosine", args.dim, searcher=searcher, ctx=ctx, device=True, comm=comm)
+        gather = None
+        if rehearse:  # gloo has no device all-gather: stage through the host (torch copies on the current stream)
+            def gather(gathered, local):
+                h = local.cpu()
+                out = torch.empty(gathered.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, h)
+                gathered.copy_(out)
+        sharded = pa.ShardedSearcher(dist, "cosine", args.dim, searcher=searcher, ctx=ctx, device=True, comm=comm,
+                                     all_gather=gather)
 
     def barrier():
         if use_dist:
@@ -171,11 +187,11 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the dominant kernel's duration: slowest rank per step decides
-        sm = torch.tensor([float(np.mean(scan_ms))], dtype=torch.float64, device="cuda")
+        sm = torch.tensor([float(np.mean(scan_ms))], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(sm, op=dist.ReduceOp.MAX)
         mean_scan_ms = float(sm.item())
     else:

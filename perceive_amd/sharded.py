@@ -105,7 +105,8 @@ class ShardedSearcher:
                   which is how the CPU tests drive the protocol without a GPU.
     """
 
-    def __init__(self, dist, metric, dim, searcher=None, ctx=None, device=True, local_search=None, comm=None):
+    def __init__(self, dist, metric, dim, searcher=None, ctx=None, device=True, local_search=None, comm=None,
+                 all_gather=None):
         self.dist = dist
         self.comm = comm  # NativeComm: exchange inside the library (pcv_searcher_search_sharded)
         self.world = comm.world if comm is not None else dist.get_world_size()
@@ -114,6 +115,9 @@ class ShardedSearcher:
         self.searcher, self.ctx = searcher, ctx
         self.device = device
         self.local_search = local_search
+        # the collective itself: (gathered, local) -> None; replaceable for rehearsals (e.g. staging
+        # device buffers through the host over gloo on a one-GPU box)
+        self._all_gather = all_gather or (lambda gathered, local: dist.all_gather_into_tensor(gathered, local))
         self._bufs = {}
         self._adopted = False
 
@@ -157,7 +161,7 @@ class ShardedSearcher:
                     if e.status != 3:  # PCV_ERR_UNSUPPORTED: needs several passes -> sequential form below
                         raise
                     break
-                self.dist.all_gather_into_tensor(gathered, local)
+                self._all_gather(gathered, local)
                 ids, scores, counts, over = merge_topk(
                     self.ctx, self.metric, self.dim, gathered.data_ptr(), self.world, B, k, flagged=True
                 )
@@ -168,7 +172,7 @@ class ShardedSearcher:
                 if attempts == 0:
                     raise RuntimeError("candidate lists still overflow after 8 reruns")
             self.searcher.search_device(sources, k, q, local.data_ptr())  # returns after its stream drained
-            self.dist.all_gather_into_tensor(gathered[: self.world * n], local[:n])
+            self._all_gather(gathered[: self.world * n], local[:n])
             torch.cuda.current_stream().synchronize()
             return merge_topk(self.ctx, self.metric, self.dim, gathered.data_ptr(), self.world, B, k)
         hits = self.local_search(q, k) if self.local_search else self._local_hits_host(sources, q, k)
