@@ -92,6 +92,20 @@ def measured_traffic(kernel, rows, dim):
         return None, None
 
 
+def measured_read_ceiling():
+    """Best streaming-read rate of tools/ubench/hbm_read.hip on this part (committed output of the round's
+    run; a plain load-only kernel over the same 153.6 GB).  Extra context for `roofline`; `peak` stays the
+    8 TB/s of the microarchitecture guide."""
+    try:
+        best = 0.0
+        for line in open(os.path.join(ROOT, "profiles", "r01_ubench_hbm_read.txt")):
+            if "GB/s best" in line:
+                best = max(best, float(line.split("GB/s avg,")[1].split("GB/s best")[0]))
+        return best or None
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,6 +254,7 @@ def main():
                 "kernel_ms": mean_scan_ms,
                 "kernel_ms_median": float(np.median(scan_ms)),
                 "kernel_ms_min": float(np.min(scan_ms)),
+                "read_ceiling_measured": measured_read_ceiling(),  # GB/s, profiles/r01_ubench_hbm_read.txt
                 "pass_ms": float(np.mean(pass_ms)),  # prep + seed + scan + rescore + select on the device
                 "host_enqueue_ms": float(np.mean([h[0] for h in host_ms])),
                 "host_wait_ms": float(np.mean([h[1] for h in host_ms])),
