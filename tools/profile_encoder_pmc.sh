@@ -1,3 +1,5 @@
+# PMC stall attribution of the encoder GEMMs (separate --pmc passes, kernel-trace only), summary in gpurun_out/pmc_enc_summary.txt.
+# COMPUTE=f32|bf16x3 gpurun -- "bash tools/profile_encoder_pmc.sh"
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 i=0

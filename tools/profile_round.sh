@@ -1,3 +1,5 @@
+# Kernel-trace statistics of the encoder (f32, bf16x3) and of the default bench, as committed under profiles/.
+# Run on the GPU box:  gpurun -- "bash tools/profile_round.sh"  then copy gpurun_out/prof/*.csv to profiles/.
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_enc -o enc -- python3 $R/tools/bench_encode.py --steps 5 --warmup 2 > $R/gpurun_out/prof_enc.log 2>&1 || exit 1
