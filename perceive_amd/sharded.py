@@ -177,7 +177,7 @@ class ShardedSearcher:
             return merge_topk(self.ctx, self.metric, self.dim, gathered.data_ptr(), self.world, B, k)
         hits = self.local_search(q, k) if self.local_search else self._local_hits_host(sources, q, k)
         local[:n].copy_(torch.from_numpy(np.ascontiguousarray(hits).view(np.uint8).reshape(-1)))
-        self.dist.all_gather_into_tensor(gathered[: self.world * n], local[:n])
+        self._all_gather(gathered[: self.world * n], local[:n])
         return merge_topk_host(self.metric, self.dim, gathered[: self.world * n].numpy(), self.world, B, k)
 
     def _local_hits_host(self, sources, q, k):

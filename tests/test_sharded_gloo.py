@@ -57,6 +57,15 @@ ss2 = pa.ShardedSearcher(dist, "cosine", D, device=False, local_search=tiny_sear
 ids2, sc2, cnt2 = ss2.search_vectors(None, 5, queries[:2])
 op2, os2, oc2 = orc.topk(queries[:2], tiny, 5)
 assert (ids2 == op2).all() and (cnt2 == 3).all()
+# a caller-supplied collective (what bench.py's one-GPU rehearsal uses) is the one that gets called
+calls = []
+def my_gather(gathered, local):
+    calls.append(local.numel())
+    dist.all_gather_into_tensor(gathered, local)
+ss3 = pa.ShardedSearcher(dist, "cosine", D, device=False, local_search=local_search, all_gather=my_gather)
+ids3, _, _ = ss3.search_vectors(None, k, queries)
+assert (ids3 == ids).all() and calls == [B * k * 24]
+assert isinstance(pa.sharded.hip_runtimes_loaded(), list)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
