@@ -252,8 +252,12 @@ enum { PCV_ACT_IDENTITY = 0, PCV_ACT_TANH = 1 };
 /* F32   : every GEMM on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), the reference's dtype.
  * BF16X3: each f32 operand is split into three bf16 terms (hi + mid + lo = 24 significand bits) and
  *         a product is six bf16 MFMAs accumulated in f32 (the lo*mid, mid*lo, lo*lo terms, < 2^-24
- *         relative, are dropped): f32-level accuracy at 6/16 of the f32-MFMA cost. */
-enum { PCV_COMPUTE_F32 = 0, PCV_COMPUTE_BF16X3 = 1 };
+ *         relative, are dropped): f32-level accuracy at 6/16 of the f32-MFMA cost.
+ * F16X2 : each f32 operand is split into two f16 terms (11 + 11 significand bits, |x - hi - lo| <= 2^-24 |x|)
+ *         and a product is three f16 MFMAs (lo*lo dropped): the same accuracy at half the matrix time of
+ *         BF16X3.  Operands are rescaled by exact powers of two so the low terms stay normal; it needs
+ *         |activation| < 4094 and |weight| < 255 (checked for weights when the model is built). */
+enum { PCV_COMPUTE_F32 = 0, PCV_COMPUTE_BF16X3 = 1, PCV_COMPUTE_F16X2 = 2 };
 
 /* Fill `d` with the all-MiniLM-L6-v2 shape. */
 void pcv_model_desc_minilm_l6(pcv_model_desc* d);

@@ -14,7 +14,7 @@ METRIC_COSINE, METRIC_DOT = 0, 1
 KERNEL_AUTO, KERNEL_WAVE, KERNEL_MFMA = 0, 1, 2
 POOL_MEAN, POOL_CLS, POOL_MAX, POOL_MEAN_SQRT_LEN = 0, 1, 2, 3
 ACT_IDENTITY, ACT_TANH = 0, 1
-COMPUTE_F32, COMPUTE_BF16X3 = 0, 1
+COMPUTE_F32, COMPUTE_BF16X3, COMPUTE_F16X2 = 0, 1, 2
 
 
 class PcvError(RuntimeError):

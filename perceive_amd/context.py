@@ -1,5 +1,6 @@
 """Device context: one process drives one GPU (one rank per device)."""
 import ctypes as C
+import weakref
 
 from . import _ffi
 
@@ -13,6 +14,12 @@ class Context:
         self._h = C.c_void_p()
         _ffi.check(_ffi.lib().pcv_init(int(device_index), C.byref(self._h)))
         self.device_index = int(device_index)
+        # handles living on this context's device and stream (Searcher, Model, NativeComm): they have to
+        # be destroyed before the context, whatever order the caller (or interpreter shutdown) picks
+        self._children = weakref.WeakSet()
+
+    def _register(self, child):
+        self._children.add(child)
 
     @property
     def handle(self):
@@ -57,8 +64,19 @@ class Context:
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                try:
+                    child.close()
+                except Exception:
+                    pass
             _ffi.lib().pcv_shutdown(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self

@@ -20,6 +20,11 @@ void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float
 // each [N][K] bf16; A is split on the fly while it is staged into LDS.
 void launch_gemm_bf16x3(hipStream_t st, const float* A, const uint16_t* Wh, const uint16_t* Wm, const uint16_t* Wl,
                         const float* bias, const float* resid, float* C, int M, int N, int K, int epilogue);
+// C = A W^T with two-term f16 splits (three v_mfma_f32_32x32x16_f16 per product); Wh/Wl = planes of 2^8 * W
+void launch_gemm_f16x2(hipStream_t st, const float* A, const uint16_t* Wh, const uint16_t* Wl, const float* bias,
+                       const float* resid, float* C, int M, int N, int K, int epilogue);
+// f32 [n] -> two f16 planes of 2^8 * x; *d_overflow (device int) is set if a weight does not fit
+void launch_split_planes_f16(hipStream_t st, const float* src, int64_t n, uint16_t* hi, uint16_t* lo, int* d_overflow);
 // f32 [n] -> three bf16 planes
 void launch_split_planes(hipStream_t st, const float* src, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo);
 

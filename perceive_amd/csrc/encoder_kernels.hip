@@ -605,6 +605,160 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_ws_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-term f16 split GEMM (PCV_COMPUTE_F16X2): x = hi + lo with hi = RN_f16(x), lo = RN_f16(x - hi).  f16
+// carries 11 significand bits, so two terms hold 22+ (|x - hi - lo| <= 2^-24 |x|, the f32 rounding unit,
+// as long as lo stays in the normal range), and
+//   a*b ~ ah*bh + ah*bl + al*bh                                  (dropped: al*bl < 2^-24 relative)
+// is THREE v_mfma_f32_32x32x16_f16 per 16-deep step against six bf16 ones — half the matrix time and two
+// thirds of the LDS traffic (the binding resource) of the three-term bf16 form, at the same
+// accuracy.  The price is f16's range: operands are scaled by exact powers of two so that the low terms stay
+// normal (activations x 2^4 while they are split, weights x 2^8 when their planes are made; the accumulator
+// is multiplied by 2^-12 in the epilogue), and |activation| must stay below 65504 / 16 — far above anything
+// a BERT-family encoder produces; weights are checked when the planes are built.
+// Same tiling, staging maps, prefetch and epilogue as gemm_bf16x3_kernel with two planes per operand.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kF16ActScale = 16.0f, kF16WeightScale = 256.0f;
+
+__device__ __forceinline__ void split2_pair(f32x2 x, uint32_t& hi, uint32_t& lo) {
+    const f16x2 h = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ void split2(const f32x4 x, float scale, f16x4& hi, f16x4& lo) {
+    uint32_t h0, l0, h1, l1;
+    split2_pair(f32x2{x.x, x.y} * scale, h0, l0);
+    split2_pair(f32x2{x.z, x.w} * scale, h1, l1);
+    hi = __builtin_bit_cast(f16x4, u32x2{h0, h1});
+    lo = __builtin_bit_cast(f16x4, u32x2{l0, l1});
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f16x2_kernel(const float* __restrict__ A, const uint16_t* __restrict__ Wh,
+                                                         const uint16_t* __restrict__ Wl,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ resid, float* __restrict__ C,
+                                                         int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][BM * LDB];
+    __shared__ __attribute__((aligned(16))) _Float16 Ws[2][BN * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    int tile_m, tile_n;
+    tile_of_block(N / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int ag_ = tid >> 3, ac4 = tid & 7;
+    const int arow = 8 * ((ag_ >> 1) >> 2) + ((ag_ >> 1) & 3) + 4 * (ag_ & 1);
+    const float* ag[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ag[u] = A + (size_t)min(m0 + arow + 32 * u, M - 1) * K + ac4 * 4;
+    const int wg_ = tid >> 3, wsub = tid & 7;
+    const int wc8 = wsub & 3;
+    const int wrow = (wg_ >> 2) * 8 + (wg_ & 3) + 4 * (wsub >> 2);
+    const size_t woff0 = (size_t)(n0 + wrow) * K + wc8 * 8;
+    const size_t woff1 = woff0 + (size_t)64 * K;
+
+    f32x4 ra[2][4];
+    f32x4 rw[2][2][2];
+    auto load_tile = [&](int set, int kt) {
+        const size_t koff = (size_t)kt * BK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ra[set][u] = *(const f32x4*)(ag[u] + koff);
+        rw[set][0][0] = *(const f32x4*)(Wh + woff0 + koff); rw[set][0][1] = *(const f32x4*)(Wh + woff1 + koff);
+        rw[set][1][0] = *(const f32x4*)(Wl + woff0 + koff); rw[set][1][1] = *(const f32x4*)(Wl + woff1 + koff);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nk = K / BK;  // even: K is a multiple of 128
+    auto step = [&](int set, int kt) {
+        __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f16x4 ph, pl;
+            split2(ra[set][u], kF16ActScale, ph, pl);
+            const int o = (arow + 32 * u) * LDB + ac4 * 4;
+            *(f16x4*)&As[0][o] = ph;
+            *(f16x4*)&As[1][o] = pl;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            *(f32x4*)&Ws[pl][wrow * LDB + wc8 * 8] = rw[set][pl][0];
+            *(f32x4*)&Ws[pl][(wrow + 64) * LDB + wc8 * 8] = rw[set][pl][1];
+        }
+        __syncthreads();
+        PCV_PIN_ORDER();  // refill pinned: see gemm_bf16x3_kernel
+        load_tile(set, min(kt + 2, nk - 1));
+        PCV_PIN_ORDER();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 af[2][2], bf[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    af[t][pl] = *(const f16x8*)&As[pl][(wr * 64 + t * 32 + i) * LDB + s * 16 + 8 * h];
+                    bf[t][pl] = *(const f16x8*)&Ws[pl][(wc * 64 + t * 32 + i) * LDB + s * 16 + 8 * h];
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    // smallest terms first
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][1], bf[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bf[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bf[b][0], acc[a][b], 0, 0, 0);
+                }
+        }
+    };
+    PCV_PIN_ORDER();
+    load_tile(0, 0);
+    PCV_PIN_ORDER();
+    load_tile(1, min(1, nk - 1));
+    PCV_PIN_ORDER();
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(0, kt);
+        step(1, kt + 1);
+    }
+    constexpr float inv = 1.0f / (kF16ActScale * kF16WeightScale);  // exact power of two
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] *= inv;
+    float bv[2];
+    load_bias2(bias, n0 + wc * 64, i, bv);
+    store_quarter<EPI>(acc, bv, resid, C, M, N, m0 + wr * 64, n0 + wc * 64, i, h);
+}
+
+// f32 [n] -> two f16 planes of 2^8 * x; *overflow is raised if a scaled weight leaves f16's range
+__global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __restrict__ src, int64_t n,
+                                                               uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                               int* __restrict__ overflow) {
+    const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= n) return;  // n is a multiple of 4 for every weight matrix
+    const f32x4 x = *(const f32x4*)(src + p);
+    f16x4 ph, pl;
+    split2(x, kF16WeightScale, ph, pl);
+    *(f16x4*)(hi + p) = ph;
+    *(f16x4*)(lo + p) = pl;
+    const float lim = 65504.0f / kF16WeightScale;
+    if (!(fabsf(x.x) < lim && fabsf(x.y) < lim && fabsf(x.z) < lim && fabsf(x.w) < lim)) *overflow = 1;
+}
+
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t n,
                                                            uint16_t* __restrict__ hi, uint16_t* __restrict__ mid,
                                                            uint16_t* __restrict__ lo) {
@@ -1006,6 +1160,24 @@ void launch_gemm_bf16x3(hipStream_t st, const float* A, const uint16_t* Wh, cons
             break;
         default: gemm_bf16x3_kernel<EPI_BIAS><<<grid, 256, 0, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;
     }
+}
+
+void launch_gemm_f16x2(hipStream_t st, const float* A, const uint16_t* Wh, const uint16_t* Wl, const float* bias,
+                       const float* resid, float* C, int M, int N, int K, int epilogue) {
+    if (M <= 0) return;
+    dim3 grid((N / BN) * ((M + BM - 1) / BM));
+    switch (epilogue) {
+        case EPI_BIAS_GELU: gemm_f16x2_kernel<EPI_BIAS_GELU><<<grid, 256, 0, st>>>(A, Wh, Wl, bias, resid, C, M, N, K); break;
+        case EPI_BIAS_RESIDUAL:
+            gemm_f16x2_kernel<EPI_BIAS_RESIDUAL><<<grid, 256, 0, st>>>(A, Wh, Wl, bias, resid, C, M, N, K);
+            break;
+        default: gemm_f16x2_kernel<EPI_BIAS><<<grid, 256, 0, st>>>(A, Wh, Wl, bias, resid, C, M, N, K); break;
+    }
+}
+
+void launch_split_planes_f16(hipStream_t st, const float* src, int64_t n, uint16_t* hi, uint16_t* lo, int* d_overflow) {
+    if (n <= 0) return;
+    split_planes_f16_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(src, n, hi, lo, d_overflow);
 }
 
 void launch_split_planes(hipStream_t st, const float* src, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo) {

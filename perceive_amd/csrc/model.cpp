@@ -21,7 +21,7 @@ struct Tensor {
     int64_t n = 0;
 };
 
-struct Planes {  // hi / mid / lo bf16 terms of an f32 weight matrix (PCV_COMPUTE_BF16X3)
+struct Planes {  // hi / mid / lo bf16 terms (PCV_COMPUTE_BF16X3) or hi / lo f16 terms of 2^8 * W (PCV_COMPUTE_F16X2)
     uint16_t* p[3] = {nullptr, nullptr, nullptr};
 };
 
@@ -85,15 +85,38 @@ Tensor alloc_tensor(pcv_model* m, int64_t n) {
 void reg(pcv_model* m, const std::string& name, float* p, int64_t n) { m->table[name] = Tensor{p, n}; }
 
 void alloc_planes(pcv_model* m, Planes& pl, int64_t n) {
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < (m->d.compute == PCV_COMPUTE_F16X2 ? 2 : 3); ++i) {
         PCV_HIP(hipMalloc((void**)&pl.p[i], (size_t)n * sizeof(uint16_t)));
         m->owned_planes.push_back(pl.p[i]);
     }
 }
 
 void refresh_planes(pcv_model* m) {
-    if (m->d.compute != PCV_COMPUTE_BF16X3 || !m->planes_dirty) return;
+    if (m->d.compute == PCV_COMPUTE_F32 || !m->planes_dirty) return;
     hipStream_t st = m->ctx->stream;
+    if (m->d.compute == PCV_COMPUTE_F16X2) {
+        int* d_over = nullptr;
+        PCV_HIP(hipMalloc((void**)&d_over, sizeof(int)));
+        int over = 0;
+        try {
+            PCV_HIP(hipMemsetAsync(d_over, 0, sizeof(int), st));
+            for (Layer& L : m->layers) {
+                launch_split_planes_f16(st, L.qkv_w.p, L.qkv_w.n, L.qkv_p.p[0], L.qkv_p.p[1], d_over);
+                launch_split_planes_f16(st, L.ao_w.p, L.ao_w.n, L.ao_p.p[0], L.ao_p.p[1], d_over);
+                launch_split_planes_f16(st, L.i_w.p, L.i_w.n, L.i_p.p[0], L.i_p.p[1], d_over);
+                launch_split_planes_f16(st, L.f_w.p, L.f_w.n, L.f_p.p[0], L.f_p.p[1], d_over);
+            }
+            PCV_HIP(hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, st));
+            PCV_HIP(hipStreamSynchronize(st));
+        } catch (...) {
+            hipFree(d_over);
+            throw;
+        }
+        hipFree(d_over);
+        if (over) PCV_FAIL(PCV_ERR_UNSUPPORTED, "PCV_COMPUTE_F16X2: a linear-layer weight is outside (-255, 255) or not finite; use PCV_COMPUTE_F32 or PCV_COMPUTE_BF16X3");
+        m->planes_dirty = false;
+        return;
+    }
     for (Layer& L : m->layers) {
         launch_split_planes(st, L.qkv_w.p, L.qkv_w.n, L.qkv_p.p[0], L.qkv_p.p[1], L.qkv_p.p[2]);
         launch_split_planes(st, L.ao_w.p, L.ao_w.n, L.ao_p.p[0], L.ao_p.p[1], L.ao_p.p[2]);
@@ -108,6 +131,8 @@ void gemm(pcv_model* m, const float* A, const Tensor& W, const Planes& P, const 
           int M, int N, int K, int epi) {
     if (m->d.compute == PCV_COMPUTE_BF16X3)
         launch_gemm_bf16x3(m->ctx->stream, A, P.p[0], P.p[1], P.p[2], bias, resid, C, M, N, K, epi);
+    else if (m->d.compute == PCV_COMPUTE_F16X2)
+        launch_gemm_f16x2(m->ctx->stream, A, P.p[0], P.p[1], bias, resid, C, M, N, K, epi);
     else
         launch_gemm_f32(m->ctx->stream, A, W.p, bias, resid, C, M, N, K, epi);
 }
@@ -140,7 +165,7 @@ void build_tensors(pcv_model* m) {
         L.f_b = alloc_tensor(m, H);
         L.ln2_w = alloc_tensor(m, H);
         L.ln2_b = alloc_tensor(m, H);
-        if (d.compute == PCV_COMPUTE_BF16X3) {
+        if (d.compute != PCV_COMPUTE_F32) {
             alloc_planes(m, L.qkv_p, 3 * H * H);
             alloc_planes(m, L.ao_p, H * H);
             alloc_planes(m, L.i_p, F * H);
@@ -410,7 +435,8 @@ pcv_status pcv_model_create(pcv_ctx* ctx, const pcv_model_desc* desc, const char
         PCV_REQUIRE(d.pooling >= PCV_POOL_MEAN && d.pooling <= PCV_POOL_MEAN_SQRT_LEN, "model_create: unknown pooling %d",
                     d.pooling);
         PCV_REQUIRE(d.dense_out >= 0 && d.dense_out <= 1024, "model_create: dense_out %d outside [0,1024]", d.dense_out);
-        PCV_REQUIRE(d.compute == PCV_COMPUTE_F32 || d.compute == PCV_COMPUTE_BF16X3, "model_create: unknown compute mode %d",
+        PCV_REQUIRE(d.compute == PCV_COMPUTE_F32 || d.compute == PCV_COMPUTE_BF16X3 || d.compute == PCV_COMPUTE_F16X2,
+                    "model_create: unknown compute mode %d",
                     d.compute);
         PCV_HIP(hipSetDevice(ctx->device));
         auto* m = new pcv_model();

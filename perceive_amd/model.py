@@ -38,10 +38,13 @@ class ModelError(RuntimeError):
     """model.rs:29-42 (`ModelError`): any failure of the device forward surfaces here."""
 
 
+_COMPUTE = {"f32": _ffi.COMPUTE_F32, "bf16x3": _ffi.COMPUTE_BF16X3, "f16x2": _ffi.COMPUTE_F16X2}
+
+
 def minilm_l6_desc(compute="f32"):
     d = _ffi.ModelDesc()
     _ffi.lib().pcv_model_desc_minilm_l6(C.byref(d))
-    d.compute = {"f32": _ffi.COMPUTE_F32, "bf16x3": _ffi.COMPUTE_BF16X3}[compute]
+    d.compute = _COMPUTE[compute]
     return d
 
 
@@ -52,7 +55,7 @@ def make_desc(vocab_size, hidden, layers, heads, intermediate, max_positions, ty
     acts = {"identity": _ffi.ACT_IDENTITY, "tanh": _ffi.ACT_TANH}
     return _ffi.ModelDesc(vocab_size, hidden, layers, heads, intermediate, max_positions, type_vocab, layer_norm_eps,
                           pools[pooling], 1 if normalize else 0, dense_out, acts[dense_activation], max_seq_length,
-                          {"f32": _ffi.COMPUTE_F32, "bf16x3": _ffi.COMPUTE_BF16X3}[compute])
+                          _COMPUTE[compute])
 
 
 def save_weights(path, tensors):
@@ -93,6 +96,7 @@ class Model:
         self._h = C.c_void_p()
         wp = weights_path.encode() if weights_path else None
         _ffi.check(_ffi.lib().pcv_model_create(ctx.handle, C.byref(self.desc), wp, int(synthetic_seed), C.byref(self._h)))
+        ctx._register(self)
 
     @property
     def output_dim(self):
@@ -290,7 +294,8 @@ class Model:
 
     def close(self):
         if self._h:
-            _ffi.lib().pcv_model_destroy(self._h)
+            if self.ctx._h:  # a context that is gone took its handles with it
+                _ffi.lib().pcv_model_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -55,6 +55,7 @@ class Searcher:
         self.metric = metric
         self._h = C.c_void_p()
         _ffi.check(_ffi.lib().pcv_searcher_create(ctx.handle, self.dim, _METRICS[metric], C.byref(self._h)))
+        ctx._register(self)
         # search.rs:31-34: ids hidden after the index was built.  Kept, and (like the reference's
         # search_vector) not consulted when searching.
         self.hidden = set()
@@ -250,7 +251,8 @@ class Searcher:
 
     def close(self):
         if self._h:
-            _ffi.lib().pcv_searcher_destroy(self._h)
+            if self.ctx._h:  # a context that is gone took its handles with it
+                _ffi.lib().pcv_searcher_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

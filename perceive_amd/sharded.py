@@ -64,6 +64,7 @@ class NativeComm:
         h = C.c_void_p()
         _ffi.check(_ffi.lib().pcv_comm_create(ctx.handle, int(world), int(rank), idb, C.byref(h)))
         self._handle, self.ctx, self.world, self.rank = h, ctx, int(world), int(rank)
+        ctx._register(self)
 
     @staticmethod
     def unique_id():

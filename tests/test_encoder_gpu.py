@@ -154,13 +154,15 @@ def test_weight_file_roundtrip_and_errors(ctx, golden_dir, tmp_path):
     assert e.value.status == 3
 
 
+@pytest.mark.parametrize("compute", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("shape", ["tiny", "minilm"])
-def test_bf16x3_mode_is_f32_accurate(ctx, oracle, golden_dir, shape):
-    # PCV_COMPUTE_BF16X3: operands split into three bf16 terms, six bf16 MFMAs per product.  Same bar
-    # as the exact-f32 mode (1e-4 on unit-norm embeddings); observed error stays at the 1e-6 level.
+def test_split_precision_modes_are_f32_accurate(ctx, oracle, golden_dir, shape, compute):
+    # PCV_COMPUTE_BF16X3: operands split into three bf16 terms, six bf16 MFMAs per product.
+    # PCV_COMPUTE_F16X2 : two f16 terms (power-of-two rescaled), three f16 MFMAs per product.
+    # Same bar as the exact-f32 mode (1e-4 on unit-norm embeddings); observed error stays at the 1e-6 level.
     if shape == "tiny":
         g, desc, weights = load_tiny(golden_dir)
-        m = make_model(ctx, desc, weights, compute="bf16x3")
+        m = make_model(ctx, desc, weights, compute=compute)
         out = m.encode_tokens(g["ids"], g["mask"])
         assert np.abs(out - g["normed"]).max() < TOL
         oout, _ = oracle.encode_tokens(desc, weights, g["ids"], g["mask"])
@@ -172,7 +174,7 @@ def test_bf16x3_mode_is_f32_accurate(ctx, oracle, golden_dir, shape):
         assert np.abs(m.encode_tokens(g["ids"], g["mask"]) - o2).max() < 2e-5
         m.close()
     else:
-        m = pa.Model(ctx, pa.minilm_l6_desc("bf16x3"), synthetic_seed=7)
+        m = pa.Model(ctx, pa.minilm_l6_desc(compute), synthetic_seed=7)
         mf = pa.Model(ctx, pa.minilm_l6_desc("f32"), synthetic_seed=7)
         rng = np.random.default_rng(2)
         toks = [list(rng.integers(1000, 30000, n)) for n in (48, 7, 31, 20, 64)]
@@ -184,6 +186,22 @@ def test_bf16x3_mode_is_f32_accurate(ctx, oracle, golden_dir, shape):
         assert np.abs(a - oout).max() < TOL
         m.close()
         mf.close()
+
+
+def test_f16x2_refuses_weights_outside_f16_range(ctx, golden_dir):
+    g, desc, weights = load_tiny(golden_dir)
+    w = dict(weights)
+    k = next(n for n in w if n.endswith("intermediate.dense.weight"))
+    w[k] = w[k].copy()
+    w[k].flat[3] = 300.0  # * 2^8 does not fit f16
+    m = make_model(ctx, desc, weights, compute="f16x2")
+    m.load_state_dict(w)
+    with pytest.raises(pa.ModelError) as e:  # ModelError::ModelPanic of the reference
+        m.encode_tokens(g["ids"], g["mask"])
+    assert "status 3" in str(e.value) and "F16X2" in str(e.value)
+    m.load_state_dict(weights)  # back in range: usable again
+    assert np.abs(m.encode_tokens(g["ids"], g["mask"]) - g["normed"]).max() < TOL
+    m.close()
 
 
 @pytest.mark.parametrize("tokens", [(1, 5), (1, 32), (2, 20), (3, 33), (8, 16), (5, 40)])

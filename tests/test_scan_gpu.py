@@ -10,6 +10,8 @@ import pytest
 
 import perceive_amd as pa
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4  # north_star: "cosine scores within 1e-4 f32"
@@ -431,6 +433,25 @@ def test_native_rccl_exchange_single_rank(ctx, oracle):
     np.testing.assert_array_equal(s.search_sharded(comm, None, k, qa)[0], oracle.topk(qa, hard, k)[0])
     comm.close()
     s.close()
+
+
+def test_process_exit_with_live_handles_is_clean():
+    # nothing closed, objects die in whatever order the interpreter picks; and a context closed before
+    # its searcher / model: the context takes its handles down first, exit code 0 either way
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import perceive_amd as pa\n"
+        "ctx = pa.Context(0); s = pa.Searcher(ctx, 64, 'cosine'); s.add_synthetic(1, 1000, 3); s.finalize()\n"
+        "m = pa.Model(ctx, pa.make_desc(300, 128, 1, 4, 256, 64), synthetic_seed=1)\n"
+        "c = pa.NativeComm(ctx, 1, 0, pa.NativeComm.unique_id())\n"
+        "print(s.search_vectors(None, 3, np.ones((1, 64), np.float32))[0][0][0])\n"
+        "MODE\n"
+    ) % ROOT
+    for mode in ("pass", "ctx.close(); s.close(); m.close(); c.close()"):
+        r = subprocess.run([sys.executable, "-c", code.replace("MODE", mode)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (mode, r.returncode, r.stderr[-800:])
 
 
 def test_error_paths(ctx):

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ragged", action="store_true", help="lengths U[32, seq] instead of all-ones masks")
-    ap.add_argument("--compute", default="f32", choices=["f32", "bf16x3"])
+    ap.add_argument("--compute", default="f32", choices=["f32", "bf16x3", "f16x2"])
     a = ap.parse_args()
     ctx = pa.Context(0)
     m = pa.Model(ctx, pa.minilm_l6_desc(a.compute), synthetic_seed=1)
