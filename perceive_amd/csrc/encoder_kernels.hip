@@ -979,14 +979,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
             }
         }
     }
+    // full query tiles store without a branch per element (see store_quarter: a branch per store costs an
+    // s_waitcnt vmcnt(0), i.e. an HBM round trip, per store)
+    float linv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) linv[r] = 1.0f / __shfl(l_run, acc_row(r, h));
+    if (qb * 32 + 32 <= L) {  // wave-uniform
+        float* const cp = ctx + (size_t)(b * L + qb * 32 + 4 * h) * H + head * HD + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) cp[(size_t)acc_row(r, 0) * H + 32 * c] = o[c][r] * linv[r];
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int q = acc_row(r, h);
-        const float linv = 1.0f / __shfl(l_run, q);
-        const int row = qb * 32 + q;
+        const int row = qb * 32 + acc_row(r, h);
         if (row < L) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c) ctx[(size_t)(b * L + row) * H + head * HD + 32 * c + i] = o[c][r] * linv;
+            for (int c = 0; c < CT; ++c) ctx[(size_t)(b * L + row) * H + head * HD + 32 * c + i] = o[c][r] * linv[r];
         }
     }
 }
