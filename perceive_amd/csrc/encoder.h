@@ -41,6 +41,10 @@ void launch_layer_norm(hipStream_t st, float* x, int T, int H, const float* w, c
 void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int H,
                       int heads);
 
+// the same with two-term f16 splits (PCV_COMPUTE_F16X2); returns false if the shape is not covered
+bool launch_attention_f16(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int H,
+                          int heads);
+
 // pooling (mean | cls | max | mean_sqrt_len) + optional L2 normalisation (worker.rs:88-103)
 void launch_pool(hipStream_t st, const float* hidden, const float* mask01, int B, int L, int H, int mode,
                  int normalize, float* out);

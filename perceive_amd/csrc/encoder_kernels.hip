@@ -765,6 +765,194 @@ __global__ __launch_bounds__(256) void split_planes_f16_kernel(const float* __re
     if (!(fabsf(x.x) < lim && fabsf(x.y) < lim && fabsf(x.z) < lim && fabsf(x.w) < lim)) *overflow = 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention with two-term f16 splits (PCV_COMPUTE_F16X2): the same S^T = K Q^T / online softmax / O += P V
+// scheme as attention_kernel, with each product as three v_mfma_f32_32x32x16_f16 on hi/lo planes —
+// 12 MFMAs of 32 cycles per 32-key tile at head_dim 32 against 32 of 64 cycles.
+//   * K is staged as [key][d] f16 hi/lo planes (rows padded by 16 B: conflict-free ds_read_b128 fragments),
+//     V as the TRANSPOSE [d][slot] with the 32 keys of a tile permuted so that the eight keys a lane owns in
+//     an S^T accumulator — acc_row(8j..8j+7, h) — are eight consecutive slots: P^T is then the B operand of
+//     P V straight from the softmax registers, and the V^T fragment is one 16-byte read.
+//   * O^T = V^T P^T puts the query on the lane for the output too: the running rescale and the final 1/l are
+//     per-lane scalars, no shuffles.
+//   * exact power-of-two scalings keep the low terms normal: Q, K, V x 2^4 while split, P x 2^10
+//     (P <= 1); undone in f32 (x 2^-8 on the scores, x 2^-14 on the output).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split2x8(const float (&x)[8], float scale, f16x8& hi, f16x8& lo) {
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2_pair(f32x2{x[2 * e], x[2 * e + 1]} * scale, hw[e], lw[e]);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    hi = __builtin_bit_cast(f16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+    lo = __builtin_bit_cast(f16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+}
+
+// NW waves per workgroup (32 queries each; K / V^T are staged once per workgroup), TPC 32-key tiles per softmax chunk
+template <int HD, int NW, int TPC>
+__global__ __launch_bounds__(NW * 64) void attention_f16_kernel(const float* __restrict__ qkv,
+                                                            const float* __restrict__ mask_add, float* __restrict__ ctx,
+                                                            int B, int L, int Lp, int H) {
+    constexpr int NC = HD / 16;      // 16-deep chunks of the head dimension (QK^T k-steps)
+    constexpr int CT = HD / 32;      // 32-row tiles of V^T / O^T
+    constexpr int KP = HD * 2 + 16;  // bytes per K row (one plane)
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_lds[];
+    const int VP = Lp * 2 + 16;  // bytes per V^T row (one plane); (VP/4) mod 64 is 4 * odd: conflict-free b128 reads
+    unsigned char* const Kh = att_lds;
+    unsigned char* const Kl = Kh + (size_t)Lp * KP;
+    unsigned char* const Vh = Kl + (size_t)Lp * KP;
+    unsigned char* const Vl = Vh + (size_t)HD * VP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int qb = blockIdx.x * NW + wave, head = blockIdx.y, b = blockIdx.z;
+    const int H3 = 3 * H;
+    constexpr float kIn = 16.0f, kP = 1024.0f;
+
+    {  // stage K: [key][d] planes; keys in [L, Lp) are zero (their scores are masked to -inf anyway)
+        constexpr int C4 = HD / 4;
+        for (int e = threadIdx.x; e < Lp * C4; e += NW * 64) {
+            const int key = e / C4, c4 = e - key * C4;
+            f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (key < L) x = *(const f32x4*)(qkv + (size_t)(b * L + key) * H3 + H + head * HD + c4 * 4);
+            f16x4 ph, pl;
+            split2(x, kIn, ph, pl);
+            *(f16x4*)(Kh + (size_t)key * KP + c4 * 8) = ph;
+            *(f16x4*)(Kl + (size_t)key * KP + c4 * 8) = pl;
+        }
+        // stage V^T: a thread takes two neighbouring keys (neighbours in slot order too) and four d
+        for (int e = threadIdx.x; e < (Lp / 2) * C4; e += NW * 64) {
+            const int kp2 = e / C4, c4 = e - kp2 * C4;
+            const int k0 = 2 * kp2;
+            f32x4 x0 = {0.0f, 0.0f, 0.0f, 0.0f}, x1 = x0;
+            if (k0 < L) x0 = *(const f32x4*)(qkv + (size_t)(b * L + k0) * H3 + 2 * H + head * HD + c4 * 4);
+            if (k0 + 1 < L) x1 = *(const f32x4*)(qkv + (size_t)(b * L + k0 + 1) * H3 + 2 * H + head * HD + c4 * 4);
+            // key = 32T + 16j + 8g + 4hh + e3  ->  slot = 32T + 16j + 8hh + 4g + e3
+            const int w = k0 & 31;
+            const int slot = (k0 & ~31) + (w & 16) + ((w & 4) << 1) + ((w & 8) >> 1) + (w & 3);
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                uint32_t hw, lw;
+                split2_pair(f32x2{x0[dd], x1[dd]} * kIn, hw, lw);
+                *(uint32_t*)(Vh + (size_t)(c4 * 4 + dd) * VP + slot * 2) = hw;
+                *(uint32_t*)(Vl + (size_t)(c4 * 4 + dd) * VP + slot * 2) = lw;
+            }
+        }
+        __syncthreads();
+    }
+    if (qb * 32 >= L) return;
+    constexpr float kLog2e = 1.44269504088896340736f;
+    const float sscale = (kLog2e / (kIn * kIn)) / sqrtf((float)HD);
+    const float ninf = -__builtin_inff();
+
+    // Q^T fragments: lane (i, h) holds query i, d = 16c + 8h .. + 7
+    f16x8 qh[NC], ql[NC];
+    {
+        const int qrow = min(qb * 32 + i, L - 1);
+        const float* qp = qkv + (size_t)(b * L + qrow) * H3 + head * HD + 8 * h;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 a = *(const f32x4*)(qp + 16 * c), bq = *(const f32x4*)(qp + 16 * c + 4);
+            const float x[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+            split2x8(x, kIn, qh[c], ql[c]);
+        }
+    }
+
+    float m_run = ninf, l_run = 0.0f;
+    f32x16 o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[c][r] = 0.0f;
+
+    for (int k0 = 0; k0 < L; k0 += 32 * TPC) {
+        f32x16 s[TPC];
+        float mc = ninf;
+#pragma unroll
+        for (int t = 0; t < TPC; ++t) {
+            const int kt = k0 + 32 * t;
+            if (kt >= L) {  // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = ninf;
+                continue;
+            }
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const size_t off = (size_t)(kt + i) * KP + (16 * c + 8 * h) * 2;
+                const f16x8 kh = *(const f16x8*)(Kh + off), kl = *(const f16x8*)(Kl + off);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[c], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], a, 0, 0, 0);
+            }
+            const float* mp = mask_add + (size_t)b * Lp + kt + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 ma = *(const float4*)(mp + 8 * g);  // keys kt + 8g + 4h + 0..3 (-inf beyond L)
+                s[t][4 * g + 0] = fmaf(a[4 * g + 0], sscale, ma.x * kLog2e);  // scores in log2 units
+                s[t][4 * g + 1] = fmaf(a[4 * g + 1], sscale, ma.y * kLog2e);
+                s[t][4 * g + 2] = fmaf(a[4 * g + 2], sscale, ma.z * kLog2e);
+                s[t][4 * g + 3] = fmaf(a[4 * g + 3], sscale, ma.w * kLog2e);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mc = fmaxf(mc, s[t][r]);
+        }
+        mc = fmaxf(mc, __shfl_xor(mc, 32));
+        const float m_new = fmaxf(m_run, mc);
+        // exp2 on scores kept in log2 units: one v_exp_f32 per probability (libm expf is ~25 VALU, and VALU
+        // time is matrix-pipe time on this part).  m_new is finite — key 0 is always a real key — so
+        // exp2(-inf - m_new) is an exact 0 for masked-out keys and no select is needed.
+        const float factor = (m_run == ninf) ? 0.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+        float lc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TPC; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[t][r] - m_new);
+                s[t][r] = p;
+                lc += p;
+            }
+        lc += __shfl_xor(lc, 32);
+        l_run = l_run * factor + lc;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[c][r] *= factor;  // the lane IS the query: its own factor
+        // O^T += V^T P^T, 16 key slots per MFMA: slots 8h..8h+7 of MFMA j are this lane's registers 8j..8j+7
+#pragma unroll
+        for (int t = 0; t < TPC; ++t) {
+            const int kt = k0 + 32 * t;
+            if (kt >= L) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float pv[8] = {s[t][8 * j], s[t][8 * j + 1], s[t][8 * j + 2], s[t][8 * j + 3],
+                                     s[t][8 * j + 4], s[t][8 * j + 5], s[t][8 * j + 6], s[t][8 * j + 7]};
+                f16x8 ph, pl;
+                split2x8(pv, kP, ph, pl);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const size_t off = (size_t)(32 * c + i) * VP + (size_t)(kt + 16 * j + 8 * h) * 2;
+                    const f16x8 vh = *(const f16x8*)(Vh + off), vl = *(const f16x8*)(Vl + off);
+                    o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[c], 0, 0, 0);
+                    o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[c], 0, 0, 0);
+                    o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // lane (i, h), register 4g + e of tile c: query i, d = 32c + 8g + 4h + e -> four consecutive floats
+    if (qb * 32 + i < L) {
+        const float fin = (1.0f / (kIn * kP)) / l_run;
+        float* const op = ctx + (size_t)(b * L + qb * 32 + i) * H + head * HD + 4 * h;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(f32x4*)(op + 32 * c + 8 * g) = f32x4{o[c][4 * g] * fin, o[c][4 * g + 1] * fin, o[c][4 * g + 2] * fin, o[c][4 * g + 3] * fin};
+    }
+}
+
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t n,
                                                            uint16_t* __restrict__ hi, uint16_t* __restrict__ mid,
                                                            uint16_t* __restrict__ lo) {
@@ -886,7 +1074,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         __syncthreads();
     }
     if (qb * 32 >= L) return;
-    const float scale = 1.0f / sqrtf((float)HD);
+    constexpr float kLog2e = 1.44269504088896340736f;
+    const float scale = kLog2e / sqrtf((float)HD);
     const float ninf = -__builtin_inff();
 
     const int qrow = min(qb * 32 + i, L - 1);
@@ -934,23 +1123,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 ma = *(const float4*)(mp + 8 * g);  // keys kt + 8g + 4h + 0..3 (-inf beyond L)
-                s[t][4 * g + 0] = a[4 * g + 0] * scale + ma.x;
-                s[t][4 * g + 1] = a[4 * g + 1] * scale + ma.y;
-                s[t][4 * g + 2] = a[4 * g + 2] * scale + ma.z;
-                s[t][4 * g + 3] = a[4 * g + 3] * scale + ma.w;
+                s[t][4 * g + 0] = fmaf(a[4 * g + 0], scale, ma.x * kLog2e);  // scores in log2 units
+                s[t][4 * g + 1] = fmaf(a[4 * g + 1], scale, ma.y * kLog2e);
+                s[t][4 * g + 2] = fmaf(a[4 * g + 2], scale, ma.z * kLog2e);
+                s[t][4 * g + 3] = fmaf(a[4 * g + 3], scale, ma.w * kLog2e);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) mc = fmaxf(mc, s[t][r]);
         }
         mc = fmaxf(mc, __shfl_xor(mc, 32));
         const float m_new = fmaxf(m_run, mc);
-        const float factor = (m_run == ninf) ? 0.0f : expf(m_run - m_new);
+        // exp2 on scores kept in log2 units: one v_exp_f32 per probability (libm expf is ~25 VALU, and VALU
+        // time is matrix-pipe time on this part).  m_new is finite — key 0 is always a real key — so
+        // exp2(-inf - m_new) is an exact 0 for masked-out keys and no select is needed.
+        const float factor = (m_run == ninf) ? 0.0f : __builtin_amdgcn_exp2f(m_run - m_new);
         float lc = 0.0f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = (s[t][r] == ninf) ? 0.0f : expf(s[t][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(s[t][r] - m_new);
                 s[t][r] = p;
                 lc += p;
             }
@@ -1220,6 +1412,40 @@ void launch_embed_ln(hipStream_t st, const int64_t* ids, const int64_t* mask, in
 
 void launch_layer_norm(hipStream_t st, float* x, int T, int H, const float* w, const float* b, float eps) {
     layer_norm_kernel<<<(T + 3) / 4, 256, 0, st>>>(x, T, H, w, b, eps);
+}
+
+// head_dim 32 / 64 with K and V^T planes resident in LDS; false when they do not fit (caller falls back to f32)
+template <int HD, int NW, int TPC>
+static void launch_attention_f16_v(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int Lp, int H,
+                                   int heads, size_t lds) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)attention_f16_kernel<HD, NW, TPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    dim3 grid((Lp / 32 + NW - 1) / NW, heads, B);
+    attention_f16_kernel<HD, NW, TPC><<<grid, NW * 64, lds, st>>>(qkv, mask_add, ctx, B, L, Lp, H);
+}
+
+bool launch_attention_f16(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int H,
+                          int heads) {
+    const int Lp = (L + 31) / 32 * 32;
+    const int HD = H / heads;
+    if (HD != 32 && HD != 64) return false;
+    const size_t lds = (size_t)2 * Lp * (HD * 2 + 16) + (size_t)2 * HD * (Lp * 2 + 16);
+    if (lds > 150 * 1024) return false;
+    // 64-key softmax chunks keep the kernel at 96 VGPRs (4+ waves per SIMD); eight waves per workgroup stage
+    // K / V^T once for 256 queries (measured on 256 x 256 tokens: 7.29 ms per forward against 7.92 ms with
+    // four waves and 128-key chunks)
+    const bool wide = Lp >= 256;
+    if (HD == 32) {
+        if (wide) launch_attention_f16_v<32, 8, 2>(st, qkv, mask_add, ctx, B, L, Lp, H, heads, lds);
+        else launch_attention_f16_v<32, 4, 2>(st, qkv, mask_add, ctx, B, L, Lp, H, heads, lds);
+    } else {
+        if (wide) launch_attention_f16_v<64, 8, 2>(st, qkv, mask_add, ctx, B, L, Lp, H, heads, lds);
+        else launch_attention_f16_v<64, 4, 2>(st, qkv, mask_add, ctx, B, L, Lp, H, heads, lds);
+    }
+    return true;
 }
 
 void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int H,

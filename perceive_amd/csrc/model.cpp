@@ -311,7 +311,8 @@ void launch_forward(pcv_model* m, int B, int L) {
     for (int ly = 0; ly < d.layers; ++ly) {
         const Layer& W = m->layers[ly];
         gemm(m, m->hidden, W.qkv_w, W.qkv_p, W.qkv_b.p, nullptr, m->qkv, T, 3 * H, H, EPI_BIAS);
-        launch_attention(st, m->qkv, m->mask_add, m->ctxbuf, B, L, H, d.heads);
+        if (!(d.compute == PCV_COMPUTE_F16X2 && launch_attention_f16(st, m->qkv, m->mask_add, m->ctxbuf, B, L, H, d.heads)))
+            launch_attention(st, m->qkv, m->mask_add, m->ctxbuf, B, L, H, d.heads);
         gemm(m, m->ctxbuf, W.ao_w, W.ao_p, W.ao_b.p, m->hidden, m->tmp, T, H, H, EPI_BIAS_RESIDUAL);
         launch_layer_norm(st, m->tmp, T, H, W.ln1_w.p, W.ln1_b.p, d.layer_norm_eps);
         gemm(m, m->tmp, W.i_w, W.i_p, W.i_b.p, nullptr, m->ff, T, F, H, EPI_BIAS_GELU);

@@ -188,6 +188,27 @@ def test_split_precision_modes_are_f32_accurate(ctx, oracle, golden_dir, shape, 
         mf.close()
 
 
+@pytest.mark.parametrize("compute", ["f32", "f16x2"])
+@pytest.mark.parametrize("heads,L", [(4, 77), (8, 40), (4, 200), (8, 129), (4, 256), (8, 250)])
+def test_attention_shapes_head_dim_64_and_32_ragged(ctx, oracle, compute, heads, L):
+    # hidden 256: head_dim 64 (4 heads) and 32 (8 heads); sequence lengths that are not multiples of 32,
+    # more than one 128-key chunk, ragged masks — both attention kernels (exact f32 and two-term f16)
+    desc = dict(vocab=400, hidden=256, layers=2, heads=heads, inter=512, max_pos=256, eps=1e-12, pooling=0, normalize=1)
+    m = make_model(ctx, desc, seed=11, compute=compute)
+    rng = np.random.default_rng(heads * 1000 + L)
+    B = 5
+    ids = rng.integers(1, 400, (B, L)).astype(np.int64)
+    mask = np.ones_like(ids)
+    for bb, n in enumerate(rng.integers(1, L + 1, B)):
+        mask[bb, n:] = 0
+    mask[0, :] = 1
+    ids *= mask
+    out = m.encode_tokens(ids, mask)
+    oout, _ = oracle.encode_tokens(desc, m.state_dict(), ids, mask)
+    assert np.abs(out - oout).max() < 2e-5
+    m.close()
+
+
 def test_f16x2_refuses_weights_outside_f16_range(ctx, golden_dir):
     g, desc, weights = load_tiny(golden_dir)
     w = dict(weights)
