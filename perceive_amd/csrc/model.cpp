@@ -525,6 +525,14 @@ pcv_status pcv_model_encode_tokens(pcv_model* m, const int64_t* ids, const int64
         PCV_HIP(hipStreamSynchronize(m->ctx->stream));
         PCV_HIP(hipGetLastError());
         finish_stats(m);
+        if (m->d.compute == PCV_COMPUTE_F16X2) {
+            // the one way this mode can fail silently: an activation beyond f16's (rescaled) range turns into inf
+            // and the embedding into NaN.  The f32 path would have produced numbers, so say so instead.
+            for (size_t e = 0; e < (size_t)B * OD; ++e)
+                if (!std::isfinite(out[e]))
+                    PCV_FAIL(PCV_ERR_UNSUPPORTED, "PCV_COMPUTE_F16X2: non-finite embedding (activation outside the f16 range?); "
+                                                  "use PCV_COMPUTE_F32 or PCV_COMPUTE_BF16X3 for this model");
+        }
     });
 }
 

@@ -209,6 +209,23 @@ def test_attention_shapes_head_dim_64_and_32_ragged(ctx, oracle, compute, heads,
     m.close()
 
 
+def test_f16x2_reports_activation_overflow(ctx, golden_dir):
+    # an FFN bias of 1e4 makes the FFN2 input exceed 65504 / 16: the f16 split turns it into inf; the
+    # library says so instead of returning NaN embeddings (the f32 mode handles the same model)
+    g, desc, weights = load_tiny(golden_dir)
+    w = dict(weights)
+    k = next(n for n in w if n.endswith("intermediate.dense.bias"))
+    w[k] = np.full_like(w[k], 1e4)
+    m = make_model(ctx, desc, w, compute="f16x2")
+    with pytest.raises(pa.ModelError) as e:
+        m.encode_tokens(g["ids"], g["mask"])
+    assert "non-finite" in str(e.value)
+    m.close()
+    mf = make_model(ctx, desc, w, compute="f32")
+    assert np.isfinite(mf.encode_tokens(g["ids"], g["mask"])).all()
+    mf.close()
+
+
 def test_f16x2_refuses_weights_outside_f16_range(ctx, golden_dir):
     g, desc, weights = load_tiny(golden_dir)
     w = dict(weights)
