@@ -11,6 +11,8 @@ import pytest
 
 import perceive_amd as pa
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
@@ -207,6 +209,32 @@ def test_attention_shapes_head_dim_64_and_32_ragged(ctx, oracle, compute, heads,
     oout, _ = oracle.encode_tokens(desc, m.state_dict(), ids, mask)
     assert np.abs(out - oout).max() < 2e-5
     m.close()
+
+
+def test_wave_specialised_bf16x3_gemm_is_bit_identical(ctx, tmp_path):
+    # PCV_GEMM_WS=1 selects the persistent producer/consumer form of the bf16x3 GEMM: same staging maps,
+    # fragment layout and product order, hence the same bits (the switch is read once per process)
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(4)
+    ids = rng.integers(1000, 30000, (6, 160)).astype(np.int64)  # 960 tokens: 8 row tiles, the last one partial
+    mask = np.ones_like(ids)
+    mask[2, 100:] = 0
+    m = pa.Model(ctx, pa.minilm_l6_desc("bf16x3"), synthetic_seed=3)
+    ref = m.encode_tokens(ids * mask, mask)
+    m.close()
+    np.save(tmp_path / "ids.npy", ids * mask)
+    np.save(tmp_path / "mask.npy", mask)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import perceive_amd as pa\n"
+        "ctx = pa.Context(0); m = pa.Model(ctx, pa.minilm_l6_desc('bf16x3'), synthetic_seed=3)\n"
+        "np.save(%r, m.encode_tokens(np.load(%r), np.load(%r)))\n"
+        "m.close(); ctx.close()\n"
+    ) % (ROOT, str(tmp_path / "out.npy"), str(tmp_path / "ids.npy"), str(tmp_path / "mask.npy"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCV_GEMM_WS="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    np.testing.assert_array_equal(np.load(tmp_path / "out.npy"), ref)
 
 
 def test_f16x2_reports_activation_overflow(ctx, golden_dir):
