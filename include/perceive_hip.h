@@ -162,8 +162,10 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
  * holds n_queries*k hits followed by ONE extra pcv_hit whose `pos` is 1 if a candidate list of this
  * pass overflowed (the results are then incomplete and the pass must be repeated), else 0.  `end` waits
  * for the stream, books the statistics and, after an overflow, enlarges the lists for the repeat.
- * No other call may use the searcher between the two.  PCV_ERR_UNSUPPORTED when the request needs more
- * than one pass (use pcv_searcher_search_device then).  Typical step:
+ * No other call may use the searcher between the two.  PCV_ERR_UNSUPPORTED only when n_queries exceeds
+ * one pass (use pcv_searcher_search_device then) — a condition every rank of a sharded search evaluates
+ * alike, so all ranks exchange the same payload; a shard that holds none of the selected sources, or more
+ * segments than one launch takes, completes inside `begin` and delivers the same layout.  Typical step:
  *   begin -> all-gather of (n*k+1)*24 bytes -> pcv_merge_topk_flagged -> end -> repeat if any_overflow. */
 pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* queries, int n_queries,
                                             const int64_t* source_ids, int n_sources, int k, void* d_out);

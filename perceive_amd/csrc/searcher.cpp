@@ -106,6 +106,7 @@ struct pcv_searcher {
     // a pass queued by enqueue_pass and not yet collected by finish_pass
     struct Pending {
         bool active = false;
+        bool done = false;  // the work was finished synchronously (nothing to collect)
         int B = 0;
         int64_t rows = 0;
     } pending;
@@ -345,6 +346,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     if (download)
         PCV_HIP(hipMemcpyAsync(s->pin->hits, out, (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
     s->pending.active = true;
+    s->pending.done = false;
     s->pending.B = B;
     s->pending.rows = rows;
     s->stats.host_enqueue_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -357,6 +359,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
 bool finish_pass(pcv_searcher* s) {
     PCV_REQUIRE(s->pending.active, "no pass is pending");
     s->pending.active = false;
+    if (s->pending.done) return false;
     const auto t_begin = std::chrono::steady_clock::now();
     PCV_HIP(hipStreamSynchronize(s->ctx->stream));
     s->stats.host_wait_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -772,13 +775,27 @@ pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* querie
         PCV_HIP(hipSetDevice(s->ctx->device));
         std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
         const int kernel = pick_kernel(s, n_queries);
-        if (segs.empty() || segs.size() > (size_t)kMaxSeg || n_queries > pass_queries(s, kernel))
-            PCV_FAIL(PCV_ERR_UNSUPPORTED, "search_device_begin: %d queries over %zu segments need more than one pass",
-                     n_queries, segs.size());
+        // Only a condition every rank evaluates alike may refuse: the ranks of a sharded search must all
+        // take the same protocol (the exchanged payload differs by the overflow record).
+        if (n_queries > pass_queries(s, kernel))
+            PCV_FAIL(PCV_ERR_UNSUPPORTED, "search_device_begin: %d queries need more than one pass", n_queries);
+        pcv_hit_dev* out = (pcv_hit_dev*)d_out;
+        const size_t n = (size_t)n_queries * k;
+        if (segs.empty() || segs.size() > (size_t)kMaxSeg) {
+            // this shard holds none of the selected rows, or more segments than one launch takes: finish
+            // here (host-merged groups), hand over the same layout with a clear overflow record
+            std::vector<pcv_hit_dev> hits;
+            search_hits(s, queries, n_queries, source_ids, n_sources, k, hits);
+            hits.push_back(pcv_hit_dev{0.0, 0, 0});
+            PCV_HIP(hipMemcpyAsync(out, hits.data(), (n + 1) * sizeof(pcv_hit_dev), hipMemcpyHostToDevice, s->ctx->stream));
+            PCV_HIP(hipStreamSynchronize(s->ctx->stream));  // `hits` dies with this scope
+            s->pending.active = true;
+            s->pending.done = true;
+            return;
+        }
         s->stats = pcv_scan_stats{};
         s->stats.kernel_used = kernel;
-        pcv_hit_dev* out = (pcv_hit_dev*)d_out;
-        enqueue_pass(s, queries, n_queries, segs.data(), (int)segs.size(), k, kernel, out, false, out + (size_t)n_queries * k);
+        enqueue_pass(s, queries, n_queries, segs.data(), (int)segs.size(), k, kernel, out, false, out + n);
     });
 }
 

@@ -371,6 +371,51 @@ def test_begin_end_protocol_two_shards(ctx, oracle):
         s.close()
 
 
+def test_begin_end_when_a_shard_holds_none_or_many_of_the_selected_sources(ctx, oracle):
+    # shard 0: sources 1..11 (11 segments > one launch group); shard 1: source 20 only.  Filtering by source
+    # leaves one shard without rows — it must still deliver the same payload layout (begin/end protocol)
+    rng = np.random.default_rng(31)
+    D, k = 64, 5
+    parts0 = [(src, rng.standard_normal((60 + src, D)).astype(np.float32)) for src in range(1, 12)]
+    part1 = rng.standard_normal((500, D)).astype(np.float32)
+    n0 = sum(p.shape[0] for _, p in parts0)
+    s0 = pa.Searcher(ctx, D, "cosine")
+    pos = 0
+    for src, m in parts0:
+        s0.add_rows(src, m, np.arange(pos, pos + m.shape[0]))
+        pos += m.shape[0]
+    s0.finalize()
+    s1 = pa.Searcher(ctx, D, "cosine")
+    s1.add_rows(20, part1, np.arange(n0, n0 + 500))
+    s1.finalize()
+    s1.set_shard_offset(n0)
+    q = rng.standard_normal((3, D)).astype(np.float32)
+    allm = np.concatenate([m for _, m in parts0] + [part1])
+    rec = 3 * k + 1
+    d = ctx.alloc(2 * rec * 24)
+
+    def step(sources):
+        for r, s in enumerate((s0, s1)):
+            s.search_device_begin(sources, k, q, d + r * rec * 24)
+            assert s.search_device_end() is False
+        ids, scores, counts, over = pa.merge_topk(ctx, "cosine", D, d, 2, 3, k, flagged=True)
+        assert over is False
+        return ids, counts
+
+    ids, counts = step([20])  # only shard 1 has it
+    np.testing.assert_array_equal(ids, oracle.topk(q, part1, k)[0] + n0)
+    ids, counts = step(None)  # everything: shard 0 needs two launch groups
+    np.testing.assert_array_equal(ids, oracle.topk(q, allm, k)[0])
+    ids, counts = step([3])  # only shard 0
+    lo = sum(p.shape[0] for src, p in parts0 if src < 3)
+    np.testing.assert_array_equal(ids, oracle.topk(q, parts0[2][1], k)[0] + lo)
+    ids, counts = step([99])  # nobody
+    assert (counts == 0).all() and (ids == -1).all()
+    ctx.free(d)
+    s0.close()
+    s1.close()
+
+
 def test_begin_end_overflow_is_repeated_by_all_shards(ctx, oracle):
     # adversarial order on shard 1 only (see test_candidate_overflow_reruns_and_stays_exact): its overflow
     # record must reach the merged flag, the step is repeated, and the answer is exact
