@@ -46,6 +46,26 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands
+    one GPU's share of the host — 16 of 256 hardware threads — to the job; starting 256 threads under a
+    16-CPU quota only adds throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(args):
     """Reference-shaped CPU leg: the oracle's multithreaded C port of lib.rs:67-77 + top-k on the
     host cores of this node, bounded sample (reported, not a target)."""
@@ -53,7 +73,7 @@ def cpu_baseline(args):
     import oracle_ffi
 
     orc = oracle_ffi.load()
-    threads = orc.hardware_threads()
+    threads = min(orc.hardware_threads(), effective_cpus())
     n = max(10_000, args.cpu_rows)
     rows = orc.synth_rows(0x5EED, 0, n, args.dim, args.normalized)
     q = orc.synth_rows(0x5EED + 1, 0, args.batch, args.dim)
@@ -73,7 +93,7 @@ def cpu_baseline(args):
         "cores": threads,
         "kind": "port",
         "sample": f"{reps} x fused f32 cosine+top-{args.k} scan of {n} x {args.dim} synthetic rows, batch={args.batch}, "
-                  f"{total:.1f} s on {threads} threads (oracle/baseline.c)",
+                  f"{total:.1f} s on {threads} threads = the job's CPU quota of {orc.hardware_threads()} hardware threads (oracle/baseline.c)",
         "queries_per_s": args.batch * reps / total,
         "reference_shaped_vectors_per_s": ns / shaped_s,
     }
