@@ -1023,6 +1023,66 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
     ln_row(v, npl, H, lane, ln_w, ln_b, eps, hidden + (size_t)tok * H);
 }
 
+// H a multiple of 64 (every BERT-family width): NPL values per lane known at compile time, TOK tokens per wave
+// with their loads and both reduction chains interleaved (the generic kernel is latency-bound: one token's two
+// dependent wave reductions per wave at a time).  Same arithmetic per token, in the same order.
+template <int NPL, int TOK>
+__global__ __launch_bounds__(256) void layer_norm_fixed_kernel(float* __restrict__ x, int T, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float eps) {
+    constexpr int H = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * TOK;
+    if (t0 >= T) return;
+    float v[TOK][NPL];
+#pragma unroll
+    for (int k = 0; k < TOK; ++k) {
+        const float* row = x + (size_t)min(t0 + k, T - 1) * H;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) v[k][j] = row[lane + 64 * j];
+    }
+    float wv[NPL], bv[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        wv[j] = w[lane + 64 * j];
+        bv[j] = b[lane + 64 * j];
+    }
+    float mean[TOK], inv[TOK];
+#pragma unroll
+    for (int k = 0; k < TOK; ++k) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) s += v[k][j];
+        mean[k] = s;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < TOK; ++k) mean[k] += __shfl_xor(mean[k], off);
+#pragma unroll
+    for (int k = 0; k < TOK; ++k) {
+        mean[k] = mean[k] / (float)H;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const float d = v[k][j] - mean[k];
+            q += d * d;
+        }
+        inv[k] = q;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < TOK; ++k) inv[k] += __shfl_xor(inv[k], off);
+#pragma unroll
+    for (int k = 0; k < TOK; ++k) {
+        if (t0 + k >= T) break;  // wave-uniform
+        const float r = 1.0f / sqrtf(inv[k] / (float)H + eps);
+        float* row = x + (size_t)(t0 + k) * H;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) row[lane + 64 * j] = (v[k][j] - mean[k]) * r * wv[j] + bv[j];
+    }
+}
+
 __global__ __launch_bounds__(256) void layer_norm_kernel(float* __restrict__ x, int T, int H,
                                                          const float* __restrict__ w, const float* __restrict__ b,
                                                          float eps) {
@@ -1412,6 +1472,14 @@ void launch_embed_ln(hipStream_t st, const int64_t* ids, const int64_t* mask, in
 }
 
 void launch_layer_norm(hipStream_t st, float* x, int T, int H, const float* w, const float* b, float eps) {
+    constexpr int TOK = 2;
+    const unsigned grid = (unsigned)((T + 4 * TOK - 1) / (4 * TOK));
+    switch (T >= 64 ? H : 0) {  // a handful of tokens: one token per wave spreads over more CUs
+        case 384: layer_norm_fixed_kernel<6, TOK><<<grid, 256, 0, st>>>(x, T, w, b, eps); return;
+        case 768: layer_norm_fixed_kernel<12, TOK><<<grid, 256, 0, st>>>(x, T, w, b, eps); return;
+        case 1024: layer_norm_fixed_kernel<16, TOK><<<grid, 256, 0, st>>>(x, T, w, b, eps); return;
+        default: break;
+    }
     layer_norm_kernel<<<(T + 3) / 4, 256, 0, st>>>(x, T, H, w, b, eps);
 }
 
