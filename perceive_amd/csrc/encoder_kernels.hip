@@ -1269,15 +1269,43 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hidden, const float* __restrict__ mask01,
                                                    int L, int H, int mode, int normalize, float* __restrict__ out) {
+    // The four waves split the tokens (wave w: l = w, w + 4, ...), every lane owning H/64 columns, and meet in
+    // LDS; one column per thread walking all L tokens left three quarters of the loads un-issued (124 us for
+    // 256 documents of 256 tokens).
     __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float part[4][1024];  // H <= 1024
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* hb = hidden + (size_t)b * L * H;
     const float* mb = mask01 + (size_t)b * L;
     float msum = 0.0f;
     for (int l = tid; l < L; l += 256) msum += mb[l];
     msum = block_sum(msum, red);
     const float den = fmaxf(msum, 1e-9f);  // clamp_min(1e-9) of rust-bert's mean pooling
-    float vals[4];                         // H <= 1024
+    const int npl = (H + 63) / 64;
+    if (mode != PCV_POOL_CLS) {
+        float acc[kMaxPerLane];
+#pragma unroll
+        for (int j = 0; j < kMaxPerLane; ++j) acc[j] = mode == PCV_POOL_MAX ? -__builtin_inff() : 0.0f;
+        for (int l = wave; l < L; l += 4) {
+            const float m = mb[l];
+            const float* row = hb + (size_t)l * H;
+#pragma unroll
+            for (int j = 0; j < kMaxPerLane; ++j) {
+                const int c = lane + 64 * j;
+                if (j < npl && c < H) {
+                    const float x = row[c];
+                    acc[j] = mode == PCV_POOL_MAX ? fmaxf(acc[j], m != 0.0f ? x : -1e9f) : acc[j] + x * m;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxPerLane; ++j) {
+            const int c = lane + 64 * j;
+            if (j < npl && c < H) part[wave][c] = acc[j];
+        }
+        __syncthreads();
+    }
+    float vals[4];
     float ss = 0.0f;
     for (int j = 0; j < 4; ++j) {
         const int c = tid + 256 * j;
@@ -1286,11 +1314,9 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hid
             if (mode == PCV_POOL_CLS) {
                 v = hb[c];
             } else if (mode == PCV_POOL_MAX) {
-                v = -__builtin_inff();
-                for (int l = 0; l < L; ++l) v = fmaxf(v, mb[l] != 0.0f ? hb[(size_t)l * H + c] : -1e9f);
+                v = fmaxf(fmaxf(part[0][c], part[1][c]), fmaxf(part[2][c], part[3][c]));
             } else {
-                float s = 0.0f;
-                for (int l = 0; l < L; ++l) s += hb[(size_t)l * H + c] * mb[l];
+                const float s = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
                 v = mode == PCV_POOL_MEAN_SQRT_LEN ? s / sqrtf(den) : s / den;
             }
         }
