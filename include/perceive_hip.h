@@ -115,6 +115,8 @@ pcv_status pcv_searcher_finalize(pcv_searcher* s);
 pcv_status pcv_searcher_num_rows(pcv_searcher* s, int64_t* out_rows);
 pcv_status pcv_searcher_num_sources(pcv_searcher* s, int* out_n);
 pcv_status pcv_searcher_source_ids(pcv_searcher* s, int64_t* out_ids, int cap);
+/* Rows held for one source (0 if the source is unknown). */
+pcv_status pcv_searcher_source_num_rows(pcv_searcher* s, int64_t source_id, int64_t* out_rows);
 /* Read rows back (row-major) by global position (sources in insertion order, rows in insertion
  * order inside a source).  Test/diagnostic path. */
 pcv_status pcv_searcher_get_rows(pcv_searcher* s, const int64_t* positions, int64_t n, float* out_rows,

@@ -29,7 +29,9 @@ from .database import (  # noqa: F401,E402
     Item,
     ItemMetadata,
     build_searcher,
+    load_searcher_cache,
     rebuild_source,
+    save_searcher_cache,
     search_and_retrieve,
     search_vector_and_retrieve,
 )

@@ -100,6 +100,7 @@ SYMBOLS = {
     "pcv_searcher_num_rows": (C.c_int, [_P, _I64P]),
     "pcv_searcher_num_sources": (C.c_int, [_P, _INTP]),
     "pcv_searcher_source_ids": (C.c_int, [_P, _I64P, C.c_int]),
+    "pcv_searcher_source_num_rows": (C.c_int, [_P, C.c_int64, _I64P]),
     "pcv_searcher_get_rows": (C.c_int, [_P, _I64P, C.c_int64, _F32P, _I64P]),
     "pcv_searcher_set_kernel": (C.c_int, [_P, C.c_int]),
     "pcv_searcher_search": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _I64P, _F32P, _INTP]),

@@ -659,6 +659,17 @@ pcv_status pcv_searcher_source_ids(pcv_searcher* s, int64_t* out_ids, int cap) {
     });
 }
 
+pcv_status pcv_searcher_source_num_rows(pcv_searcher* s, int64_t source_id, int64_t* out_rows) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && out_rows != nullptr, "source_num_rows: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->dirty, "source_num_rows: pending rows; call pcv_searcher_finalize first");
+        *out_rows = 0;
+        if (Source* src = s->find_source(source_id))
+            for (const Segment& g : src->segs) *out_rows += g.nrows;
+    });
+}
+
 pcv_status pcv_searcher_get_rows(pcv_searcher* s, const int64_t* positions, int64_t n, float* out_rows,
                                  int64_t* out_ids) {
     return guarded([&] {

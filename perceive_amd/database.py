@@ -123,3 +123,67 @@ def search_and_retrieve(searcher, database, model, sources, num_results, query):
     from .search import encode_query
 
     return search_vector_and_retrieve(searcher, database, sources, num_results, encode_query(model, query))
+
+
+# ---- packed corpus cache (start-up as a straight H2D stream instead of SQL + decode) ---------
+_CACHE_MAGIC = b"PCVS0001"
+_CACHE_CHUNK = 1 << 18  # rows per read / upload step
+
+
+def save_searcher_cache(searcher: Searcher, path, model_id=0, model_version=0):
+    """Write the searcher's rows, per source, to a flat little-endian file:
+    magic, dim i32, metric i32 (0 cosine / 1 dot), model_id u32, model_version u32, n_sources i32, then per
+    source: source_id i64, n i64, ids i64[n], rows f32[n][dim] — the blob format of search.rs:288-294, row
+    after row.  The key (model_id, model_version) is the one Searcher::build is called with."""
+    metric = {"cosine": 0, "dot": 1}[searcher.metric]
+    sources = searcher.source_ids
+    with open(path, "wb") as f:
+        f.write(_CACHE_MAGIC)
+        f.write(np.array([searcher.dim, metric], dtype="<i4").tobytes())
+        f.write(np.array([model_id, model_version], dtype="<u4").tobytes())
+        f.write(np.array([len(sources)], dtype="<i4").tobytes())
+        pos = 0
+        for sid in sources:
+            n = searcher.source_num_rows(sid)
+            f.write(np.array([sid, n], dtype="<i8").tobytes())
+            ids_at = f.tell()
+            f.write(b"\0" * (8 * n))  # ids, filled in after the rows have been streamed
+            all_ids = np.empty(n, dtype="<i8")
+            for r0 in range(0, n, _CACHE_CHUNK):
+                r1 = min(n, r0 + _CACHE_CHUNK)
+                rows, ids = searcher.get_rows(np.arange(pos + r0, pos + r1, dtype=np.int64))
+                all_ids[r0:r1] = ids
+                f.write(np.ascontiguousarray(rows, dtype="<f4").tobytes())
+            end = f.tell()
+            f.seek(ids_at)
+            f.write(all_ids.tobytes())
+            f.seek(end)
+            pos += n
+
+
+def load_searcher_cache(ctx, path, model_id=None, model_version=None) -> Searcher:
+    """Rebuild a Searcher from `save_searcher_cache` output: the file is memory-mapped and each source goes up
+    in chunks through `add_rows` (pinned staging inside the library), no decode, no SQL.  If model_id /
+    model_version are given they must match the key stored in the file."""
+    with open(path, "rb") as f:
+        if f.read(8) != _CACHE_MAGIC:
+            raise ValueError(f"{path}: not a perceive-hip corpus cache")
+        dim, metric = np.frombuffer(f.read(8), dtype="<i4")
+        mid, mver = np.frombuffer(f.read(8), dtype="<u4")
+        (nsrc,) = np.frombuffer(f.read(4), dtype="<i4")
+    if model_id is not None and (int(mid), int(mver)) != (int(model_id), int(model_version or 0)):
+        raise ValueError(f"{path}: cache holds model ({mid}, {mver}), wanted ({model_id}, {model_version})")
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    off = 28
+    s = Searcher(ctx, int(dim), "dot" if metric == 1 else "cosine")
+    for _ in range(int(nsrc)):
+        sid, n = (int(x) for x in np.frombuffer(mm[off:off + 16], dtype="<i8"))
+        off += 16
+        ids = np.frombuffer(mm[off:off + 8 * n], dtype="<i8")
+        off += 8 * n
+        rows = np.frombuffer(mm[off:off + 4 * n * int(dim)], dtype="<f4").reshape(n, int(dim))
+        off += 4 * n * int(dim)
+        for r0 in range(0, n, _CACHE_CHUNK):
+            s.add_rows(sid, rows[r0:r0 + _CACHE_CHUNK], ids[r0:r0 + _CACHE_CHUNK])
+    s.finalize()
+    return s

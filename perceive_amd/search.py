@@ -231,6 +231,11 @@ class Searcher:
         _ffi.check(_ffi.lib().pcv_searcher_source_ids(self._handle, _ffi.i64p(out), out.size))
         return [int(x) for x in out[: n.value]]
 
+    def source_num_rows(self, source_id):
+        n = C.c_int64()
+        _ffi.check(_ffi.lib().pcv_searcher_source_num_rows(self._handle, int(source_id), C.byref(n)))
+        return n.value
+
     def get_rows(self, positions):
         pos = np.ascontiguousarray(positions, dtype=np.int64)
         rows = np.empty((pos.size, self.dim), dtype=np.float32)

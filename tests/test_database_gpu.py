@@ -64,3 +64,39 @@ def test_build_search_retrieve_rebuild(ctx, oracle, tmp_path):
     assert top not in [it.id for it in s.search_vector([1, 2], 50, q)]
     rw.close()
     s.close()
+
+
+def test_packed_corpus_cache_round_trip(ctx, oracle, tmp_path):
+    # a searcher written to the flat cache file and streamed back gives the same rows, ids,
+    # sources and search results (three sources, explicit ids, dot metric = the reference Searcher's)
+    rng = np.random.default_rng(17)
+    D = 96
+    s = pa.Searcher(ctx, D, "dot")
+    parts = {}
+    for sid, n in ((7, 300), (2, 1), (40, 1500)):
+        rows = rng.standard_normal((n, D)).astype(np.float32)
+        ids = rng.permutation(10_000)[:n].astype(np.int64) + 100_000 * sid
+        s.add_rows(sid, rows, ids)
+        parts[sid] = (rows, ids)
+    s.finalize()
+    path = tmp_path / "corpus.pcvs"
+    pa.save_searcher_cache(s, path, model_id=3, model_version=1)
+    assert path.stat().st_size == 28 + sum(16 + n * 8 + n * D * 4 for n in (300, 1, 1500))
+    with pytest.raises(ValueError):
+        pa.load_searcher_cache(ctx, path, model_id=4, model_version=1)
+    t = pa.load_searcher_cache(ctx, path, model_id=3, model_version=1)
+    assert t.metric == "dot" and t.dim == D and t.source_ids == s.source_ids and t.num_rows == s.num_rows
+    for sid, (rows, ids) in parts.items():
+        assert t.source_num_rows(sid) == rows.shape[0]
+    pos = np.arange(s.num_rows)
+    r0, i0 = s.get_rows(pos)
+    r1, i1 = t.get_rows(pos)
+    np.testing.assert_array_equal(r0, r1)
+    np.testing.assert_array_equal(i0, i1)
+    q = rng.standard_normal((4, D)).astype(np.float32)
+    for sources in (None, [40], [2, 7]):
+        a, b = s.search_vectors(sources, 8, q), t.search_vectors(sources, 8, q)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    s.close()
+    t.close()
