@@ -28,7 +28,9 @@ from .database import (  # noqa: F401,E402
     Database,
     Item,
     ItemMetadata,
+    EMBEDDING_BATCH_SIZE,
     build_searcher,
+    calculate_embeddings,
     load_searcher_cache,
     rebuild_source,
     save_searcher_cache,

@@ -187,3 +187,21 @@ def load_searcher_cache(ctx, path, model_id=None, model_version=None) -> Searche
             s.add_rows(sid, rows[r0:r0 + _CACHE_CHUNK], ids[r0:r0 + _CACHE_CHUNK])
     s.finalize()
     return s
+
+
+# ---- pipeline hook (sources/pipeline/calculate_embeddings.rs:9-36) --------------------------------------------
+EMBEDDING_BATCH_SIZE = 256  # the reference batches 64 documents for its CPU model (pipeline.rs:76); a 256 x 256
+#                             token batch is what keeps an MI355X's matrix cores busy
+
+
+def calculate_embeddings(model, documents, batch_size=EMBEDDING_BATCH_SIZE):
+    """`calculate_embeddings_batch` for a list of documents: `model.encode` in batches of `batch_size`, each
+    embedding returned as the little-endian f32 blob the reference stores in `item_embeddings.embedding`
+    (update_db.rs:118-126).  Order follows the input, like the reference's drain/zip."""
+    from .search import serialize_embedding
+
+    out = []
+    for i in range(0, len(documents), batch_size):
+        emb = model.encode(documents[i:i + batch_size])
+        out.extend(serialize_embedding(row) for row in emb)
+    return out

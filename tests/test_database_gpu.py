@@ -1,6 +1,7 @@
 """GPU: Searcher::build / rebuild_source / search_vector_and_retrieve over a SQLite file shaped like
 the one the reference's pipeline writes (tables and columns named as the queries at
 search.rs:87-93,209-211 expect; the schema below is a minimal restatement for the test)."""
+import os
 import sqlite3
 
 import numpy as np
@@ -100,3 +101,21 @@ def test_packed_corpus_cache_round_trip(ctx, oracle, tmp_path):
         np.testing.assert_array_equal(a[1], b[1])
     s.close()
     t.close()
+
+
+def test_calculate_embeddings_pipeline_hook(ctx, golden_dir):
+    # calculate_embeddings.rs:9-36: documents -> model.encode in batches -> blobs in input order; the blobs
+    # decode to exactly what a single encode of the same documents returns (padding to the batch's longest
+    # document does not change a row: masked positions carry no weight)
+    tok = pa.BertTokenizer(os.path.join(golden_dir, "tokenizer_vocab.txt"))
+    m = pa.Model(ctx, pa.make_desc(tok.vocab_size, 128, 2, 4, 256, 64), synthetic_seed=2, tokenizer=tok)
+    docs = ["hello world", "the quick brown fox jumps over the lazy dog", "a", "search the index again and again " * 3,
+            "unaffable", "x y z"] * 3
+    blobs = pa.calculate_embeddings(m, docs, batch_size=4)
+    assert len(blobs) == len(docs) and all(len(b) == 128 * 4 for b in blobs)
+    whole = m.encode(docs)
+    got = np.stack([pa.deserialize_embedding(b) for b in blobs])
+    assert np.abs(got - whole).max() < 1e-6
+    assert np.abs(got[:6] - got[6:12]).max() < 1e-6  # same document in another batch (other padding length)
+    assert pa.EMBEDDING_BATCH_SIZE == 256
+    m.close()
