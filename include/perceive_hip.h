@@ -320,6 +320,12 @@ pcv_status pcv_tokenizer_special_ids(pcv_tokenizer* t, int64_t* pad, int64_t* un
  *   cap               capacity of the output arrays; out_len receives the token count */
 pcv_status pcv_tokenizer_encode(pcv_tokenizer* t, const char* text, size_t n_bytes, int max_len, int64_t* out_ids,
                                 int32_t* out_begin, int32_t* out_end, uint8_t* out_special, int cap, int* out_len);
+/* The batch form behind Model::tokenize (tokenize.rs:60-77) + generate_token_tensors (tokenize.rs:9-57):
+ * text i -> row i of out_ids ([n_texts][max_len], right-padded with pad_id), out_lens[i] = token count
+ * (truncated to max_len like pcv_tokenizer_encode).  Texts are spread over n_threads host threads
+ * (0 = all hardware threads). */
+pcv_status pcv_tokenizer_encode_batch(pcv_tokenizer* t, const char* const* texts, const size_t* n_bytes, int n_texts,
+                                      int max_len, int64_t pad_id, int64_t* out_ids, int32_t* out_lens, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -132,6 +132,8 @@ SYMBOLS = {
     "pcv_tokenizer_destroy": (C.c_int, [_P]),
     "pcv_tokenizer_vocab_size": (C.c_int, [_P, _INTP]),
     "pcv_tokenizer_special_ids": (C.c_int, [_P, _I64P, _I64P, _I64P, _I64P]),
+    "pcv_tokenizer_encode_batch": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int64,
+                                             _I64P, _INTP, C.c_int]),
     "pcv_tokenizer_encode": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.c_int, _I64P, _INTP,
                                        _INTP, _U8P, C.c_int, _INTP]),
 }

@@ -16,6 +16,10 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <atomic>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -356,6 +360,53 @@ pcv_status pcv_tokenizer_encode(pcv_tokenizer* t, const char* text, size_t n_byt
         put(0, Piece{t->cls, -1, -1, 1});
         for (size_t i = 0; i < pieces.size(); ++i) put((int)i + 1, pieces[i]);
         put(total - 1, Piece{t->sep, -1, -1, 1});
+    });
+}
+
+// Model::tokenize for a whole batch (tokenize.rs:60-77 + generate_token_tensors, tokenize.rs:9-57): every text
+// is encoded like pcv_tokenizer_encode, written right-padded with `pad_id` into row i of out_ids
+// ([n_texts][max_len]); out_lens[i] = its token count.  The texts are independent, so they are spread over
+// `n_threads` host threads (0 = hardware concurrency, capped by n_texts): the reference tokenizes on the CPU
+// too, and at GPU encode rates a single thread (~70 us per 256-token document) would be the bottleneck.
+pcv_status pcv_tokenizer_encode_batch(pcv_tokenizer* t, const char* const* texts, const size_t* n_bytes, int n_texts,
+                                      int max_len, int64_t pad_id, int64_t* out_ids, int32_t* out_lens, int n_threads) {
+    return guarded([&] {
+        PCV_REQUIRE(t != nullptr && (n_texts == 0 || (texts != nullptr && n_bytes != nullptr && out_ids != nullptr && out_lens != nullptr)),
+                    "tokenizer_encode_batch: NULL argument");
+        PCV_REQUIRE(max_len >= 2, "tokenizer_encode_batch: max_len %d leaves no room for [CLS] [SEP]", max_len);
+        PCV_REQUIRE(n_texts >= 0, "tokenizer_encode_batch: negative count");
+        auto one = [&](int i) {
+            std::vector<Piece> pieces = t->tokenize(texts[i], n_bytes[i]);
+            const size_t room = (size_t)max_len - 2;
+            if (pieces.size() > room) pieces.resize(room);
+            int64_t* row = out_ids + (size_t)i * max_len;
+            row[0] = t->cls;
+            for (size_t j = 0; j < pieces.size(); ++j) row[j + 1] = pieces[j].id;
+            row[pieces.size() + 1] = t->sep;
+            for (size_t j = pieces.size() + 2; j < (size_t)max_len; ++j) row[j] = pad_id;
+            out_lens[i] = (int32_t)pieces.size() + 2;
+        };
+        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        nt = std::max(1, std::min(nt, n_texts));
+        if (nt == 1) {
+            for (int i = 0; i < n_texts; ++i) one(i);
+            return;
+        }
+        std::atomic<int> next{0};
+        std::vector<std::thread> pool;
+        std::exception_ptr err;
+        std::mutex err_mu;
+        for (int w = 0; w < nt; ++w)
+            pool.emplace_back([&] {
+                try {
+                    for (int i = next.fetch_add(1); i < n_texts; i = next.fetch_add(1)) one(i);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    if (!err) err = std::current_exception();
+                }
+            });
+        for (auto& th : pool) th.join();
+        if (err) std::rethrow_exception(err);
     });
 }
 

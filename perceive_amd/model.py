@@ -38,6 +38,18 @@ class ModelError(RuntimeError):
     """model.rs:29-42 (`ModelError`): any failure of the device forward surfaces here."""
 
 
+def _tokenizer_threads():
+    """Host threads for batch tokenization: the CPUs this process may use (affinity mask, cgroup quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 _COMPUTE = {"f32": _ffi.COMPUTE_F32, "bf16x3": _ffi.COMPUTE_BF16X3, "f16x2": _ffi.COMPUTE_F16X2}
 
 
@@ -139,7 +151,13 @@ class Model:
         then generate_token_tensors."""
         if self.tokenizer is None:
             raise ModelError("this Model was built without a tokenizer (pass tokenizer=BertTokenizer(vocab.txt))")
-        enc = self.tokenizer.encode_list(list(inputs), self.desc.max_seq_length)
+        inputs = list(inputs)
+        if hasattr(self.tokenizer, "encode_batch_ids"):  # threaded C++ batch path; same ids as encode_list
+            ids, lens = self.tokenizer.encode_batch_ids(inputs, self.desc.max_seq_length, self.pad_token_id,
+                                                        n_threads=_tokenizer_threads())
+            ids = np.ascontiguousarray(ids[:, : int(lens.max()) if len(inputs) else 0])
+            return ids, (ids != self.pad_token_id).astype(np.int64)
+        enc = self.tokenizer.encode_list(inputs, self.desc.max_seq_length)
         return self.generate_token_tensors([e.token_ids for e in enc])
 
     def encode(self, inputs):

@@ -59,6 +59,20 @@ class BertTokenizer:
             offs = [None if sp[i] else (int(beg[i]), int(end[i])) for i in range(k)]
             return TokenizedInput([int(x) for x in ids[:k]], offs, [int(x) for x in sp[:k]])
 
+    def encode_batch_ids(self, inputs, max_len, pad_id=0, n_threads=0):
+        """All of `inputs` at once, in C++ threads: (ids [n, max_len] int64 right-padded with pad_id,
+        lens [n] int32).  What Model.tokenize needs (ids only); same tokens as encode_list."""
+        texts = [t.encode("utf-8") for t in inputs]
+        n = len(texts)
+        ids = np.empty((n, int(max_len)), np.int64)
+        lens = np.zeros(n, np.int32)
+        if n:
+            arr = (C.c_char_p * n)(*texts)
+            nb = (C.c_size_t * n)(*[len(b) for b in texts])
+            _ffi.check(_ffi.lib().pcv_tokenizer_encode_batch(self._h, arr, nb, n, int(max_len), int(pad_id), _ffi.i64p(ids),
+                                                             _ffi.i32p(lens), int(n_threads)))
+        return ids, lens
+
     def encode_list(self, inputs, max_len, truncation_strategy="LongestFirst", stride=0):
         """rust_tokenizers `encode_list` as called at tokenize.rs:64-75 / highlight.rs:32-38."""
         if truncation_strategy != "LongestFirst" or stride != 0:

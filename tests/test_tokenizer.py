@@ -36,6 +36,30 @@ def test_ids_offsets_and_masks_match_hf(golden, vocab_path):
     assert len(golden) >= 300
 
 
+def test_batch_entry_point_matches_hf_ids(golden, vocab_path):
+    # pcv_tokenizer_encode_batch (threaded, what Model.tokenize uses): same ids as the golden HF cases for every
+    # max_len, rows right-padded with the pad id, any thread count; empty input list
+    by_cfg = {}
+    for c in golden:
+        by_cfg.setdefault((c["lower"], c["strip"], c["max_len"]), []).append(c)
+    checked = 0
+    for (lower, strip, max_len), cases in by_cfg.items():
+        tok = pa.BertTokenizer(vocab_path, lower_case=lower, strip_accents=strip)
+        texts = [c["text"] for c in cases]
+        for nt in (1, 3, 0):
+            ids, lens = tok.encode_batch_ids(texts, max_len, pad_id=7, n_threads=nt)
+            assert ids.shape == (len(cases), max_len)
+            for i, c in enumerate(cases):
+                assert lens[i] == len(c["ids"]) and list(ids[i, : lens[i]]) == c["ids"], (c["text"][:40], nt)
+                assert (ids[i, lens[i]:] == 7).all()
+        checked += len(cases)
+        ids0, lens0 = tok.encode_batch_ids([], max_len)
+        assert ids0.shape == (0, max_len) and lens0.shape == (0,)
+    assert checked == len(golden)
+    with pytest.raises(pa.PcvError):
+        tok.encode_batch_ids(["a"], 1)  # no room for [CLS] [SEP]
+
+
 def test_encode_list_and_padding_layout(vocab_path):
     # Model::tokenize (tokenize.rs:60-77): encode_list -> token_ids -> generate_token_tensors
     t = pa.BertTokenizer(vocab_path)
