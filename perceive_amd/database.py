@@ -12,6 +12,8 @@ import numpy as np
 
 from .search import SearchItem, Searcher
 
+_CACHE_CHUNK = 1 << 18  # rows per read / upload step (ingestion and the packed corpus cache)
+
 
 @dataclass
 class ItemMetadata:  # lib.rs:14-21
@@ -64,6 +66,13 @@ def _load(searcher, conn, model_id, model_version, sources):
     """build_sources (search.rs:81-155): stream the join, keep rows of `sources`, group by source."""
     src_set = set(int(s) for s in sources)
     by_source = {int(s): ([], bytearray()) for s in sources}
+
+    def flush(source_id):
+        ids, blobs = by_source[source_id]
+        if ids:
+            searcher.add_blobs(source_id, bytes(blobs), len(ids), np.asarray(ids, dtype=np.int64))
+            by_source[source_id] = ([], bytearray())
+
     for item_id, source_id, blob in conn.execute(_ROWS_SQL, (model_id, model_version)):
         if source_id not in src_set:  # search.rs:106-109
             continue
@@ -72,9 +81,10 @@ def _load(searcher, conn, model_id, model_version, sources):
         ids, blobs = by_source[source_id]
         ids.append(item_id)
         blobs.extend(blob)
-    for source_id, (ids, blobs) in by_source.items():
-        if ids:
-            searcher.add_blobs(source_id, bytes(blobs), len(ids), np.asarray(ids, dtype=np.int64))
+        if len(ids) >= _CACHE_CHUNK:  # hand full chunks to the library as they arrive: bounded host memory
+            flush(source_id)
+    for source_id in list(by_source):
+        flush(source_id)
 
 
 def build_searcher(ctx, database, model_id, model_version, metric="dot", dim=None):
@@ -127,7 +137,6 @@ def search_and_retrieve(searcher, database, model, sources, num_results, query):
 
 # ---- packed corpus cache (start-up as a straight H2D stream instead of SQL + decode) ---------
 _CACHE_MAGIC = b"PCVS0001"
-_CACHE_CHUNK = 1 << 18  # rows per read / upload step
 
 
 def save_searcher_cache(searcher: Searcher, path, model_id=0, model_version=0):
