@@ -81,7 +81,7 @@ def _load(searcher, conn, model_id, model_version, sources):
         ids, blobs = by_source[source_id]
         ids.append(item_id)
         blobs.extend(blob)
-        if len(ids) >= _CACHE_CHUNK:  # hand full chunks to the library as they arrive: bounded host memory
+        if len(ids) >= _CACHE_CHUNK:  # hand full chunks over as they arrive: no second whole-corpus copy on the Python side
             flush(source_id)
     for source_id in list(by_source):
         flush(source_id)
