@@ -237,6 +237,24 @@ def test_wave_specialised_bf16x3_gemm_is_bit_identical(ctx, tmp_path):
     np.testing.assert_array_equal(np.load(tmp_path / "out.npy"), ref)
 
 
+@pytest.mark.parametrize("compute", ["f32", "bf16x3", "f16x2"])
+def test_bert_base_width_cls_pooling_no_normalisation(ctx, oracle, compute):
+    # the reference's default model (MsMarcoBertBaseDotV5) is BERT-base wide: hidden 768, 12 heads of 64, FFN 3072,
+    # CLS pooling, dot-product embeddings (no L2 normalisation).  Two layers of that width against the oracle.
+    desc = dict(vocab=1000, hidden=768, layers=2, heads=12, inter=3072, max_pos=128, eps=1e-12, pooling=1, normalize=0)
+    m = make_model(ctx, desc, seed=13, compute=compute, pooling="cls", normalize=False)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(1, 1000, (3, 70)).astype(np.int64)
+    mask = np.ones_like(ids)
+    mask[1, 33:] = 0
+    ids *= mask
+    out = m.encode_tokens(ids, mask)
+    oout, _ = oracle.encode_tokens(desc, m.state_dict(), ids, mask)
+    scale = np.abs(oout).max()
+    assert np.abs(out - oout).max() < 2e-5 * max(1.0, scale), (np.abs(out - oout).max(), scale)
+    m.close()
+
+
 def test_f16x2_reports_activation_overflow(ctx, golden_dir):
     # an FFN bias of 1e4 makes the FFN2 input exceed 65504 / 16: the f16 split turns it into inf; the
     # library says so instead of returning NaN embeddings (the f32 mode handles the same model)

@@ -25,9 +25,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ragged", action="store_true", help="lengths U[32, seq] instead of all-ones masks")
     ap.add_argument("--compute", default="f32", choices=["f32", "bf16x3", "f16x2"])
+    ap.add_argument("--model", default="minilm-l6", choices=["minilm-l6", "bert-base"],
+                    help="minilm-l6: 6 x 384, 12 heads, FFN 1536 (BASELINE configs[4]); bert-base: 12 x 768, 12 heads, FFN 3072 "
+                         "(the shape of the reference's default MsMarcoBertBaseDotV5: CLS pooling, no normalisation)")
     a = ap.parse_args()
     ctx = pa.Context(0)
-    m = pa.Model(ctx, pa.minilm_l6_desc(a.compute), synthetic_seed=1)
+    if a.model == "bert-base":
+        desc = pa.make_desc(30522, 768, 12, 12, 3072, 512, pooling="cls", normalize=False, max_seq_length=512, compute=a.compute)
+    else:
+        desc = pa.minilm_l6_desc(a.compute)
+    m = pa.Model(ctx, desc, synthetic_seed=1)
     rng = np.random.default_rng(0)
     ids = rng.integers(1000, 30000, (a.batch, a.seq)).astype(np.int64)
     mask = np.ones((a.batch, a.seq), np.int64)
@@ -47,9 +54,10 @@ def main():
     dev_ms = float(np.mean(ms))
     tf = st["flops"] / (dev_ms * 1e-3) / 1e12
     print(json.dumps({
-        "metric": "encoder tokens/sec (all-MiniLM-L6-v2 shape, f32)", "value": a.batch * a.seq * a.steps / wall,
+        "metric": f"encoder tokens/sec ({a.model} shape)", "value": a.batch * a.seq * a.steps / wall,
         "unit": "tokens/s", "ms_per_step": 1e3 * wall / a.steps, "device_ms": dev_ms, "dtype": "f32",
-        "config": {"workload": f"encode batch={a.batch} seq_len={a.seq}" + (" ragged" if a.ragged else ""), "compute": a.compute},
+        "config": {"workload": f"encode batch={a.batch} seq_len={a.seq}" + (" ragged" if a.ragged else ""), "compute": a.compute,
+                   "shape": a.model},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / F32_MFMA_PEAK_TFLOPS, "flops_per_step": st["flops"]},
         "docs_per_s": a.batch * a.steps / wall,
