@@ -6,9 +6,11 @@ model/configs.rs:97-119).  The reference reads, per model, the sentence-transfor
 
 with weights converted to rust-bert's `rust_model.ot`.  Here the weights are taken from the files the
 HF checkpoint itself ships (`model.safetensors`, or `pytorch_model.bin` loaded with
-`torch.load(weights_only=True)`), since `.ot` is a libtorch pickle.  Only BERT-type transformers
-(`ModelType::Bert`: all-MiniLM-*, msmarco-bert-base-dot-v5) are built; DistilBERT / RoBERTa / ALBERT
-variants of the enum raise ModelError (their op graphs differ).
+`torch.load(weights_only=True)`), since `.ot` is a libtorch pickle.  Built: `ModelType::Bert`
+(all-MiniLM-*, msmarco-bert-base-dot-v5) and `ModelType::DistilBert` (msmarco-distilbert-*,
+distiluse-base-multilingual-cased) — DistilBERT is the same post-LayerNorm encoder without token-type
+embeddings, so its tensors are renamed onto the BERT graph with a zero token-type row.  The RoBERTa and
+ALBERT variants of the enum raise ModelError (byte-level BPE / SentencePiece tokenizers, other op graphs).
 """
 import json
 import os
@@ -24,7 +26,34 @@ MODEL_DIRS = {
     SentenceEmbeddingsModelType.AllMiniLmL6V2: "all-MiniLM-L6-v2",
     SentenceEmbeddingsModelType.AllMiniLmL12V2: "all-MiniLM-L12-v2",
     SentenceEmbeddingsModelType.MsMarcoBertBaseDotV5: "msmarco-bert-base-dot-v5",
+    SentenceEmbeddingsModelType.MsMarcoDistilbertDotV5: "msmarco-distilbert-dot-v5",        # configs.rs:124-131
+    SentenceEmbeddingsModelType.MsMarcoDistilbertBaseTasB: "msmarco-distilbert-base-tas-b",  # configs.rs:133-140
+    SentenceEmbeddingsModelType.DistiluseBaseMultilingualCased: "distiluse-base-multilingual-cased",
 }
+
+# HF DistilBertModel tensor names -> the BERT names the encoder graph uses
+_DISTIL_RENAMES = (
+    ("transformer.layer.", "encoder.layer."),
+    (".attention.q_lin.", ".attention.self.query."),
+    (".attention.k_lin.", ".attention.self.key."),
+    (".attention.v_lin.", ".attention.self.value."),
+    (".attention.out_lin.", ".attention.output.dense."),
+    (".sa_layer_norm.", ".attention.output.LayerNorm."),
+    (".ffn.lin1.", ".intermediate.dense."),
+    (".ffn.lin2.", ".output.dense."),
+    (".output_layer_norm.", ".output.LayerNorm."),
+)
+
+
+def _distilbert_to_bert(tensors, hidden):
+    out = {}
+    for k, v in tensors.items():
+        k = k[11:] if k.startswith("distilbert.") else k
+        for a, b in _DISTIL_RENAMES:
+            k = k.replace(a, b)
+        out[k] = v
+    out["embeddings.token_type_embeddings.weight"] = np.zeros((1, hidden), np.float32)  # DistilBERT has none
+    return out
 
 
 def _read_json(path, default=None):
@@ -58,10 +87,16 @@ def parse_model_dir(directory):
     if not kinds or kinds[0] != "Transformer":
         raise ModelError(f"{directory}: first module must be a Transformer, got {kinds}")
     cfg = _read_json(os.path.join(directory, "config.json"))                            # model.rs:118-121
-    if cfg.get("model_type", "bert") != "bert":
-        raise ModelError(f"transformer type '{cfg.get('model_type')}' is not supported (BERT only)")
-    if cfg.get("hidden_act", "gelu") != "gelu":
-        raise ModelError(f"activation '{cfg.get('hidden_act')}' is not supported (erf GELU only)")
+    arch = cfg.get("model_type", "bert")
+    if arch not in ("bert", "distilbert"):
+        raise ModelError(f"transformer type '{arch}' is not supported (BERT and DistilBERT only)")
+    if cfg.get("hidden_act", cfg.get("activation", "gelu")) != "gelu":
+        raise ModelError(f"activation '{cfg.get('hidden_act', cfg.get('activation'))}' is not supported (erf GELU only)")
+    if arch == "distilbert":  # same quantities under DistilBertConfig's names
+        if cfg.get("sinusoidal_pos_embds"):
+            raise ModelError("sinusoidal position embeddings are not supported")
+        cfg = dict(cfg, hidden_size=cfg["dim"], num_hidden_layers=cfg["n_layers"], num_attention_heads=cfg["n_heads"],
+                   intermediate_size=cfg["hidden_dim"], type_vocab_size=1, layer_norm_eps=1e-12)
     sbert = _read_json(os.path.join(directory, "sentence_bert_config.json"), {})        # model.rs:93-95
     tok_cfg = _read_json(os.path.join(directory, "tokenizer_config.json"), {})          # model.rs:90-92
     pooling_dir = next((m["path"] for m in modules if m["type"].endswith("Pooling")), "1_Pooling")
@@ -93,6 +128,7 @@ def parse_model_dir(directory):
     )
     lower = tok_cfg.get("do_lower_case", sbert.get("do_lower_case", True))               # model.rs:108-110
     tok = dict(lower_case=bool(lower), strip_accents=tok_cfg.get("strip_accents"))
+    desc["_arch"] = arch
     return desc, tok, dense
 
 
@@ -101,17 +137,20 @@ def new_pretrained(ctx, model, model_data_dir=None, compute="f32"):
     `model_data_dir`, the reference's `model_data/`, configs.rs:87-95) or a path to a model directory."""
     if isinstance(model, SentenceEmbeddingsModelType):
         if model not in MODEL_DIRS:
-            raise ModelError(f"{model.name} is not a BERT-type model; only {[m.name for m in MODEL_DIRS]} are built")
+            raise ModelError(f"{model.name} is not a BERT / DistilBERT model; only {[m.name for m in MODEL_DIRS]} are built")
         directory = os.path.join(model_data_dir or os.environ.get("PERCEIVE_MODEL_DATA", "model_data"), MODEL_DIRS[model])
         model_type = model
     else:
         directory, model_type = str(model), SentenceEmbeddingsModelType.AllMiniLmL6V2
     desc_kw, tok_kw, dense = parse_model_dir(directory)
+    arch = desc_kw.pop("_arch")
     tokenizer = BertTokenizer(os.path.join(directory, "vocab.txt"), **tok_kw)            # model.rs:96-113
     d = make_desc(compute=compute, **desc_kw)
     m = Model(ctx, d, synthetic_seed=0, model_type=model_type, tokenizer=tokenizer)
     tensors = _load_tensors(directory)                                                   # var_store.load, model.rs:124
     tensors = {(k[5:] if k.startswith("bert.") else k): v for k, v in tensors.items()}
+    if arch == "distilbert":
+        tensors = _distilbert_to_bert(tensors, desc_kw["hidden"])
     if dense:
         dt = _load_tensors(os.path.join(directory, dense["path"]))
         tensors["dense.linear.weight"] = dt["linear.weight"]

@@ -65,7 +65,7 @@ def test_parse_model_dir(tmp_path, golden_dir):
     assert tok == {"lower_case": True, "strip_accents": None}  # tokenizer_config wins over sentence_bert_config
     # unsupported architectures fail loudly
     cfg = json.loads((d / "config.json").read_text())
-    cfg["model_type"] = "distilbert"
+    cfg["model_type"] = "roberta"
     (d / "config.json").write_text(json.dumps(cfg))
     with pytest.raises(pa.ModelError):
         pa.parse_model_dir(str(d))
@@ -98,5 +98,68 @@ def test_new_pretrained_matches_hf(ctx, tmp_path, golden_dir, fmt, with_dense):
     q = pa.encode_query(m, "hello world")
     np.testing.assert_allclose(q, out[0], atol=1e-6)
     m.close()
-    with pytest.raises(pa.ModelError):
+    with pytest.raises(pa.ModelError):  # no such directory
         pa.new_pretrained(ctx, pa.SentenceEmbeddingsModelType.MsMarcoDistilbertDotV5, model_data_dir=str(tmp_path))
+    with pytest.raises(pa.ModelError):  # RoBERTa / ALBERT variants are not built
+        pa.new_pretrained(ctx, pa.SentenceEmbeddingsModelType.AllDistilrobertaV1, model_data_dir=str(tmp_path))
+
+
+def make_distilbert_dir(tmp_path, golden_dir, name, pooling_cls, normalize):
+    import torch
+    from transformers import DistilBertConfig, DistilBertModel
+
+    torch.manual_seed(5)
+    d = tmp_path / name
+    d.mkdir(parents=True)
+    vocab = os.path.join(golden_dir, "tokenizer_vocab.txt")
+    nvocab = sum(1 for _ in open(vocab, encoding="utf-8"))
+    cfg = DistilBertConfig(vocab_size=nvocab, dim=128, n_layers=2, n_heads=4, hidden_dim=256, max_position_embeddings=64,
+                           activation="gelu", sinusoidal_pos_embds=False, dropout=0.0, attention_dropout=0.0)
+    model = DistilBertModel(cfg).eval()
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if v.dim() == 2:
+                v.mul_(4.0)
+    model.save_pretrained(d, safe_serialization=True)
+    shutil.copy(vocab, d / "vocab.txt")
+    mods = [{"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+            {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]
+    if normalize:
+        mods.append({"idx": 2, "name": "2", "path": "2_Normalize", "type": "sentence_transformers.models.Normalize"})
+    (d / "1_Pooling").mkdir()
+    (d / "1_Pooling" / "config.json").write_text(json.dumps({
+        "word_embedding_dimension": 128, "pooling_mode_cls_token": pooling_cls, "pooling_mode_mean_tokens": not pooling_cls,
+        "pooling_mode_max_tokens": False, "pooling_mode_mean_sqrt_len_tokens": False}))
+    (d / "modules.json").write_text(json.dumps(mods))
+    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 48, "do_lower_case": False}))
+    (d / "tokenizer_config.json").write_text(json.dumps({"do_lower_case": True}))
+    return d, model
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["MsMarcoDistilbertBaseTasB", "MsMarcoDistilbertDotV5"])
+def test_distilbert_checkpoints_match_hf(ctx, tmp_path, golden_dir, variant):
+    # ModelType::DistilBert (configs.rs:124-140): the DistilBERT tensors renamed onto the BERT graph with a zero
+    # token-type row; tas-b pools the CLS token, dot-v5 the mean; neither normalises (dot-product models)
+    import torch
+    from transformers import BertTokenizerFast
+
+    mt = getattr(pa.SentenceEmbeddingsModelType, variant)
+    cls_pool = variant == "MsMarcoDistilbertBaseTasB"
+    d, hf = make_distilbert_dir(tmp_path, golden_dir, pa.pretrained.MODEL_DIRS[mt], cls_pool, normalize=False)
+    m = pa.new_pretrained(ctx, mt, model_data_dir=str(tmp_path))
+    assert m.model_type is mt and m.desc.normalize == 0 and m.desc.type_vocab == 1
+    texts = ["Hello world", "how do transformers without token types work?", "document " * 60, "x"]
+    out = m.encode(texts)
+    tok = BertTokenizerFast(str(d / "vocab.txt"), do_lower_case=True)
+    enc = tok(texts, padding=True, truncation=True, max_length=48, return_tensors="pt")
+    with torch.no_grad():
+        h = hf(input_ids=enc["input_ids"], attention_mask=enc["attention_mask"]).last_hidden_state
+        if cls_pool:
+            ref = h[:, 0].numpy()
+        else:
+            msk = enc["attention_mask"].unsqueeze(-1).float()
+            ref = ((h * msk).sum(1) / msk.sum(1).clamp_min(1e-9)).numpy()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    m.close()
