@@ -306,6 +306,12 @@ typedef struct pcv_tokenizer pcv_tokenizer;
 /* TokenizerOption::from_file (model.rs:96-113).  strip_accents < 0: follow lower_case (the default of
  * rust_tokenizers / HF when tokenizer_config.strip_accents is absent). */
 pcv_status pcv_tokenizer_create(const char* vocab_path, int lower_case, int strip_accents, pcv_tokenizer** out);
+/* Byte-level BPE tokenizer of the RoBERTa-family models in the reference's list (AllDistilrobertaV1:
+ * `RobertaTokenizer::from_file(vocab.json, merges.txt, lower_case, add_prefix_space)` in rust_tokenizers): GPT-2
+ * pre-tokenization, bytes_to_unicode symbols, ranked merges, <s> ... </s> framing.  The handle works with
+ * pcv_tokenizer_encode / _encode_batch / _special_ids (pad = <pad>, cls = <s>, sep = </s>). */
+pcv_status pcv_tokenizer_create_bpe(const char* vocab_json_path, const char* merges_path, int add_prefix_space,
+                                    pcv_tokenizer** out);
 pcv_status pcv_tokenizer_destroy(pcv_tokenizer* t);
 pcv_status pcv_tokenizer_vocab_size(pcv_tokenizer* t, int* out_n);
 /* ids of [PAD] (get_pad_id, tokenize.rs:19), [UNK], [CLS], [SEP]; -1 when the vocab lacks one */

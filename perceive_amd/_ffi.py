@@ -129,6 +129,7 @@ SYMBOLS = {
     "pcv_model_debug_hidden": (C.c_int, [_P, C.c_int, _F32P, C.c_int64]),
     "pcv_model_last_stats": (C.c_int, [_P, C.POINTER(EncodeStats)]),
     "pcv_tokenizer_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "pcv_tokenizer_create_bpe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_P)]),
     "pcv_tokenizer_destroy": (C.c_int, [_P]),
     "pcv_tokenizer_vocab_size": (C.c_int, [_P, _INTP]),
     "pcv_tokenizer_special_ids": (C.c_int, [_P, _I64P, _I64P, _I64P, _I64P]),

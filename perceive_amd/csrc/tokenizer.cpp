@@ -20,6 +20,8 @@
 #include <exception>
 #include <mutex>
 #include <thread>
+#include <climits>
+#include <iterator>
 #include <vector>
 
 #include "common.h"
@@ -163,6 +165,17 @@ struct Piece {
 struct pcv_tokenizer {
     std::unordered_map<std::string, int64_t> vocab;
     bool lower_case = true, strip_accents = true;
+    // byte-level BPE (RoBERTa family): merge ranks keyed by "left\x01right", the 256 byte symbols of GPT-2's
+    // bytes_to_unicode, and a cache of finished words (shared by the batch threads)
+    bool bpe = false, add_prefix_space = false;
+    std::unordered_map<std::string, int> merges;
+    std::string byte_sym[256];
+    struct BpeTok {
+        int64_t id;
+        int32_t b0, b1;  // byte range inside the word
+    };
+    mutable std::unordered_map<std::string, std::vector<BpeTok>> bpe_cache;
+    mutable std::mutex bpe_mu;
     int64_t pad = -1, unk = -1, cls = -1, sep = -1, mask = -1;
     std::vector<std::pair<std::vector<uint32_t>, int64_t>> specials;  // kept whole when found in text
 
@@ -239,7 +252,144 @@ struct pcv_tokenizer {
         out.insert(out.end(), pieces.begin(), pieces.end());
     }
 
+    // ---- byte-level BPE -------------------------------------------------------------------------------
+    // GPT-2's pre-tokenizer pattern, by hand (no regex engine):
+    //   's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+
+    static bool bpe_space(uint32_t c) {  // \s: Unicode White_Space
+        return (c >= 9 && c <= 13) || c == 32 || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) ||
+               c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+    }
+    static int bpe_class(uint32_t c) {  // 0 letter, 1 number, 2 other, 3 whitespace
+        if (bpe_space(c)) return 3;
+        if (in_ranges(uni::kLetter, c)) return 0;
+        if (in_ranges(uni::kNumber, c)) return 1;
+        return 2;
+    }
+    static size_t bpe_next_pretoken(const std::vector<uint32_t>& cp, size_t i) {
+        const size_t n = cp.size();
+        if (cp[i] == '\'' && i + 1 < n) {
+            const uint32_t a = cp[i + 1], b = i + 2 < n ? cp[i + 2] : 0;
+            if (a == 's' || a == 't' || a == 'm' || a == 'd') return i + 2;
+            if ((a == 'r' && b == 'e') || (a == 'v' && b == 'e') || (a == 'l' && b == 'l')) return i + 3;
+        }
+        size_t j = i;
+        if (cp[j] == ' ' && j + 1 < n && bpe_class(cp[j + 1]) != 3) ++j;  // " ?" in front of a non-space run
+        const int cls = bpe_class(cp[j]);
+        if (cls != 3) {
+            size_t k = j + 1;
+            while (k < n && bpe_class(cp[k]) == cls) ++k;
+            return k;
+        }
+        size_t k = i;  // whitespace run: all of it at the end of the text, else all but its last char (>= 1)
+        while (k < n && bpe_space(cp[k])) ++k;
+        if (k == n || k - i == 1) return k;
+        return k - 1;
+    }
+
+    // merges of one pre-token (bytes w[0..len)): ids + byte ranges
+    std::vector<BpeTok> bpe_word(const unsigned char* w, size_t len) const {
+        const std::string key((const char*)w, len);
+        {
+            std::lock_guard<std::mutex> lk(bpe_mu);
+            auto it = bpe_cache.find(key);
+            if (it != bpe_cache.end()) return it->second;
+        }
+        struct Sym {
+            std::string s;
+            int32_t b0, b1;
+        };
+        std::vector<Sym> syms;
+        syms.reserve(len);
+        for (size_t i = 0; i < len; ++i) syms.push_back({byte_sym[w[i]], (int32_t)i, (int32_t)i + 1});
+        while (syms.size() > 1) {
+            int best = INT32_MAX;
+            std::string bl, br;
+            for (size_t i = 0; i + 1 < syms.size(); ++i) {
+                auto it = merges.find(syms[i].s + '\x01' + syms[i + 1].s);
+                if (it != merges.end() && it->second < best) {
+                    best = it->second;
+                    bl = syms[i].s;
+                    br = syms[i + 1].s;
+                }
+            }
+            if (best == INT32_MAX) break;
+            std::vector<Sym> next;
+            next.reserve(syms.size());
+            for (size_t i = 0; i < syms.size();) {
+                if (i + 1 < syms.size() && syms[i].s == bl && syms[i + 1].s == br) {
+                    next.push_back({bl + br, syms[i].b0, syms[i + 1].b1});
+                    i += 2;
+                } else {
+                    next.push_back(syms[i]);
+                    ++i;
+                }
+            }
+            syms.swap(next);
+        }
+        std::vector<BpeTok> out;
+        out.reserve(syms.size());
+        for (const Sym& y : syms) {
+            const int64_t id = lookup(y.s);
+            out.push_back({id >= 0 ? id : unk, y.b0, y.b1});
+        }
+        if (len <= 64) {
+            std::lock_guard<std::mutex> lk(bpe_mu);
+            if (bpe_cache.size() < (1u << 20)) bpe_cache.emplace(key, out);
+        }
+        return out;
+    }
+
+    std::vector<Piece> tokenize_bpe(const char* text, size_t n) const {
+        std::string buf;
+        const bool prefixed = add_prefix_space && n > 0 && text[0] != ' ';
+        if (prefixed) {
+            buf.reserve(n + 1);
+            buf.push_back(' ');
+            buf.append(text, n);
+            text = buf.data();
+            n = buf.size();
+        }
+        const std::vector<uint32_t> cp = decode_utf8(text, n);
+        std::vector<uint32_t> boff(cp.size() + 1);  // byte offset of every char
+        {
+            size_t b = 0, i = 0, ci = 0;
+            while (i < n) {  // same walk as decode_utf8
+                const unsigned char c = (unsigned char)text[i];
+                int len = 1;
+                if (c >= 0x80) {
+                    if ((c & 0xE0) == 0xC0 && i + 1 < n) len = 2;
+                    else if ((c & 0xF0) == 0xE0 && i + 2 < n) len = 3;
+                    else if ((c & 0xF8) == 0xF0 && i + 3 < n) len = 4;
+                }
+                boff[ci++] = (uint32_t)b;
+                b += len;
+                i += len;
+            }
+            boff[ci] = (uint32_t)b;
+        }
+        std::vector<int32_t> char_of(n + 1);  // char index of every byte
+        for (size_t ci = 0; ci < cp.size(); ++ci)
+            for (uint32_t b = boff[ci]; b < boff[ci + 1]; ++b) char_of[b] = (int32_t)ci;
+        std::vector<Piece> out;
+        size_t i = 0;
+        while (i < cp.size()) {
+            const size_t k = bpe_next_pretoken(cp, i);
+            const uint32_t b0 = boff[i], b1 = boff[k];
+            for (const BpeTok& tk : bpe_word((const unsigned char*)text + b0, b1 - b0)) {
+                int32_t cb = char_of[b0 + tk.b0], ce = char_of[b0 + tk.b1 - 1] + 1;
+                if (prefixed) {  // offsets are reported against the caller's text (the tokenizers library's convention)
+                    cb = cb > 0 ? cb - 1 : 0;
+                    ce = ce > 1 ? ce - 1 : ce;
+                }
+                out.push_back({tk.id, cb, ce, 0});
+            }
+            i = k;
+        }
+        return out;
+    }
+
     std::vector<Piece> tokenize(const char* text, size_t n) const {
+        if (bpe) return tokenize_bpe(text, n);
         const std::vector<uint32_t> raw = decode_utf8(text, n);
         std::vector<Piece> out;
         std::vector<Cp> word;
@@ -313,6 +463,121 @@ pcv_status pcv_tokenizer_create(const char* vocab_path, int lower_case, int stri
             const int64_t sid = t->lookup(sp);
             if (sid >= 0) t->specials.push_back({decode_utf8(sp, std::strlen(sp)), sid});
         }
+        *out = t.release();
+    });
+}
+
+namespace {
+// {"token": id, ...} — the only JSON the byte-level BPE vocabulary needs
+void parse_vocab_json(const std::string& j, std::unordered_map<std::string, int64_t>& vocab) {
+    size_t i = 0;
+    auto ws = [&] { while (i < j.size() && (j[i] == ' ' || j[i] == '\n' || j[i] == '\r' || j[i] == '\t')) ++i; };
+    auto hex4 = [&](size_t at) {
+        uint32_t v = 0;
+        for (int k = 0; k < 4; ++k) {
+            const char c = at + k < j.size() ? j[at + k] : '0';
+            v = v * 16 + (uint32_t)(c >= '0' && c <= '9' ? c - '0' : (c | 32) >= 'a' && (c | 32) <= 'f' ? (c | 32) - 'a' + 10 : 0);
+        }
+        return v;
+    };
+    ws();
+    PCV_REQUIRE(i < j.size() && j[i] == '{', "vocab.json: expected an object");
+    ++i;
+    while (true) {
+        ws();
+        if (i < j.size() && j[i] == '}') break;
+        PCV_REQUIRE(i < j.size() && j[i] == '"', "vocab.json: expected a string key at byte %zu", i);
+        ++i;
+        std::string key;
+        while (i < j.size() && j[i] != '"') {
+            if (j[i] == '\\' && i + 1 < j.size()) {
+                const char e = j[i + 1];
+                i += 2;
+                switch (e) {
+                    case 'n': key.push_back('\n'); break;
+                    case 't': key.push_back('\t'); break;
+                    case 'r': key.push_back('\r'); break;
+                    case 'b': key.push_back('\b'); break;
+                    case 'f': key.push_back('\f'); break;
+                    case 'u': {
+                        uint32_t cp = hex4(i);
+                        i += 4;
+                        if (cp >= 0xD800 && cp <= 0xDBFF && i + 5 < j.size() && j[i] == '\\' && j[i + 1] == 'u') {
+                            const uint32_t lo = hex4(i + 2);
+                            if (lo >= 0xDC00 && lo <= 0xDFFF) {
+                                cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                                i += 6;
+                            }
+                        }
+                        append_utf8(key, cp);
+                        break;
+                    }
+                    default: key.push_back(e); break;  // \" \\ \/
+                }
+            } else {
+                key.push_back(j[i++]);
+            }
+        }
+        PCV_REQUIRE(i < j.size(), "vocab.json: unterminated string");
+        ++i;
+        ws();
+        PCV_REQUIRE(i < j.size() && j[i] == ':', "vocab.json: expected ':' at byte %zu", i);
+        ++i;
+        ws();
+        int64_t v = 0;
+        bool any = false;
+        while (i < j.size() && j[i] >= '0' && j[i] <= '9') {
+            v = v * 10 + (j[i++] - '0');
+            any = true;
+        }
+        PCV_REQUIRE(any, "vocab.json: expected an integer id for \"%s\"", key.c_str());
+        vocab.emplace(key, v);
+        ws();
+        if (i < j.size() && j[i] == ',') ++i;
+    }
+}
+}  // namespace
+
+// RobertaTokenizer::from_file(vocab.json, merges.txt, .., add_prefix_space) of rust_tokenizers (what rust-bert
+// builds for ModelType::Roberta): byte-level BPE with <s> ... </s> framing.
+pcv_status pcv_tokenizer_create_bpe(const char* vocab_json_path, const char* merges_path, int add_prefix_space,
+                                    pcv_tokenizer** out) {
+    return guarded([&] {
+        PCV_REQUIRE(vocab_json_path != nullptr && merges_path != nullptr && out != nullptr, "tokenizer_create_bpe: NULL argument");
+        *out = nullptr;
+        std::ifstream vf(vocab_json_path, std::ios::binary);
+        if (!vf) PCV_FAIL(PCV_ERR_IO, "tokenizer_create_bpe: cannot open vocab file %s", vocab_json_path);
+        const std::string json((std::istreambuf_iterator<char>(vf)), std::istreambuf_iterator<char>());
+        auto t = std::make_unique<pcv_tokenizer>();
+        t->bpe = true;
+        t->add_prefix_space = add_prefix_space != 0;
+        parse_vocab_json(json, t->vocab);
+        PCV_REQUIRE(!t->vocab.empty(), "tokenizer_create_bpe: vocab file %s is empty", vocab_json_path);
+        std::ifstream mf(merges_path, std::ios::binary);
+        if (!mf) PCV_FAIL(PCV_ERR_IO, "tokenizer_create_bpe: cannot open merges file %s", merges_path);
+        std::string line;
+        int rank = 0;
+        while (std::getline(mf, line)) {
+            while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+            if (line.empty() || line.rfind("#version", 0) == 0) continue;
+            const size_t sp = line.find(' ');
+            if (sp == std::string::npos) continue;
+            t->merges.emplace(line.substr(0, sp) + '\x01' + line.substr(sp + 1), rank++);
+        }
+        {  // bytes_to_unicode of GPT-2: printable bytes map to themselves, the rest to U+0100...
+            int extra = 0;
+            for (int b = 0; b < 256; ++b) {
+                const bool keep = (b >= 33 && b <= 126) || (b >= 161 && b <= 172) || (b >= 174 && b <= 255);
+                append_utf8(t->byte_sym[b], keep ? (uint32_t)b : (uint32_t)(256 + extra++));
+            }
+        }
+        t->pad = t->lookup("<pad>");
+        t->unk = t->lookup("<unk>");
+        t->cls = t->lookup("<s>");
+        t->sep = t->lookup("</s>");
+        t->mask = t->lookup("<mask>");
+        if (t->unk < 0 || t->cls < 0 || t->sep < 0)
+            PCV_FAIL(PCV_ERR_IO, "tokenizer_create_bpe: vocab %s lacks <unk>/<s>/</s>", vocab_json_path);
         *out = t.release();
     });
 }

@@ -9,8 +9,9 @@ HF checkpoint itself ships (`model.safetensors`, or `pytorch_model.bin` loaded w
 `torch.load(weights_only=True)`), since `.ot` is a libtorch pickle.  Built: `ModelType::Bert`
 (all-MiniLM-*, msmarco-bert-base-dot-v5) and `ModelType::DistilBert` (msmarco-distilbert-*,
 distiluse-base-multilingual-cased) — DistilBERT is the same post-LayerNorm encoder without token-type
-embeddings, so its tensors are renamed onto the BERT graph with a zero token-type row.  The RoBERTa and
-ALBERT variants of the enum raise ModelError (byte-level BPE / SentencePiece tokenizers, other op graphs).
+embeddings, so its tensors are renamed onto the BERT graph with a zero token-type row — and `ModelType::Roberta`
+(all-distilroberta-v1): the BERT graph with a byte-level BPE tokenizer and the position table read from row
+padding_idx + 1.  The ALBERT variant raises ModelError (SentencePiece tokenizer, factorised embeddings).
 """
 import json
 import os
@@ -19,7 +20,7 @@ import numpy as np
 
 from . import _ffi
 from .model import Model, ModelError, SentenceEmbeddingsModelType, make_desc
-from .tokenizer import BertTokenizer
+from .tokenizer import BertTokenizer, RobertaTokenizer
 
 # configs.rs:42-69,121-141: directory names of the enum variants (sentence-transformers repo names)
 MODEL_DIRS = {
@@ -29,6 +30,7 @@ MODEL_DIRS = {
     SentenceEmbeddingsModelType.MsMarcoDistilbertDotV5: "msmarco-distilbert-dot-v5",        # configs.rs:124-131
     SentenceEmbeddingsModelType.MsMarcoDistilbertBaseTasB: "msmarco-distilbert-base-tas-b",  # configs.rs:133-140
     SentenceEmbeddingsModelType.DistiluseBaseMultilingualCased: "distiluse-base-multilingual-cased",
+    SentenceEmbeddingsModelType.AllDistilrobertaV1: "all-distilroberta-v1",
 }
 
 # HF DistilBertModel tensor names -> the BERT names the encoder graph uses
@@ -88,8 +90,8 @@ def parse_model_dir(directory):
         raise ModelError(f"{directory}: first module must be a Transformer, got {kinds}")
     cfg = _read_json(os.path.join(directory, "config.json"))                            # model.rs:118-121
     arch = cfg.get("model_type", "bert")
-    if arch not in ("bert", "distilbert"):
-        raise ModelError(f"transformer type '{arch}' is not supported (BERT and DistilBERT only)")
+    if arch not in ("bert", "distilbert", "roberta"):
+        raise ModelError(f"transformer type '{arch}' is not supported (BERT, DistilBERT and RoBERTa only)")
     if cfg.get("hidden_act", cfg.get("activation", "gelu")) != "gelu":
         raise ModelError(f"activation '{cfg.get('hidden_act', cfg.get('activation'))}' is not supported (erf GELU only)")
     if arch == "distilbert":  # same quantities under DistilBertConfig's names
@@ -128,6 +130,12 @@ def parse_model_dir(directory):
     )
     lower = tok_cfg.get("do_lower_case", sbert.get("do_lower_case", True))               # model.rs:108-110
     tok = dict(lower_case=bool(lower), strip_accents=tok_cfg.get("strip_accents"))
+    if arch == "roberta":
+        # RoBERTa numbers positions from padding_idx + 1 (pad tokens sit at padding_idx): for right-padded batches
+        # token l has position l + pad + 1, so the table is used from that row on (see new_pretrained)
+        desc["_pos_shift"] = int(cfg.get("pad_token_id", 1)) + 1
+        desc["max_positions"] = cfg["max_position_embeddings"] - desc["_pos_shift"]
+        tok = dict(add_prefix_space=bool(tok_cfg.get("add_prefix_space", False)))
     desc["_arch"] = arch
     return desc, tok, dense
 
@@ -137,18 +145,25 @@ def new_pretrained(ctx, model, model_data_dir=None, compute="f32"):
     `model_data_dir`, the reference's `model_data/`, configs.rs:87-95) or a path to a model directory."""
     if isinstance(model, SentenceEmbeddingsModelType):
         if model not in MODEL_DIRS:
-            raise ModelError(f"{model.name} is not a BERT / DistilBERT model; only {[m.name for m in MODEL_DIRS]} are built")
+            raise ModelError(f"{model.name} is not a BERT / DistilBERT / RoBERTa model; only {[m.name for m in MODEL_DIRS]} are built")
         directory = os.path.join(model_data_dir or os.environ.get("PERCEIVE_MODEL_DATA", "model_data"), MODEL_DIRS[model])
         model_type = model
     else:
         directory, model_type = str(model), SentenceEmbeddingsModelType.AllMiniLmL6V2
     desc_kw, tok_kw, dense = parse_model_dir(directory)
     arch = desc_kw.pop("_arch")
-    tokenizer = BertTokenizer(os.path.join(directory, "vocab.txt"), **tok_kw)            # model.rs:96-113
+    pos_shift = desc_kw.pop("_pos_shift", 0)
+    if arch == "roberta":
+        tokenizer = RobertaTokenizer(os.path.join(directory, "vocab.json"), os.path.join(directory, "merges.txt"), **tok_kw)
+    else:
+        tokenizer = BertTokenizer(os.path.join(directory, "vocab.txt"), **tok_kw)        # model.rs:96-113
     d = make_desc(compute=compute, **desc_kw)
     m = Model(ctx, d, synthetic_seed=0, model_type=model_type, tokenizer=tokenizer)
     tensors = _load_tensors(directory)                                                   # var_store.load, model.rs:124
-    tensors = {(k[5:] if k.startswith("bert.") else k): v for k, v in tensors.items()}
+    tensors = {(k[5:] if k.startswith("bert.") else k[8:] if k.startswith("roberta.") else k): v for k, v in tensors.items()}
+    if pos_shift:
+        tensors["embeddings.position_embeddings.weight"] = np.ascontiguousarray(
+            tensors["embeddings.position_embeddings.weight"][pos_shift:])
     if arch == "distilbert":
         tensors = _distilbert_to_bert(tensors, desc_kw["hidden"])
     if dense:

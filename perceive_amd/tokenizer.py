@@ -89,3 +89,17 @@ class BertTokenizer:
             self.close()
         except Exception:
             pass
+
+
+class RobertaTokenizer(BertTokenizer):
+    """TokenizerOption::from_file(Roberta, vocab.json, merges.txt, .., add_prefix_space) — the byte-level BPE
+    tokenizer of the RoBERTa-family entries of the reference's model list (all-distilroberta-v1).  Same methods
+    as BertTokenizer (`encode`, `encode_list`, `encode_batch_ids`); cls / sep / pad are <s> / </s> / <pad>."""
+
+    def __init__(self, vocab_json_path, merges_path, add_prefix_space=False):
+        self._h = C.c_void_p()
+        _ffi.check(_ffi.lib().pcv_tokenizer_create_bpe(str(vocab_json_path).encode(), str(merges_path).encode(),
+                                                       1 if add_prefix_space else 0, C.byref(self._h)))
+        ids = [C.c_int64() for _ in range(4)]
+        _ffi.check(_ffi.lib().pcv_tokenizer_special_ids(self._h, *[C.byref(x) for x in ids]))
+        self.pad_id, self.unk_id, self.cls_id, self.sep_id = [x.value for x in ids]

@@ -65,7 +65,7 @@ def test_parse_model_dir(tmp_path, golden_dir):
     assert tok == {"lower_case": True, "strip_accents": None}  # tokenizer_config wins over sentence_bert_config
     # unsupported architectures fail loudly
     cfg = json.loads((d / "config.json").read_text())
-    cfg["model_type"] = "roberta"
+    cfg["model_type"] = "albert"
     (d / "config.json").write_text(json.dumps(cfg))
     with pytest.raises(pa.ModelError):
         pa.parse_model_dir(str(d))
@@ -100,8 +100,8 @@ def test_new_pretrained_matches_hf(ctx, tmp_path, golden_dir, fmt, with_dense):
     m.close()
     with pytest.raises(pa.ModelError):  # no such directory
         pa.new_pretrained(ctx, pa.SentenceEmbeddingsModelType.MsMarcoDistilbertDotV5, model_data_dir=str(tmp_path))
-    with pytest.raises(pa.ModelError):  # RoBERTa / ALBERT variants are not built
-        pa.new_pretrained(ctx, pa.SentenceEmbeddingsModelType.AllDistilrobertaV1, model_data_dir=str(tmp_path))
+    with pytest.raises(pa.ModelError):  # the ALBERT variant is not built
+        pa.new_pretrained(ctx, pa.SentenceEmbeddingsModelType.ParaphraseAlbertSmallV2, model_data_dir=str(tmp_path))
 
 
 def make_distilbert_dir(tmp_path, golden_dir, name, pooling_cls, normalize):
@@ -162,4 +162,56 @@ def test_distilbert_checkpoints_match_hf(ctx, tmp_path, golden_dir, variant):
             ref = ((h * msk).sum(1) / msk.sum(1).clamp_min(1e-9)).numpy()
     assert out.shape == ref.shape
     assert np.abs(out - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    m.close()
+
+
+@pytest.mark.gpu
+def test_roberta_checkpoint_matches_hf(ctx, tmp_path, golden_dir):
+    # ModelType::Roberta (all-distilroberta-v1): byte-level BPE tokenizer + position ids from padding_idx + 1.
+    # Expected values: HF RobertaModel on ids made by the `tokenizers` library from the same vocab / merges.
+    import torch
+    from tokenizers import ByteLevelBPETokenizer
+    from transformers import RobertaConfig, RobertaModel
+
+    torch.manual_seed(9)
+    mt = pa.SentenceEmbeddingsModelType.AllDistilrobertaV1
+    d = tmp_path / pa.pretrained.MODEL_DIRS[mt]
+    d.mkdir(parents=True)
+    shutil.copy(os.path.join(golden_dir, "bpe_vocab.json"), d / "vocab.json")
+    shutil.copy(os.path.join(golden_dir, "bpe_merges.txt"), d / "merges.txt")
+    nvocab = len(json.load(open(d / "vocab.json", encoding="utf-8")))
+    cfg = RobertaConfig(vocab_size=nvocab, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+                        max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0,
+                        eos_token_id=2, hidden_act="gelu")
+    hf = RobertaModel(cfg, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for k, v in hf.state_dict().items():
+            if v.dim() == 2:
+                v.mul_(4.0)
+    hf.save_pretrained(d, safe_serialization=True)
+    (d / "1_Pooling").mkdir()
+    (d / "1_Pooling" / "config.json").write_text(json.dumps({
+        "word_embedding_dimension": 128, "pooling_mode_cls_token": False, "pooling_mode_mean_tokens": True,
+        "pooling_mode_max_tokens": False, "pooling_mode_mean_sqrt_len_tokens": False}))
+    (d / "modules.json").write_text(json.dumps([
+        {"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+        {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"},
+        {"idx": 2, "name": "2", "path": "2_Normalize", "type": "sentence_transformers.models.Normalize"}]))
+    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 40, "do_lower_case": False}))
+    (d / "tokenizer_config.json").write_text(json.dumps({"add_prefix_space": False}))
+    m = pa.new_pretrained(ctx, mt, model_data_dir=str(tmp_path))
+    assert m.pad_token_id == 1 and m.desc.max_positions == 64 and m.desc.type_vocab == 1
+    texts = ["Hello world", "don't stop searching, it's 1234 times faster!", "word " * 60, "Ünïcödé 中文 🙂"]
+    out = m.encode(texts)
+    tok = ByteLevelBPETokenizer(str(d / "vocab.json"), str(d / "merges.txt"))
+    rows = [[0] + tok.encode(t).ids[:38] + [2] for t in texts]
+    L = max(len(r) for r in rows)
+    ids = torch.tensor([r + [1] * (L - len(r)) for r in rows])
+    am = (ids != 1).long()
+    with torch.no_grad():
+        h = hf(input_ids=ids, attention_mask=am).last_hidden_state
+        msk = am.unsqueeze(-1).float()
+        pooled = (h * msk).sum(1) / msk.sum(1).clamp_min(1e-9)
+        ref = (pooled / pooled.norm(dim=1, keepdim=True).clamp_min(1e-12)).numpy()
+    assert np.abs(out - ref).max() < 1e-4
     m.close()

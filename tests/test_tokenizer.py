@@ -87,3 +87,27 @@ def test_errors(tmp_path, vocab_path):
     t = pa.BertTokenizer(vocab_path)
     with pytest.raises(pa.PcvError):
         t.encode("hello", 1)
+
+
+def test_byte_level_bpe_matches_the_tokenizers_library(golden_dir):
+    # RoBERTa-family tokenizer: ids and character offsets against Hugging Face `tokenizers` on a vocabulary
+    # trained by tests/golden/gen_bpe_golden.py (110 cases: contractions, digits, whitespace runs of every kind,
+    # NBSP / ideographic space, CJK, emoji split across tokens, both add_prefix_space settings)
+    cases = json.load(open(os.path.join(golden_dir, "bpe_golden.json"), encoding="utf-8"))
+    toks = {p: pa.RobertaTokenizer(os.path.join(golden_dir, "bpe_vocab.json"), os.path.join(golden_dir, "bpe_merges.txt"),
+                                   add_prefix_space=p) for p in (False, True)}
+    assert toks[False].cls_id == 0 and toks[False].pad_id == 1 and toks[False].sep_id == 2 and toks[False].unk_id == 3
+    bad = []
+    for c in cases:
+        enc = toks[c["add_prefix_space"]].encode(c["text"], 4096)
+        ids = enc.token_ids[1:-1]
+        offs = [list(o) for o in enc.token_offsets[1:-1]]
+        if ids != c["ids"] or offs != c["offsets"] or enc.token_ids[0] != 0 or enc.token_ids[-1] != 2:
+            bad.append((c["text"][:40], c["add_prefix_space"], ids[:12], c["ids"][:12], offs[:6], c["offsets"][:6]))
+    assert not bad, f"{len(bad)} of {len(cases)} cases differ; first: {bad[0]}"
+    assert len(cases) >= 100
+    # truncation keeps <s> ... </s>; the batch entry point pads with <pad>
+    e = toks[False].encode("word " * 80, 16)
+    assert len(e.token_ids) == 16 and e.token_ids[0] == 0 and e.token_ids[-1] == 2
+    ids, lens = toks[False].encode_batch_ids(["Hello world", "", "x" * 300], 12, pad_id=1, n_threads=2)
+    assert list(lens) == [4, 2, 12] and list(ids[1]) == [0, 2] + [1] * 10 and ids[0][3] == 2
