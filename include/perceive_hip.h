@@ -94,8 +94,10 @@ pcv_status pcv_searcher_create(pcv_ctx* ctx, int dim, int metric, pcv_searcher**
 pcv_status pcv_searcher_destroy(pcv_searcher* s);
 
 /* build_sources row insert (search.rs:87-113,146-148): append `n` rows (row-major [n][dim] f32,
- * host memory) with their item ids to source `source_id`.  Rows become searchable after
- * pcv_searcher_finalize.  `ids` may be NULL: ids are then the row's running index in the source. */
+ * host memory) with their item ids to source `source_id`.  The rows are uploaded and packed into the HBM
+ * layout before the call returns (staged in bounded steps: the library keeps no host copy, so a corpus can
+ * be streamed through a buffer of any size); they become searchable after pcv_searcher_finalize.
+ * `ids` may be NULL: ids are then the row's running index in the source. */
 pcv_status pcv_searcher_add_rows(pcv_searcher* s, int64_t source_id, const int64_t* ids,
                                  const float* rows, int64_t n);
 /* Same, from the on-disk form: `n` blobs of dim*4 bytes each, back to back (search.rs:99,281). */
@@ -106,6 +108,15 @@ pcv_status pcv_searcher_add_blobs(pcv_searcher* s, int64_t source_id, const int6
  * data; oracle/synth.c is the CPU twin.  normalize != 0 stores x/|x| instead of x. */
 pcv_status pcv_searcher_add_synthetic(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
                                       int64_t first_row, int normalize);
+/* Clustered synthetic rows (what a fixed-width screen has to survive on real sentence embeddings):
+ * row = centroid(cluster(row)) / sqrt(dim) + noise * synth_row(seed, row) with n_clusters seeded centroids;
+ * members of a cluster sit within a few `noise` of each other in cosine.  n_clusters = 0: plain rows. */
+pcv_status pcv_searcher_add_synthetic_clustered(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
+                                                int64_t first_row, int normalize, int n_clusters, float noise);
+/* Capacity hint (search.rs:138-140 sizes each source's index from its row count before inserting): the
+ * host is about to add `n_rows` more rows to `source_id`, e.g. the COUNT(*) of the build query.  The rows
+ * then land in one device segment instead of a chain of growing ones.  Optional; no-op for n_rows = 0. */
+pcv_status pcv_searcher_reserve(pcv_searcher* s, int64_t source_id, int64_t n_rows);
 /* Searcher::rebuild_source (search.rs:58-79): drop every row of `source_id`; follow with
  * add_* + finalize to install the replacement.  Unknown source: no-op. */
 pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id);
@@ -113,6 +124,8 @@ pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id);
 pcv_status pcv_searcher_finalize(pcv_searcher* s);
 
 pcv_status pcv_searcher_num_rows(pcv_searcher* s, int64_t* out_rows);
+/* Device segments the rows currently occupy (diagnostics: adds append in place while a segment has room). */
+pcv_status pcv_searcher_num_segments(pcv_searcher* s, int* out_n);
 pcv_status pcv_searcher_num_sources(pcv_searcher* s, int* out_n);
 pcv_status pcv_searcher_source_ids(pcv_searcher* s, int64_t* out_ids, int cap);
 /* Rows held for one source (0 if the source is unknown). */
@@ -129,7 +142,9 @@ pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel);
 
 /* Searcher::search_vector (search.rs:157-182), batched over `n_queries` query vectors.
  *   queries      [n_queries][dim] f32
- *   source_ids   sources to search (search.rs:166 filter); NULL/0 = all sources
+ *   source_ids   sources to search (search.rs:166 filter): NULL = all sources (n_sources ignored);
+ *                non-NULL = exactly the n_sources listed ones, so n_sources = 0 matches nothing,
+ *                like `sources.contains(..)` on an empty slice
  *   k            num_results
  *   out_ids      [n_queries][k] item ids, best first
  *   out_scores   [n_queries][k] cosine (COSINE) or reference distance (DOT)
@@ -153,8 +168,9 @@ typedef struct pcv_hit {
 pcv_status pcv_searcher_set_shard_offset(pcv_searcher* s, int64_t first_global_pos);
 
 /* Local (per-shard) exact top-k, results left on the device: `d_out` is a DEVICE pointer to
- * [n_queries][k] pcv_hit; unfilled entries have pos = -1.  Queued on the context stream; the
- * call returns after the stream has drained unless `async` != 0. */
+ * [n_queries][k] pcv_hit; unfilled entries have pos = -1.  Runs on the context stream; the call
+ * returns after every pass has been collected (`async` is accepted for compatibility and ignored: use
+ * the begin/end pair below to overlap an exchange with the host). */
 pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int n_queries,
                                       const int64_t* source_ids, int n_sources, int k, void* d_out,
                                       int async);
@@ -166,8 +182,9 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
  * for the stream, books the statistics and, after an overflow, enlarges the lists for the repeat.
  * No other call may use the searcher between the two.  PCV_ERR_UNSUPPORTED only when n_queries exceeds
  * one pass (use pcv_searcher_search_device then) — a condition every rank of a sharded search evaluates
- * alike, so all ranks exchange the same payload; a shard that holds none of the selected sources, or more
- * segments than one launch takes, completes inside `begin` and delivers the same layout.  Typical step:
+ * alike, so all ranks exchange the same payload; a shard that holds none of the selected sources delivers
+ * the same layout (empty lists, clear overflow record).  One launch takes any number of segments.
+ * Typical step:
  *   begin -> all-gather of (n*k+1)*24 bytes -> pcv_merge_topk_flagged -> end -> repeat if any_overflow. */
 pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* queries, int n_queries,
                                             const int64_t* source_ids, int n_sources, int k, void* d_out);

@@ -64,3 +64,31 @@ void orc_synth_row(uint64_t seed, int64_t row, int D, int normalize, float* out)
 void orc_synth_rows(uint64_t seed, int64_t first_row, int64_t n, int D, int normalize, float* out) {
     for (int64_t r = 0; r < n; ++r) orc_synth_row(seed, first_row + r, D, normalize, out + (size_t)r * D);
 }
+
+/* Clustered variant (twin of synth_piece_clustered in perceive_amd/csrc/synth.h). */
+#define CLUSTER_SEED_XOR 0xC1057E25EED5ull
+static uint32_t cluster_of(int64_t row, uint32_t n_clusters) {
+    return (uint32_t)(((uint64_t)row * 0x9E3779B97F4A7C15ull) >> 33) % n_clusters;
+}
+
+void orc_synth_rows_clustered(uint64_t seed, int64_t first_row, int64_t n, int D, int normalize, int n_clusters,
+                              float noise, float* out) {
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
+    for (int64_t r = 0; r < n; ++r) {
+        float* o = out + (size_t)r * D;
+        const int64_t row = first_row + r;
+        const int64_t cl = (int64_t)cluster_of(row, (uint32_t)n_clusters);
+        for (int f4 = 0; f4 < D / 4; ++f4) {
+            float c[4], v[4];
+            synth_piece(seed ^ CLUSTER_SEED_XOR, cl, (uint32_t)f4, c);
+            synth_piece(seed, row, (uint32_t)f4, v);
+            for (int j = 0; j < 4; ++j) o[4 * f4 + j] = fmaf(noise, v[j], c[j] * inv_sqrt_d);
+        }
+        if (normalize) {
+            double nx = 0.0;
+            for (int i = 0; i < D; ++i) nx += (double)o[i] * (double)o[i];
+            float inv = (float)(1.0 / sqrt(nx));
+            for (int i = 0; i < D; ++i) o[i] = o[i] * inv;
+        }
+    }
+}

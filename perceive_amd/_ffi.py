@@ -92,9 +92,12 @@ SYMBOLS = {
     "pcv_serialize_embedding": (C.c_int, [_F32P, C.c_size_t, _U8P, C.c_size_t]),
     "pcv_searcher_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "pcv_searcher_destroy": (C.c_int, [_P]),
+    "pcv_searcher_reserve": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "pcv_searcher_num_segments": (C.c_int, [_P, _INTP]),
     "pcv_searcher_add_rows": (C.c_int, [_P, C.c_int64, _I64P, _F32P, C.c_int64]),
     "pcv_searcher_add_blobs": (C.c_int, [_P, C.c_int64, _I64P, _U8P, C.c_int64]),
     "pcv_searcher_add_synthetic": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int]),
+    "pcv_searcher_add_synthetic_clustered": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_float]),
     "pcv_searcher_clear_source": (C.c_int, [_P, C.c_int64]),
     "pcv_searcher_finalize": (C.c_int, [_P]),
     "pcv_searcher_num_rows": (C.c_int, [_P, _I64P]),

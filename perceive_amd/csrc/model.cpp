@@ -1,5 +1,6 @@
 // model.cpp — Model C ABI: weights, workspace and the forward pass orchestration
 // (replaces model.rs:56-191 + model/worker.rs:78-106 of the reference; kernels: encoder_kernels.hip).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,8 +48,8 @@ struct pcv_model {
     std::mutex mu;
     pcv_encode_stats stats{};
 
-    // workspace, grown on demand
-    int64_t cap_tokens = 0, cap_batch = 0;
+    // workspace, grown on demand: capacities in tokens (B*L), padded tokens (B*roundup32(L)) and batch rows
+    int64_t cap_tokens = 0, cap_padded = 0, cap_batch = 0;
     int64_t* d_ids = nullptr;
     int64_t* d_mask = nullptr;
     float *hidden = nullptr, *qkv = nullptr, *ctxbuf = nullptr, *tmp = nullptr, *ff = nullptr;
@@ -265,14 +266,20 @@ void free_workspace(pcv_model* m) {
         if (p) hipFree(p);
     m->d_ids = m->d_mask = nullptr;
     m->hidden = m->qkv = m->ctxbuf = m->tmp = m->ff = m->mask_add = m->mask01 = m->pooled = m->out = m->dbg = nullptr;
-    m->cap_tokens = m->cap_batch = 0;
+    m->cap_tokens = m->cap_padded = m->cap_batch = 0;
 }
 
 void ensure_workspace(pcv_model* m, int B, int L) {
-    const int64_t T = (int64_t)B * L;
-    const int64_t Tp = (int64_t)B * ((L + 31) / 32 * 32);
-    if (Tp <= m->cap_tokens && B <= m->cap_batch) return;
+    int64_t T = (int64_t)B * L;
+    int64_t Tp = (int64_t)B * ((L + 31) / 32 * 32);
+    if (T <= m->cap_tokens && Tp <= m->cap_padded && B <= m->cap_batch) return;
+    // every buffer is sized from the capacities that are recorded, and a capacity never shrinks: a later
+    // call with more tokens at the same padded count (B=4,L=33 then B=4,L=60) must not reuse short buffers
+    T = std::max(T, m->cap_tokens);
+    Tp = std::max(Tp, m->cap_padded);
+    B = (int)std::max<int64_t>(B, m->cap_batch);
     drop_graphs(m);  // they hold the old workspace pointers
+    PCV_HIP(hipStreamSynchronize(m->ctx->stream));
     free_workspace(m);
     const int64_t H = m->d.hidden, F = m->d.intermediate;
     const int64_t OD = m->d.dense_out > 0 ? m->d.dense_out : H;
@@ -287,8 +294,9 @@ void ensure_workspace(pcv_model* m, int B, int L) {
     PCV_HIP(hipMalloc((void**)&m->mask01, T * 4));
     PCV_HIP(hipMalloc((void**)&m->pooled, (int64_t)B * H * 4));
     PCV_HIP(hipMalloc((void**)&m->out, (int64_t)B * OD * 4));
-    if (T <= kDebugTokenLimit) PCV_HIP(hipMalloc((void**)&m->dbg, (int64_t)(m->d.layers + 1) * T * H * 4));
-    m->cap_tokens = Tp;
+    if (T <= kDebugTokenLimit) PCV_HIP(hipMalloc((void**)&m->dbg, (int64_t)(m->d.layers + 1) * T * H * 4));  // T = capacity: any smaller batch fits
+    m->cap_tokens = T;
+    m->cap_padded = Tp;
     m->cap_batch = B;
 }
 
@@ -384,6 +392,13 @@ void check_tokens(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, 
     PCV_REQUIRE(L <= m->d.max_positions, "encode_tokens: sequence length %d exceeds max_position_embeddings %d", L,
                 m->d.max_positions);
     PCV_REQUIRE((int64_t)B * L < ((int64_t)1 << 31), "encode_tokens: batch of %d x %d tokens is too large", B, L);
+    // an id outside the embedding table is a tokenizer / checkpoint mismatch: the reference's embedding lookup
+    // fails on it (worker.rs:85-86 -> libtorch index error); it must not be clamped into a plausible vector
+    const int64_t V = m->d.vocab_size;
+    for (int64_t i = 0, n = (int64_t)B * L; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= V)
+            PCV_FAIL(PCV_ERR_INVALID, "encode_tokens: token id %lld at [%lld][%lld] is outside the vocabulary [0,%lld)",
+                     (long long)ids[i], (long long)(i / L), (long long)(i % L), (long long)V);
 }
 
 void finish_stats(pcv_model* m) {

@@ -16,7 +16,6 @@
 namespace pcv {
 
 constexpr int kBlockRows = 32;      // rows per corpus block
-constexpr int kMaxSeg = 8;          // corpus segments one scan launch can walk
 constexpr int kMaxK = 128;          // largest num_results the running top-k slots hold
 constexpr int kSeedPartRows = 512;   // rows one seed workgroup ranks
 constexpr int kSeedParts = 32;       // seed workgroups per query group -> up to 16384 seed rows
@@ -25,6 +24,9 @@ constexpr int kHot = 256;            // uint32 words between per-query hot words
                                      // so the device-wide atomics on them do not queue on one HBM channel
 constexpr int kMfmaQueries = 128;   // MFMA kernel handles up to 128 queries per pass
 
+// One corpus segment as a scan launch sees it.  A launch walks any number of them: the table lives in
+// device memory next to the ScanParams (one source of the reference = one or more segments,
+// search.rs:24-27; every incremental add can append one).
 struct SegDesc {
     const float4* blk;   // blocked matrix
     const float* scale;  // [nblocks*32] 1/|x| (cosine) or 1 (dot); 0 = row not searchable
@@ -37,30 +39,47 @@ struct SegDesc {
     uint32_t pad;
 };
 
+struct pcv_hit_dev {
+    double score;
+    int64_t pos;
+    int64_t id;
+};
+
+// Everything one pass needs, resident in device memory (uploaded with the segment table and the
+// queries in ONE copy): the kernels index p.seg[] at run time, which a by-value kernel argument would
+// force through scratch memory.
 struct ScanParams {
-    SegDesc seg[kMaxSeg];
+    const SegDesc* seg;      // [nseg] device table, blk0 ascending
     int nseg;
     uint32_t total_blocks;
-    int D4;              // Dp / 4
-    int B;               // queries in this pass
+    int D;                   // embedding width
+    int D4;                  // Dp / 4
+    int B;                   // queries in this pass
     int k;
     int metric;
-    const float* qf32;       // [B][Dp]   scan-side query (normalised for cosine), zero padded
-    const uint16_t* qbf16;   // [64][Dp]  same, rounded to bf16; rows >= B are zero
-    const float* qraw;       // [B][Dp]   original query values (exact rescoring)
-    const double* qnorm2;    // [B]       f64 |q|^2
-    const float* margin;     // [B]       2*eps in score units: rows with s < tau - margin are dropped
-    uint32_t* tau;           // [B*kHot]  ordered key of the running k-th best approximate score (word q*kHot)
-    uint32_t* slots;         // [B][kMaxK] ordered keys of k distinct rows' approximate scores
+    uint32_t tile_rows;      // rows of the bf16 query tile the scan kernel stages (rows >= B are zeroed)
+    const float* queries;    // [B][D]    raw queries as the caller passed them
+    float* qf32;             // [B][Dp]   scan-side query (normalised for cosine), zero padded
+    uint16_t* qbf16;         // [128][Dp] same, rounded to bf16
+    float* qraw;             // [B][Dp]   original query values, zero padded (exact rescoring)
+    float* margin;           // [B]  coarse screen: rows with s16 < tau - margin are dropped       (eps16 + eps32)
+    float* margin32;         // [B]  fine screen:   rows with s32 < tau - margin32 are dropped     (2 * eps32)
+    uint32_t* tau;           // [B*kHot]  ordered key of the running k-th best f32 score (word q*kHot)
+    uint32_t* slots;         // [B][kMaxK] ordered keys of k distinct rows' f32 scores
     uint32_t* cand_cnt;      // [B*kHot]  survivors emitted per query (word q*kHot)
-    uint32_t* cand_cnt_out;  // [B]       compact copy written by select_kernel for the host
     uint64_t* cand;          // [B][cand_cap]  (segment index << 32) | row
-    float* cand_s;           // [B][cand_cap]  screening score the row was emitted with
-    double* cand_score;      // [B][cand_cap]  canonical score, filled by the rescoring kernel
-    uint32_t* seed_part;     // [B][kSeedParts][kMaxK] per-part seed keys
+    float* cand_s;           // [B][cand_cap]  f32 screening score the row was emitted with
+    double* cand_score;      // [B][cand_cap]  canonical score (only used when a list outgrows the LDS path)
+    uint32_t* ticket;        // arrival counter of the seed workgroups (left at 0)
+    pcv_hit_dev* out;        // [B][k] device results
+    pcv_hit_dev* out_host;   // pinned host mirror of `out`, or nullptr
+    uint32_t* cnt_host;      // [B] pinned host: survivors per query, uncapped (the host sizes a rerun from it)
+    pcv_hit_dev* flag_rec;   // overflow record behind a shard's hit list (device), or nullptr
     uint32_t cand_cap;
     uint32_t seed_blocks;    // leading blocks of segment 0 ranked by the seed kernel
     uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bits 8..15: workgroups per CU override (tuning)
+    float eps16, eps32;      // |s - c| bounds of the bf16 / f32 screening scores, relative to |q||x|
+    float max_norm;          // upper bound of |x| over the corpus (dot metric margins)
 };
 
 // float <-> order-preserving uint32 key (for atomicMax / CAS on scores)
@@ -74,36 +93,26 @@ __host__ __device__ static inline float key_f32(uint32_t k) {
 }
 constexpr uint32_t kKeyNegInf = 0x007fffffu;  // f32_key(-inf)
 
-struct pcv_hit_dev {
-    double score;
-    int64_t pos;
-    int64_t id;
-};
-
-// ---- launchers (scan_kernels.hip) ----
-void launch_pack_rows(hipStream_t st, const float* rows_rowmajor, int64_t n, int D, int D4, float4* blk,
-                      uint32_t nblocks, uint32_t row0);
-void launch_row_scales(hipStream_t st, const float4* blk, uint32_t nblocks, uint32_t nrows, int D4, int metric,
-                       float* scale, uint32_t* max_norm_bits);
-void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nblocks, uint32_t nrows, uint32_t row0, int D, int D4,
-                       uint64_t seed, int64_t first_row, int normalize);
+// ---- launchers (scan_kernels.hip); they throw pcv::Error on a bad shape or a failed HIP call ----
+void launch_pack_rows(hipStream_t st, const float* rows_rowmajor, int64_t n, int D, int D4, float4* blk, uint32_t row0);
+void launch_iota_ids(hipStream_t st, int64_t* ids, int64_t first, int64_t n);
+// scales of the rows in blocks [first_block, nblocks) of a segment
+void launch_row_scales(hipStream_t st, const float4* blk, uint32_t first_block, uint32_t nblocks, uint32_t nrows, int D4,
+                       int metric, float* scale, uint32_t* max_norm_bits);
+void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nrows, uint32_t row0, int D, int D4, uint64_t seed,
+                       int64_t first_row, int normalize, uint32_t n_clusters, float noise);
 void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const int64_t* d_pos, int64_t n, int D,
                         int D4, float* out_rows, int64_t* out_ids);
-void launch_prep_queries(hipStream_t st, const float* d_queries, int B, int D, int Dp, int metric, float eps_rel,
-                         float max_norm, int k, float* qf32, uint16_t* qbf16, float* qraw, double* qnorm2,
-                         float* margin, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt);
-// `p` is the host copy (shapes for the launch geometry), `dp` the same struct resident in device
-// memory: the kernels index p.seg[] at run time, which a by-value kernel argument would force
-// through scratch memory.
-void launch_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp);  // seed_partial + seed_merge
+// `p` is the host copy (shapes for the launch geometry), `dp` the same struct resident in device memory.
+void launch_prep_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp);
 void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);
 void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);
-int mfma_pass_queries(int Dp);  // queries one MFMA pass can take at this padded dim (LDS-limited), 0 = none
-void launch_rescore(hipStream_t st, const ScanParams& p, const ScanParams* dp);
-void launch_select(hipStream_t st, const ScanParams& p, const ScanParams* dp, pcv_hit_dev* out);
+int mfma_pass_queries(int Dp);   // queries one MFMA pass can take at this padded dim (LDS-limited), 0 = none
+uint32_t mfma_tile_rows(int B);  // rows of the bf16 query tile the MFMA kernel stages for B queries
+void launch_rescore_select(hipStream_t st, const ScanParams& p, const ScanParams* dp);
+void launch_reset_scan_state(hipStream_t st, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt, uint32_t* ticket);
 void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out,
                   int flagged = 0);
-void launch_overflow_flag(hipStream_t st, const uint32_t* cnt, int B, uint32_t cap, pcv_hit_dev* rec);
 void launch_similarity_matrix(hipStream_t st, const float* a, int B, const float* m, int64_t N, int D, int cosine,
                               float* out);
 

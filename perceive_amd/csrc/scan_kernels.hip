@@ -1,16 +1,22 @@
 // scan_kernels.hip — gfx950 kernels of the exact similarity scan (replaces lib.rs:63-77 +
 // search.rs:157-182 of the reference).
 //
-// Pipeline of one search (all on the context stream, no host round trip in between):
-//   prep_queries -> seed -> scan (wave | mfma) -> rescore -> select
-// The scan is a *screening* pass: it streams the corpus once, computes an approximate score s per
-// (query,row) with |s - c| <= eps of the canonical f64 score c, and emits every row that could
-// still be in the top-k:   emit iff !(s < tau_q - 2*eps),   tau_q = running k-th best s.
-// tau only grows, so the emitted set is a superset of the exact top-k; rescore+select then rank
-// the few hundred survivors per query in exact f64.  HBM traffic = one pass over the rows.
+// Pipeline of one search: ONE host->device copy (parameters, segment table, queries) and three
+// kernels on the context stream, results written straight into pinned host memory:
+//   prep_seed  ->  scan (wave | mfma)  ->  rescore_select
+// The scan is a *screening* pass: it streams the corpus once and keeps, per query, the running k-th
+// best f32 score tau (k DISTINCT rows' f32 scores live in slots[q][0..k), tau <= min(slots) and only
+// grows).  With |s32 - c| <= eps32 and |s16 - c| <= eps16 bounding the f32 / bf16 screening scores
+// against the canonical f64 score c:
+//   coarse test (MFMA kernel, every row):   drop iff s16 < tau - (eps16 + eps32)
+//   fine test   (f32 score of a survivor):  drop iff s32 < tau - 2*eps32
+// Either way c < tau - eps32 <= c_j for each of the k slot rows j, so a dropped row cannot be in the
+// exact top-k however stale tau is.  rescore_select ranks the few survivors per query in exact f64.
+// HBM traffic = one pass over the rows (+ one extra row read per coarse survivor).
 #include <algorithm>
 #include <cstdlib>
 
+#include "common.h"
 #include "scan.h"
 #include "synth.h"
 
@@ -20,7 +26,6 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Every pointer the kernels follow comes out of a struct in memory, so the compiler only knows it
@@ -53,6 +58,12 @@ __device__ __forceinline__ uint32_t g_atomic_cas(uint32_t* p, uint32_t expected,
                                          __HIP_MEMORY_SCOPE_AGENT);
     return expected;
 }
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
+    return __hip_atomic_load((const PCV_GLOBAL uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) {
+    __hip_atomic_store((PCV_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // corpus rows are read exactly once per scan: optionally mark the loads non-temporal
 template <bool NTL>
@@ -65,20 +76,39 @@ __device__ __forceinline__ float4 ld_row(const float4* p) {
     }
 }
 
-__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
-    return __hip_atomic_load((const PCV_GLOBAL uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int off) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, off), hi = __shfl_xor((uint32_t)(v >> 32), off);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ int find_seg(const ScanParams& p, uint32_t gb) {
-    int s = 0;
-#pragma unroll
-    for (int i = 1; i < kMaxSeg; ++i)
-        if (i < p.nseg && gb >= p.seg[i].blk0) s = i;
-    return s;
+// Position of a wave in the launch's segment table.  A wave visits launch-wide block indices in
+// ascending order, so the segment only ever moves forward: the common step (same segment) costs a
+// compare against `end`; a segment change is one binary search over the blk0 column of the table.
+struct SegCursor {
+    int si = -1;
+    uint32_t begin = 0, end = 0;  // launch-wide block range of segment si
+    const float4* blk = nullptr;
+    const float* scale = nullptr;
+};
+__device__ __forceinline__ void seek_seg(const ScanParams& p, SegCursor& c, uint32_t gb) {
+    if (gb < c.end) return;
+    int lo = c.si + 1, hi = p.nseg - 1;  // last table entry with blk0 <= gb
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (gld(&p.seg[mid].blk0) <= gb)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    c.si = lo;
+    c.begin = gld(&p.seg[lo].blk0);
+    c.end = c.begin + gld(&p.seg[lo].nblocks);
+    c.blk = gld(&p.seg[lo].blk);
+    c.scale = gld(&p.seg[lo].scale);
 }
 
-// slots[q][0..k) always hold approximate scores of k DISTINCT rows (or -inf), each slot only ever
-// grows, so min(slots) is a valid lower bound of the final k-th best approximate score.
+// slots[q][0..k) always hold f32 scores of k DISTINCT rows (or -inf), each slot only ever grows, so
+// min(slots) is a valid lower bound of the final k-th best f32 score.
 // offer_slot: try to replace the current minimum by the score `s` of a row not yet in the slots.
 __device__ __forceinline__ void offer_slot(const ScanParams& p, int q, float s) {
     const uint32_t key = f32_key(s);
@@ -103,57 +133,40 @@ __device__ __forceinline__ void offer_slot(const ScanParams& p, int q, float s) 
     }
 }
 
-// offer_slot for the NT queries a lane owns (query 32*t + c), all chains advancing in lock step so
-// their memory round trips overlap.
-template <int NT>
-__device__ __forceinline__ void offer_slots(const ScanParams& p, int c, const bool (&want)[NT], const float (&s)[NT]) {
-    bool live[NT];
-    uint32_t key[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        live[t] = want[t];
-        key[t] = f32_key(s[t]);
-    }
+// The same with the whole wave working on ONE (query, score): the k slots are read lane-parallel, so an
+// offer is three dependent round trips whatever k is.  All 64 lanes must call it with the same arguments.
+__device__ __forceinline__ void offer_slot_wave(const ScanParams& p, int q, float s, int lane) {
+    const uint32_t key = f32_key(s);
+    uint32_t* sl = p.slots + (size_t)q * kMaxK;
     for (int attempt = 0; attempt < 8; ++attempt) {
-        uint32_t mn[NT];
-        int mi[NT];
-        bool any = false;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            mn[t] = 0xffffffffu;
-            mi[t] = 0;
-            if (live[t]) {
-                const uint32_t* sl = p.slots + (size_t)(32 * t + c) * kMaxK;
-                for (int i = 0; i < p.k; ++i) {
-                    const uint32_t v = ld_relaxed(&sl[i]);
-                    if (v < mn[t]) {
-                        mn[t] = v;
-                        mi[t] = i;
-                    }
-                }
-                if (key[t] <= mn[t]) live[t] = false;
-            }
-            any |= live[t];
+        unsigned long long best = ~0ull;  // (key << 32 | slot), minimum
+        for (int i = lane; i < p.k; i += 64) {
+            const unsigned long long c = ((unsigned long long)ld_relaxed(&sl[i]) << 32) | (uint32_t)i;
+            best = c < best ? c : best;
         }
-        if (!any) return;
-        uint32_t old[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            old[t] = live[t] ? g_atomic_cas(&p.slots[(size_t)(32 * t + c) * kMaxK + mi[t]], mn[t], key[t]) : 0u;
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = shfl_xor_u64(best, off);
+            best = o < best ? o : best;
+        }
+        const uint32_t mn = (uint32_t)(best >> 32), mi = (uint32_t)best;
+        if (key <= mn) return;
+        uint32_t old = 0;
+        if (lane == 0) old = g_atomic_cas(&sl[mi], mn, key);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == mn) {
+            uint32_t nm = 0xffffffffu;
+            for (int i = lane; i < p.k; i += 64) nm = min(nm, ld_relaxed(&sl[i]));
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (live[t] && old[t] == mn[t]) {
-                const uint32_t* sl = p.slots + (size_t)(32 * t + c) * kMaxK;
-                uint32_t nm = 0xffffffffu;
-                for (int i = 0; i < p.k; ++i) nm = min(nm, ld_relaxed(&sl[i]));
-                g_atomic_max(&p.tau[(32 * t + c) * kHot], nm);
-                live[t] = false;
-            }
+            for (int off = 32; off > 0; off >>= 1) nm = min(nm, (uint32_t)__shfl_xor(nm, off));
+            if (lane == 0) g_atomic_max(&p.tau[q * kHot], nm);
+            return;
+        }
     }
 }
 
-// A surviving (query,row) pair: append to the query's candidate list and, unless the row was
-// already ranked by the seed kernel, try to raise the running k-th best.
+// A surviving (query,row) pair of the wave kernel: append to the query's candidate list and, unless the
+// row was already ranked by the seed kernel, try to raise the running k-th best.
 __device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint32_t row, float s,
                                       bool feeds_slots) {
     uint32_t idx = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
@@ -165,7 +178,7 @@ __device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint3
 }
 
 // ------------------------------------------------------------------------------------------------
-// finalize-time kernels
+// ingestion-time kernels
 // ------------------------------------------------------------------------------------------------
 
 // row-major staging [n][D] -> blocked layout, rows row0.. of the segment (buffer pre-zeroed)
@@ -189,13 +202,18 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
     blk[((lb + first_blk) * D4 + f4) * 32 + r] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+__global__ __launch_bounds__(256) void iota_ids_kernel(int64_t* __restrict__ ids, int64_t first, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ids[i] = first + i;
+}
+
 // per-row scale = 1/|x| (cosine) or 1 (dot); 0 marks rows that can never be a result
 // (padding, zero / non-finite norm).  |x|^2 accumulated in f64 in feature order.
-__global__ __launch_bounds__(256) void row_scales_kernel(const float4* __restrict__ blk, uint32_t nblocks,
-                                                         uint32_t nrows, int D4, int metric,
+__global__ __launch_bounds__(256) void row_scales_kernel(const float4* __restrict__ blk, uint32_t row_begin,
+                                                         uint32_t row_end, uint32_t nrows, int D4, int metric,
                                                          float* __restrict__ scale, uint32_t* max_norm_bits) {
-    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= nblocks * 32) return;
+    const uint32_t row = row_begin + blockIdx.x * 256 + threadIdx.x;
+    if (row >= row_end) return;
     float out = 0.0f;
     if (row < nrows) {
         const float4* base = blk + (size_t)(row >> 5) * D4 * 32 + (row & 31);
@@ -221,13 +239,22 @@ __global__ __launch_bounds__(256) void row_scales_kernel(const float4* __restric
     scale[row] = out;
 }
 
+struct SynthShape {  // n_clusters == 0: plain i.i.d. rows
+    uint32_t n_clusters;
+    float noise, inv_sqrt_d;
+};
+__device__ __forceinline__ float4 synth_value(uint64_t seed, int64_t row, uint32_t f4, const SynthShape& sh) {
+    return sh.n_clusters ? synth_piece_clustered(seed, row, f4, sh.n_clusters, sh.noise, sh.inv_sqrt_d)
+                         : synth_piece(seed, row, f4);
+}
+
 __global__ __launch_bounds__(256) void synth_inv_kernel(uint32_t nrows, int D4src, uint64_t seed, int64_t first_row,
-                                                        float* __restrict__ inv) {
+                                                        SynthShape sh, float* __restrict__ inv) {
     const uint32_t row = blockIdx.x * 256 + threadIdx.x;
     if (row >= nrows) return;
     double nx = 0.0;
     for (int f4 = 0; f4 < D4src; ++f4) {
-        float4 v = synth_piece(seed, first_row + row, (uint32_t)f4);
+        float4 v = synth_value(seed, first_row + row, (uint32_t)f4, sh);
         nx += (double)v.x * (double)v.x;
         nx += (double)v.y * (double)v.y;
         nx += (double)v.z * (double)v.z;
@@ -241,7 +268,7 @@ __global__ __launch_bounds__(256) void synth_inv_kernel(uint32_t nrows, int D4sr
 // first_row.. ; pieces beyond D stay zero
 __global__ __launch_bounds__(256) void synth_fill_kernel(float4* __restrict__ blk, uint32_t nrows, uint32_t row0,
                                                          int D4src, int D4, uint64_t seed, int64_t first_row,
-                                                         const float* __restrict__ inv, int64_t total) {
+                                                         SynthShape sh, const float* __restrict__ inv, int64_t total) {
     const uint32_t first_blk = row0 >> 5;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int r = (int)(t & 31);
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(float4* __restrict__ bl
         const int64_t row = (lb + first_blk) * 32 + r;
         const int64_t src = row - row0;
         if (src < 0 || src >= nrows) continue;
-        float4 v = synth_piece(seed, first_row + src, (uint32_t)f4);
+        float4 v = synth_value(seed, first_row + src, (uint32_t)f4, sh);
         if (inv) {
             float s = inv[src];
             v.x *= s;
@@ -293,105 +320,94 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const SegDesc* __restr
 // per-search kernels
 // ------------------------------------------------------------------------------------------------
 
-// one workgroup per query slot (64 slots always, so the bf16 tile rows >= B are zeroed)
-__global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restrict__ queries, int B, int D, int Dp,
-                                                          int metric, float eps_rel, float max_norm, int k,
-                                                          float* __restrict__ qf32, uint16_t* __restrict__ qbf16,
-                                                          float* __restrict__ qraw, double* __restrict__ qnorm2,
-                                                          float* __restrict__ margin, uint32_t* __restrict__ tau,
-                                                          uint32_t* __restrict__ slots,
-                                                          uint32_t* __restrict__ cand_cnt) {
-    extern __shared__ float sraw[];  // [Dp]
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x;
-    if (q >= B) {
-        if (q < kMfmaQueries)
-            for (int i = tid; i < Dp; i += 64) qbf16[(size_t)q * Dp + i] = 0;
-        return;
+// The clean state every pass starts from and rescore_select_kernel leaves behind.
+__global__ __launch_bounds__(256) void reset_scan_state_kernel(uint32_t* __restrict__ tau, uint32_t* __restrict__ slots,
+                                                               uint32_t* __restrict__ cand_cnt,
+                                                               uint32_t* __restrict__ ticket) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < kMfmaQueries * kMaxK) slots[t] = kKeyNegInf;
+    if (t < kMfmaQueries) {
+        tau[t * kHot] = kKeyNegInf;
+        cand_cnt[t * kHot] = 0;
     }
-    __shared__ double s_nq;
-    const float* src = queries + (size_t)q * D;
-    for (int i = tid; i < Dp; i += 64) sraw[i] = i < D ? src[i] : 0.0f;
-    __syncthreads();
-    if (tid == 0) {  // f64, feature order: the canonical |q|^2 (oracle/scan.c:orc_canonical_score)
-        double nq = 0.0;
-        for (int i = 0; i < D; ++i) nq += (double)sraw[i] * (double)sraw[i];
-        s_nq = nq;
-    }
-    __syncthreads();
-    const double nq = s_nq;
-    const bool ok = (nq < __builtin_inf()) && (metric == PCV_METRIC_DOT || nq >= 0x1p-126);
-    const float inv = (metric == PCV_METRIC_DOT) ? 1.0f : (ok ? (float)(1.0 / sqrt(nq)) : 0.0f);
-    for (int i = tid; i < Dp; i += 64) {
-        const float raw = sraw[i];
-        const float qh = ok ? raw * inv : 0.0f;
-        qraw[(size_t)q * Dp + i] = raw;
-        qf32[(size_t)q * Dp + i] = qh;
-        const __bf16 hb = (__bf16)qh;
-        qbf16[(size_t)q * Dp + i] = __builtin_bit_cast(uint16_t, hb);
-    }
-    for (int i = tid; i < kMaxK; i += 64) slots[(size_t)q * kMaxK + i] = kKeyNegInf;
-    if (tid == 0) {
-        qnorm2[q] = ok ? nq : __builtin_nan("");
-        // cosine: scores are O(1); dot: |s - c| <= eps_rel * |q| * max|x|
-        float m = 2.0f * eps_rel;
-        if (metric == PCV_METRIC_DOT) m *= (float)sqrt(nq) * max_norm * 1.0001f;
-        margin[q] = m;
-        tau[q * kHot] = kKeyNegInf;
-        cand_cnt[q * kHot] = 0;
-    }
+    if (t == 0) *ticket = 0;
 }
 
-// k rounds of workgroup-wide argmax over `n` keys in LDS (0 = absent); round j's winner goes to
-// out[j] (0 when exhausted).  All 256 threads call it.
-__device__ __forceinline__ void topk_keys_lds(uint32_t* keys, uint32_t n, int k, unsigned long long* red4,
-                                              uint32_t* out) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int j = 0; j < k; ++j) {
-        unsigned long long best = 0;
-        for (uint32_t i = tid; i < n; i += 256) {
-            const unsigned long long c = ((unsigned long long)keys[i] << 32) | (0xffffffffu - i);
-            best = c > best ? c : best;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(best, off);
-            best = o > best ? o : best;
-        }
-        if (lane == 0) red4[wave] = best;
-        __syncthreads();
-        unsigned long long w = red4[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) w = red4[i] > w ? red4[i] : w;
-        const uint32_t wkey = (uint32_t)(w >> 32);
-        if (tid == 0) {
-            out[j] = wkey;
-            if (wkey) keys[0xffffffffu - (uint32_t)w] = 0;
-        }
-        __syncthreads();
-    }
-}
-
-// Seed, step 1: workgroup (part, query group) ranks rows [part*1024, +1024) of segment 0 against QG
-// queries with f32 FMA chains and keeps the k best keys per query.  Gives the streaming kernels a
-// useful threshold from the first block on: with W waves in flight the first round screens 32*W rows
-// against the seed threshold.  QG queries share every row load (one query per workgroup made the
-// 64-query seed L2-bandwidth-bound: 1.6 GB of row re-reads).
+// prep + seed in one launch.  Workgroup (part, query group) first brings its QG queries into scan form
+// (x / |x| for cosine; |q|^2 by a lane-parallel f64 sum — the canonical feature-order sum is only needed
+// for the exact scores and is made by rescore_select_kernel) — the `part == 0` workgroups also publish
+// them (f32, bf16, raw, margins) for the scan — then ranks rows [part*512, +512) of segment 0 against
+// them with f32 FMA chains.  Seed rows are split in k disjoint groups (row mod k); the best score of
+// each group goes to slot j: k distinct rows, so min(slots) is a valid running k-th best, without any
+// selection step.  The last workgroup to arrive turns the slots into the initial thresholds.  The
+// streaming kernels thus start with a useful threshold: with W waves in flight the first round screens
+// 32*W rows against it.
 template <int QG>
-__global__ __launch_bounds__(256) void seed_partial_kernel(const ScanParams* __restrict__ pp) {
+__global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
-    extern __shared__ float smem[];
-    const int Dp = p.D4 * 4;
-    float* sq = smem;                              // [QG][Dp]
-    uint32_t* keys = (uint32_t*)(smem + QG * Dp);  // [QG][kSeedPartRows]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Dp = p.D4 * 4, D = p.D;
+    float* sq = smem;                                // [QG][Dp]
+    uint32_t* gmax = (uint32_t*)(smem + QG * Dp);    // [QG][kMaxK]
+    __shared__ uint32_t s_last;
     const int part = blockIdx.x, q0 = blockIdx.y * QG, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool writer = part == 0;
+    for (int i = tid; i < QG * kMaxK; i += 256) gmax[i] = kKeyNegInf;
+    for (int g = wave; g < QG; g += 4) {
+        const int q = q0 + g;
+        float* dst = sq + g * Dp;
+        if (q >= p.B) {
+            for (int i = lane; i < Dp; i += 64) dst[i] = 0.0f;
+            continue;
+        }
+        const float* src = p.queries + (size_t)q * D;
+        double sum = 0.0;
+        for (int i = lane; i < Dp; i += 64) {
+            const float v = i < D ? gld(&src[i]) : 0.0f;
+            dst[i] = v;
+            sum += (double)v * (double)v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        const bool ok = sum >= 0x1p-126 && sum < __builtin_inf();
+        const float inv = (p.metric == PCV_METRIC_DOT) ? 1.0f : (ok ? (float)(1.0 / sqrt(sum)) : 0.0f);
+        const bool live = (p.metric == PCV_METRIC_DOT) ? (sum < __builtin_inf()) : ok;
+        for (int i = lane; i < Dp; i += 64) {  // each lane rewrites the elements it wrote
+            const float raw = dst[i];
+            const float qh = live ? raw * inv : 0.0f;
+            dst[i] = qh;
+            if (writer) {
+                gst(&p.qraw[(size_t)q * Dp + i], raw);
+                gst(&p.qf32[(size_t)q * Dp + i], qh);
+                const __bf16 hb = (__bf16)qh;
+                gst(&p.qbf16[(size_t)q * Dp + i], __builtin_bit_cast(uint16_t, hb));
+            }
+        }
+        if (writer && lane == 0) {
+            // cosine: scores are O(1); dot: |s - c| <= eps * |q| * max|x|
+            float unit = 1.0f;
+            if (p.metric == PCV_METRIC_DOT) unit = (float)sqrt(sum) * p.max_norm * 1.0001f;
+            gst(&p.margin[q], (p.eps16 + p.eps32) * unit);
+            gst(&p.margin32[q], 2.0f * p.eps32 * unit);
+        }
+    }
+    if (writer && blockIdx.y == 0) {
+        // tile rows the scan kernel stages but no query fills
+        uint16_t* z = p.qbf16 + (size_t)p.B * Dp;
+        const int nz = ((int)p.tile_rows > p.B) ? ((int)p.tile_rows - p.B) * Dp : 0;
+        for (int i = tid; i < nz; i += 256) gst(&z[i], (uint16_t)0);
+        if (tid == 0 && p.flag_rec) {
+            pcv_hit_dev f;
+            f.score = 0.0;
+            f.pos = 0;
+            f.id = 0;
+            *p.flag_rec = f;
+        }
+    }
+    __syncthreads();
+
     const SegDesc& sg = p.seg[0];
     const uint32_t nseed = min(sg.nrows, p.seed_blocks * 32u);
-    for (int i = tid; i < QG * Dp; i += 256) {
-        const int q = q0 + i / Dp;
-        sq[i] = q < p.B ? gld(&p.qf32[(size_t)q * Dp + (i % Dp)]) : 0.0f;
-    }
-    __syncthreads();
     // thread t owns rows base + t + 256*u, u = 0..RPT-1
     const uint32_t row0 = part * kSeedPartRows + tid;
     constexpr int RPT = kSeedPartRows / 256;
@@ -431,71 +447,50 @@ __global__ __launch_bounds__(256) void seed_partial_kernel(const ScanParams* __r
     for (int u = 0; u < RPT; ++u) {
         const uint32_t row = row0 + 256u * u;
         const float sc = row < nseed ? gld(&sg.scale[row]) : 0.0f;
+        const uint32_t grp = row % (uint32_t)p.k;
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             const float s = acc[u][g] * sc;
-            keys[g * kSeedPartRows + tid + 256 * u] = (sc != 0.0f && isfinite(s)) ? f32_key(s) : 0u;  // 0 = absent
+            if (sc != 0.0f && isfinite(s)) atomicMax(&gmax[g * kMaxK + grp], f32_key(s));
         }
     }
     __syncthreads();
-    // selection: each wave ranks whole queries on its own (k rounds of a wave-wide max, no barriers)
-    for (int g = wave; g < QG; g += 4) {
-        const int q = q0 + g;
-        if (q >= p.B) continue;
-        uint32_t* kq = keys + g * kSeedPartRows;
-        uint32_t* out = p.seed_part + ((size_t)q * kSeedParts + part) * kMaxK;
-        for (int j = 0; j < p.k; ++j) {
-            unsigned long long best = 0;
-            for (uint32_t i = lane; i < (uint32_t)kSeedPartRows; i += 64) {
-                const unsigned long long cnd = ((unsigned long long)kq[i] << 32) | (0xffffffffu - i);
-                best = cnd > best ? cnd : best;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(best, off);
-                best = o > best ? o : best;
-            }
-            const uint32_t wkey = (uint32_t)(best >> 32);
-            if (lane == 0) {
-                gst(&out[j], wkey);
-                if (wkey) kq[0xffffffffu - (uint32_t)best] = 0;
-            }
-            __builtin_amdgcn_wave_barrier();  // LDS is in order within a wave: the next round sees the removal
-        }
+    for (int i = tid; i < QG * p.k; i += 256) {
+        const int g = i / p.k, j = i - g * p.k, q = q0 + g;
+        const uint32_t key = gmax[g * kMaxK + j];
+        if (q < p.B && key != kKeyNegInf) g_atomic_max(&p.slots[(size_t)q * kMaxK + j], key);
     }
-}
-
-// Seed, step 2: merge the per-part lists into the query's slots and threshold.
-__global__ __launch_bounds__(256) void seed_merge_kernel(const ScanParams* __restrict__ pp, int nparts) {
-    const ScanParams& p = *pp;
-    __shared__ uint32_t keys[kSeedParts * kMaxK];
-    __shared__ uint32_t outk[kMaxK];
-    __shared__ unsigned long long red4[4];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = (uint32_t)nparts * p.k;
-    for (uint32_t i = tid; i < n; i += 256)
-        keys[i] = gld(&p.seed_part[((size_t)q * kSeedParts + i / p.k) * kMaxK + i % p.k]);
+    // arrival: every atomic of this workgroup has been performed before its ticket is drawn
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    topk_keys_lds(keys, n, p.k, red4, outk);
-    for (int j = tid; j < p.k; j += 256) gst(&p.slots[(size_t)q * kMaxK + j], outk[j] ? outk[j] : kKeyNegInf);
-    if (tid == 0) gst(&p.tau[q * kHot], outk[p.k - 1] ? outk[p.k - 1] : kKeyNegInf);  // k-th best seed row, -inf if fewer
+    if (tid == 0) s_last = g_atomic_add(p.ticket, 1u) == gridDim.x * gridDim.y - 1u;
+    __syncthreads();
+    if (s_last) {
+        for (int q = tid; q < p.B; q += 256) {
+            uint32_t mn = 0xffffffffu;
+            for (int j = 0; j < p.k; ++j) mn = min(mn, ld_relaxed(&p.slots[(size_t)q * kMaxK + j]));
+            st_relaxed(&p.tau[q * kHot], mn);
+        }
+        if (tid == 0) st_relaxed(p.ticket, 0u);
+    }
 }
 
 // Wave-reduction scan for 1..4 queries (BASELINE config "10M x 384, batch=1"): pure HBM streaming.
 // Lane (r = lane&31, h = lane>>5) owns row r of the block and the pieces f4 = 2j+h; the two halves
-// of a row are combined with one cross-lane add.  f32 FMA chain -> eps ~ Dp * 2^-24.
+// of a row are combined with one cross-lane add.  f32 FMA chain -> the fine test applies directly.
 template <int NB, bool NTL>
 __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
-    extern __shared__ float sq[];  // [NB][Dp]
+    extern __shared__ __attribute__((aligned(16))) float sq[];  // [NB][Dp]
     const int Dp = p.D4 * 4;
     for (int i = threadIdx.x; i < NB * Dp; i += 256) sq[i] = gld(&p.qf32[i]);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     float mrg[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) mrg[b] = gld(&p.margin[b]);
+    for (int b = 0; b < NB; ++b) mrg[b] = gld(&p.margin32[b]);
     const uint32_t total_waves = gridDim.x * 4;
     const int NCH = p.D4 >> 4;  // chunks of 8 pieces per lane (64 features of the row, both halves)
     if (blockIdx.x * 4 + wave >= p.total_blocks) return;
@@ -504,7 +499,7 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
     // next chunk — also across block boundaries — are in flight while the current one is multiplied.
     struct Cur {
         uint32_t gb;
-        int si;
+        SegCursor sc;
         uint32_t lb;
         const float4* base;
         int ch;
@@ -513,14 +508,14 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
         k.gb = gb;
         k.ch = 0;
         if (gb < p.total_blocks) {
-            k.si = find_seg(p, gb);
-            k.lb = gb - p.seg[k.si].blk0;
-            k.base = p.seg[k.si].blk + (size_t)k.lb * p.D4 * 32 + h * 32 + r;
+            seek_seg(p, k.sc, gb);
+            k.lb = gb - k.sc.begin;
+            k.base = k.sc.blk + (size_t)k.lb * p.D4 * 32 + h * 32 + r;
         }
     };
     enter(cons, blockIdx.x * 4 + wave);
     prod = cons;
-    float sc_cur = gld(&p.seg[cons.si].scale[(size_t)cons.lb * 32 + r]), sc_next = 0.0f;
+    float sc_cur = gld(&cons.sc.scale[(size_t)cons.lb * 32 + r]), sc_next = 0.0f;
     uint32_t tk[NB];
     float acc[NB];
 #pragma unroll
@@ -533,7 +528,7 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
         for (int i = 0; i < 8; ++i) bf[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 8 + i) * 64);
         if (++prod.ch == NCH) {
             enter(prod, prod.gb + total_waves);
-            if (prod.gb < p.total_blocks) sc_next = gld(&p.seg[prod.si].scale[(size_t)prod.lb * 32 + r]);
+            if (prod.gb < p.total_blocks) sc_next = gld(&prod.sc.scale[(size_t)prod.lb * 32 + r]);
         }
     };
     auto consume = [&](const float4 (&bf)[8]) {
@@ -567,10 +562,10 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
                 acc[b] = 0.0f;
             }
             if (__any(any)) {
-                const bool feeds = !(cons.si == 0 && cons.lb < p.seed_blocks);
+                const bool feeds = !(cons.sc.si == 0 && cons.lb < p.seed_blocks);
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    if ((h == 0) && (sc_cur != 0.0f) && !(s[b] < thr[b])) emit_hit(p, b, cons.si, row, s[b], feeds);
+                    if ((h == 0) && (sc_cur != 0.0f) && !(s[b] < thr[b])) emit_hit(p, b, cons.sc.si, row, s[b], feeds);
             }
             enter(cons, cons.gb + total_waves);
             sc_cur = sc_next;
@@ -587,28 +582,47 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
     }
 }
 
-// MFMA tile scan for up to 64 queries (BASELINE config "100M x 384, batch=64").
+// MFMA tile scan for up to 128 queries (BASELINE config "100M x 384, batch=64").
 // D[row][query] = sum_k A[row][k] * B[k][query] on v_mfma_f32_32x32x16_bf16: A = 32 corpus rows of a
 // block (f32 from HBM, rounded to bf16 in registers), B = the query tile (bf16, LDS, XOR-swizzled so
-// the 16-lane ds_read_b128 groups are conflict-free).  One bf16 product term -> eps = 2^-8: ~2.4x
-// more survivors than an f32 screen on random data, for 1/16 of the f32 matrix cost; survivors are
-// re-ranked exactly anyway.  Each wave streams its own blocks straight into registers: the blocked
-// HBM layout makes every load two contiguous 512 B runs, so there is no LDS round trip for the corpus.
+// the 16-lane ds_read_b128 groups are conflict-free).  One bf16 product term -> eps16 = 2^-8: the
+// coarse test passes a few hundred rows per query out of 10^8, for 1/16 of the f32 matrix cost; each
+// of those is scored again in exact f32 by the whole wave (one more read of that row) and has to pass
+// the fine test before it is emitted, so the candidate lists stay a few dozen long even when thousands
+// of rows sit inside the bf16 margin of the k-th best (clustered embeddings).  Each wave streams its
+// own blocks straight into registers: the blocked HBM layout makes every load two contiguous 512 B
+// runs, so there is no LDS round trip for the corpus.
 // Variants: NT = 32-query tiles per wave (1, 2 -> B <= 64; 4 -> B <= 128), WPB = waves per
 // workgroup, NBUF = chunk buffers per wave (NBUF-1 chunks of loads in flight while one is consumed).
-//   B <= 64 : 256 threads, 3 workgroups/CU (155 VGPR, 3 waves/SIMD), NBUF 2 (NBUF 3 at 2 waves/SIMD
-//             measured no faster)
+//   B <= 64 : 256 threads, 3 workgroups/CU (3 waves/SIMD), NBUF 2 (NBUF 3 at 2 waves/SIMD measured no faster)
 //   B <= 128: 512 threads sharing one 96 KB query tile, 1 workgroup/CU, 2 waves/SIMD, NBUF 3: the
 //             scan stays HBM-bound (MFMA ~25 % busy), so 128 queries cost the same 23 ms as 64
 // (A 512-thread / 4-waves-per-SIMD build of the B <= 64 kernel was tried: the 128-VGPR cap spills 23
 // registers into the chunk loop and runs 15 % slower.)
 struct BlockCursor {  // position of a wave in its flat (block, chunk) stream
     uint32_t gb;      // launch-wide block index (>= total_blocks: exhausted)
-    int si;           // segment
+    SegCursor sc;     // segment
     uint32_t lb;      // block inside the segment
     const float4* base;
     int ch;           // chunk inside the block
 };
+
+// exact-f32 dot of query row `qf` with corpus row (`rowbase` = its piece 0; pieces are 32 float4 apart),
+// computed by the whole wave: every lane returns the same bits
+__device__ __forceinline__ float wave_dot_f32(const float* qf, const float4* rowbase, int D4, int lane) {
+    float part = 0.0f;
+    for (int f4 = lane; f4 < D4; f4 += 64) {
+        const float4 v = gld4(rowbase + (size_t)f4 * 32);
+        const float4 qv = gld4(qf + 4 * f4);
+        part = fmaf(qv.x, v.x, part);
+        part = fmaf(qv.y, v.y, part);
+        part = fmaf(qv.z, v.z, part);
+        part = fmaf(qv.w, v.w, part);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    return part;
+}
 
 template <int NT, bool NTL, int WPB, int NBUF>
 __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void scan_mfma_kernel(
@@ -623,7 +637,8 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
         lq[q * P8 + ((pc & ~15) | ((pc ^ q) & 15))] = __builtin_bit_cast(uint4, gld4((const float4*)p.qbf16 + i));
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     float mrg[NT];
 #pragma unroll
@@ -642,9 +657,9 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
         k.gb = gb;
         k.ch = 0;
         if (gb < p.total_blocks) {
-            k.si = find_seg(p, gb);
-            k.lb = gb - p.seg[k.si].blk0;
-            k.base = p.seg[k.si].blk + (size_t)k.lb * D4 * 32 + h * 64 + c;
+            seek_seg(p, k.sc, gb);
+            k.lb = gb - k.sc.begin;
+            k.base = k.sc.blk + (size_t)k.lb * D4 * 32 + h * 64 + c;
         }
     };
     BlockCursor cons, prod;  // consumer (MFMA) and producer (loads) positions; prod runs NBUF-1 chunks ahead
@@ -653,7 +668,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
     // scale of this lane's row (1/|x|, 1 or 0): multiplied into the A operand before the bf16
     // rounding, so the accumulators are final screening scores.  sc_next belongs to the block the
     // producer has entered but the consumer has not.
-    float sc_cur = gld(&p.seg[cons.si].scale[(size_t)cons.lb * 32 + c]), sc_next = 0.0f;
+    float sc_cur = gld(&cons.sc.scale[(size_t)cons.lb * 32 + c]), sc_next = 0.0f;
 
     float4 buf[NBUF][8];
     // lane's pieces of k-step ks of a chunk: f4 = chunk*16 + ks*4 + 2h + e  (2h folded into base)
@@ -664,7 +679,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
             b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 16 + (i >> 1) * 4 + (i & 1)) * 32);
         if (++prod.ch == NCH) {
             enter_block(prod, prod.gb + total_waves);
-            if (prod.gb < p.total_blocks) sc_next = gld(&p.seg[prod.si].scale[(size_t)prod.lb * 32 + c]);
+            if (prod.gb < p.total_blocks) sc_next = gld(&prod.sc.scale[(size_t)prod.lb * 32 + c]);
         }
     };
 
@@ -676,7 +691,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
         for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? ld_relaxed(&p.tau[(32 * t + c) * kHot]) : 0u;
     };
 
-    auto epilogue = [&](int esi, uint32_t elb) {
+    auto epilogue = [&](const SegCursor& esc, uint32_t elb) {
         if (NCH < 2) tau_prefetch();
         float thr[NT];
         bool any = false;
@@ -688,65 +703,46 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
             for (int i = 0; i < 16; ++i) any |= !(acc[t][i] < thr[t]);
         }
         if (__any(any)) {
-            // Rare path — but every wave takes it a handful of times while the thresholds are still
-            // loose, and under a saturated memory system each dependent round trip costs ~4 us, so it
-            // is organised in phases that keep all tiles' requests in flight together:
-            //   A  per lane (= one query per tile): hit mask, count, best score          (registers)
-            //   B  one list-space reservation per tile                                   (1 round trip)
-            //   C  store the hits (fire and forget)
-            //   D  offer the best hit to the running top-k, only if it beats the threshold the lane
-            //      already holds (hits inside the 2*eps margin cannot raise it)          (<= 3 round trips)
-            const bool feeds = !(esi == 0 && elb < p.seed_blocks);
-            const float* scp = p.seg[esi].scale + (size_t)elb * 32;
-            uint32_t hitmask[NT], idx[NT];
-            float best[NT];
+            // Rare path (a few hundred coarse survivors per query over 10^8 rows; every wave also takes it
+            // a handful of times while the thresholds are still loose).  Each survivor is handled by the
+            // whole wave: exact-f32 score from a second read of that row, fine test against the current
+            // threshold, and only then the list append and the offer to the running top-k.
+            const bool feeds = !(esc.si == 0 && elb < p.seed_blocks);
+            const float* scp = esc.scale + (size_t)elb * 32;
+            const float4* bbase = esc.blk + (size_t)elb * D4 * 32;
+            const int Dp = D4 * 4;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int q = 32 * t + c;
-                hitmask[t] = 0;
-                best[t] = -__builtin_inff();
-                if (q < p.B) {
+                uint32_t mask = 0;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float s = acc[t][i];  // the row scale is already folded into the A operand
-                        if (!(s < thr[t])) {
-                            // a zero / non-finite score may belong to a padding or invalid row (scale 0)
-                            const bool suspect = (s == 0.0f) || !isfinite(s);
-                            if (!suspect || gld(&scp[(i & 3) + 8 * (i >> 2) + 4 * h]) != 0.0f) {
-                                hitmask[t] |= 1u << i;
-                                if (isfinite(s)) best[t] = fmaxf(best[t], s);
+                for (int i = 0; i < 16; ++i) mask |= (!(acc[t][i] < thr[t])) ? (1u << i) : 0u;
+                unsigned long long ball = __ballot(mask != 0);
+                while (ball) {
+                    const int src = __builtin_ctzll(ball);
+                    ball &= ball - 1;
+                    uint32_t m = __builtin_amdgcn_readlane(mask, src);
+                    const int q = 32 * t + (src & 31), hh = src >> 5;
+                    const float m32 = gld(&p.margin32[q]);
+                    while (m) {
+                        const int i = __builtin_ctz(m);
+                        m &= m - 1;
+                        const int rib = (i & 3) + 8 * (i >> 2) + 4 * hh;  // row of the block this accumulator holds
+                        const float sc = gld(&scp[rib]);
+                        if (sc == 0.0f) continue;  // padding / unsearchable row
+                        const float s32 = wave_dot_f32(p.qf32 + (size_t)q * Dp, bbase + rib, D4, lane) * sc;
+                        const float taun = key_f32(ld_relaxed(&p.tau[q * kHot]));
+                        if (s32 < taun - m32) continue;
+                        if (lane == 0) {
+                            const uint32_t at = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
+                            if (at < p.cand_cap) {
+                                gst(&p.cand[(size_t)q * p.cand_cap + at],
+                                    ((uint64_t)(uint32_t)esc.si << 32) | (elb * 32 + (uint32_t)rib));
+                                gst(&p.cand_s[(size_t)q * p.cand_cap + at], s32);
                             }
                         }
+                        if (feeds && isfinite(s32) && s32 > taun) offer_slot_wave(p, q, s32, lane);
                     }
                 }
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                idx[t] = hitmask[t] ? g_atomic_add(&p.cand_cnt[(32 * t + c) * kHot], (uint32_t)__builtin_popcount(hitmask[t])) : 0u;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int q = 32 * t + c;
-                uint32_t at = idx[t];
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (hitmask[t] & (1u << i)) {
-                        if (at < p.cand_cap) {
-                            const uint32_t row = elb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                            gst(&p.cand[(size_t)q * p.cand_cap + at], ((uint64_t)(uint32_t)esi << 32) | row);
-                            gst(&p.cand_s[(size_t)q * p.cand_cap + at], acc[t][i]);
-                        }
-                        ++at;
-                    }
-            }
-            if (feeds) {
-                bool want[NT];
-                bool anyw = false;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    want[t] = hitmask[t] && best[t] > key_f32(tauk[t]);  // tau only grows: below it, no effect
-                    anyw |= want[t];
-                }
-                if (anyw) offer_slots<NT>(p, c, want, best);
             }
         }
 #pragma unroll
@@ -771,7 +767,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
             }
         }
         if (++cons.ch == NCH) {
-            epilogue(cons.si, cons.lb);
+            epilogue(cons.sc, cons.lb);
             enter_block(cons, cons.gb + total_waves);
             sc_cur = sc_next;
         }
@@ -801,259 +797,240 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
 #undef PCV_STEP
 }
 
-// Exact canonical score of every surviving (query,row) pair: f64, products exact, sums in feature
-// order — the same definition as oracle/scan.c:orc_canonical_score.
-__global__ __launch_bounds__(256) void rescore_kernel(const ScanParams* __restrict__ pp) {
-    const ScanParams& p = *pp;
-    extern __shared__ float sqr[];  // [Dp] raw query
-    const int q = blockIdx.y;
-    const int Dp = p.D4 * 4;
-    const uint32_t cnt = min(p.cand_cnt[q * kHot], p.cand_cap);
-    if (blockIdx.x * 256u >= cnt) return;
-    for (int i = threadIdx.x; i < Dp; i += 256) sqr[i] = p.qraw[(size_t)q * Dp + i];
-    __syncthreads();
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cnt) return;
-    // rows emitted while tau was still low: the final threshold already excludes most of them
-    // (same rule as the scan: a row with s < tau - 2*eps cannot reach the final k-th best)
-    const float thr_final = key_f32(p.tau[q * kHot]) - p.margin[q];
-    if (p.cand_s[(size_t)q * p.cand_cap + j] < thr_final) {
-        p.cand_score[(size_t)q * p.cand_cap + j] = __builtin_nan("");
-        return;
-    }
-    const uint64_t e = p.cand[(size_t)q * p.cand_cap + j];
-    const SegDesc& sg = p.seg[(int)(e >> 32)];
-    const uint32_t row = (uint32_t)e;
-    const float4* base = sg.blk + (size_t)(row >> 5) * p.D4 * 32 + (row & 31);
-    double dot = 0.0, nx = 0.0;
-#pragma unroll 8
-    for (int f4 = 0; f4 < p.D4; ++f4) {
-        const float4 v = base[(size_t)f4 * 32];
-        const float4 qv = *(const float4*)&sqr[f4 * 4];
-        dot += (double)qv.x * (double)v.x;
-        nx += (double)v.x * (double)v.x;
-        dot += (double)qv.y * (double)v.y;
-        nx += (double)v.y * (double)v.y;
-        dot += (double)qv.z * (double)v.z;
-        nx += (double)v.z * (double)v.z;
-        dot += (double)qv.w * (double)v.w;
-        nx += (double)v.w * (double)v.w;
-    }
-    const double nq = p.qnorm2[q];
-    const double inf = __builtin_inf();
-    double score = __builtin_nan("");
-    if (p.metric == PCV_METRIC_DOT) {
-        if (dot < inf && dot > -inf && nq == nq) score = dot;
-    } else if (nq >= 0x1p-126 && nq < inf && nx >= 0x1p-126 && nx < inf) {
-        const double cc = dot / (sqrt(nq) * sqrt(nx));
-        if (cc < inf && cc > -inf) score = cc;
-    }
-    p.cand_score[(size_t)q * p.cand_cap + j] = score;
-}
-
-// Cooperative form of the rescoring for dim <= 512: a workgroup takes a slice of 1024 survivors of
-// one query, compacts the ones the final threshold still admits, then every wave handles 8 of them
-// at a time — 8 lanes per row fetch its pieces together (all loads in flight at once) into LDS, and
-// one lane per row runs the canonical feature-order f64 sums from there.  Same arithmetic as
-// rescore_kernel, ~10x less latency.
-constexpr int kCoopMaxD4 = 112;  // LDS: (D4 + 32*(D4+1)) * 16 B <= 64 KB
-__global__ __launch_bounds__(256) void rescore_coop_kernel(const ScanParams* __restrict__ pp) {
-    const ScanParams& p = *pp;
-    extern __shared__ float4 lds4[];  // [D4] raw query | 4 waves x 8 slots x (D4+1) row pieces
-    __shared__ uint32_t surv[1024];
-    __shared__ uint32_t nsurv;
-    const int q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int D4 = p.D4;
-    const uint32_t cnt = min(p.cand_cnt[q * kHot], p.cand_cap);
-    const uint32_t base = blockIdx.x * 1024u;
-    if (base >= cnt) return;
-    float4* sq = lds4;
-    float4* rows = lds4 + D4 + (size_t)wave * 8 * (D4 + 1);
-    for (int i = tid; i < D4; i += 256) sq[i] = ((const float4*)(p.qraw + (size_t)q * D4 * 4))[i];
-    if (tid == 0) nsurv = 0;
-    __syncthreads();
-    const float thr_final = key_f32(p.tau[q * kHot]) - p.margin[q];
-    for (uint32_t j = base + tid; j < min(cnt, base + 1024u); j += 256) {
-        if (p.cand_s[(size_t)q * p.cand_cap + j] < thr_final)
-            p.cand_score[(size_t)q * p.cand_cap + j] = __builtin_nan("");
-        else
-            surv[atomicAdd(&nsurv, 1u)] = j;
-    }
-    __syncthreads();
-    const uint32_t ns = nsurv;
-    const int slot = lane >> 3, part = lane & 7;
-    const double nq = p.qnorm2[q];
-    const double inf = __builtin_inf();
-    for (uint32_t g = wave * 8; g < ns; g += 32) {
-        const uint32_t si = g + slot;
-        const bool live = si < ns;
-        const uint32_t j = live ? surv[si] : 0;
-        if (live) {
-            const uint64_t e = p.cand[(size_t)q * p.cand_cap + j];
-            const SegDesc& sg = p.seg[(int)(e >> 32)];
-            const uint32_t row = (uint32_t)e;
-            const float4* src = sg.blk + (size_t)(row >> 5) * D4 * 32 + (row & 31);
-            for (int f4 = part; f4 < D4; f4 += 8) rows[slot * (D4 + 1) + f4] = src[(size_t)f4 * 32];
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0);  // the row pieces of this wave are in LDS
-        if (live && part == 0) {
-            const float4* r = rows + slot * (D4 + 1);
-            double dot = 0.0, nx = 0.0;
-            for (int f4 = 0; f4 < D4; ++f4) {
-                const float4 v = r[f4];
-                const float4 qv = sq[f4];
-                dot += (double)qv.x * (double)v.x;
-                nx += (double)v.x * (double)v.x;
-                dot += (double)qv.y * (double)v.y;
-                nx += (double)v.y * (double)v.y;
-                dot += (double)qv.z * (double)v.z;
-                nx += (double)v.z * (double)v.z;
-                dot += (double)qv.w * (double)v.w;
-                nx += (double)v.w * (double)v.w;
-            }
-            double score = __builtin_nan("");
-            if (p.metric == PCV_METRIC_DOT) {
-                if (dot < inf && dot > -inf && nq == nq) score = dot;
-            } else if (nq >= 0x1p-126 && nq < inf && nx >= 0x1p-126 && nx < inf) {
-                const double cc = dot / (sqrt(nq) * sqrt(nx));
-                if (cc < inf && cc > -inf) score = cc;
-            }
-            p.cand_score[(size_t)q * p.cand_cap + j] = score;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-struct Best {
-    double score;
-    int64_t pos;
-    uint32_t idx;
-};
 __device__ __forceinline__ bool better(double sa, int64_t pa, double sb, int64_t pb) {
     return sa > sb || (sa == sb && pa < pb);
 }
 
-// Final ranking of the rescored survivors: descending canonical score, ties -> lower global
-// position.  One workgroup per query.  The valid survivors (normally a few dozen) are compacted
-// into LDS, then k rounds of argmax run there; lists that do not fit fall back to global memory.
+// Exact ranking of one query's survivors, one workgroup per query:
+//   1. keep the survivors the FINAL threshold still admits (rows emitted while tau was low);
+//   2. canonical score of each: f64, products exact, sums in feature order — the definition of
+//      oracle/scan.c:orc_canonical_score.  COOP (dim <= 448): every wave takes 8 survivors at a time,
+//      8 lanes fetch a row's pieces together into LDS (all loads in flight at once) and one lane per
+//      row runs the feature-order sums from there; otherwise a thread per survivor reads its row
+//      from global memory;
+//   3. rank: descending score, ties -> lower global position.  Up to kSelCap valid survivors (the normal
+//      case is a few dozen) are ranked in LDS by counting, each thread the rows that beat its own;
+//      longer lists fall back to k rounds of argmax over the scores kept in global memory;
+//   4. write the k hits to the device list and, if asked, straight into pinned host memory; report the
+//      uncapped survivor count; leave the per-query scan state clean for the next pass.
 constexpr int kSelCap = 1024;
-__global__ __launch_bounds__(256) void select_kernel(const ScanParams* __restrict__ pp, pcv_hit_dev* __restrict__ out) {
+constexpr int kCoopMaxD4 = 112;  // LDS: (D4 + 32*(D4+1)) * 16 B <= 58 KB
+template <bool COOP>
+__global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
+    extern __shared__ float4 lds4[];  // [D4] raw query | COOP: 4 waves x 8 slots x (D4+1) row pieces
     __shared__ double c_s[kSelCap];
     __shared__ int64_t c_p[kSelCap];
     __shared__ uint32_t c_i[kSelCap];
+    __shared__ uint32_t surv[1024];
+    __shared__ uint32_t nsurv, n_valid;
+    __shared__ double s_nq;
     __shared__ double r_s[4];
     __shared__ int64_t r_p[4];
     __shared__ uint32_t r_i[4];
-    __shared__ uint32_t n_valid;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t cnt = min(p.cand_cnt[q * kHot], p.cand_cap);
+    const int D4 = p.D4;
+    const uint32_t raw_cnt = ld_relaxed(&p.cand_cnt[q * kHot]);
+    const uint32_t cnt = min(raw_cnt, p.cand_cap);
     const uint64_t* cand = p.cand + (size_t)q * p.cand_cap;
+    const float* cs = p.cand_s + (size_t)q * p.cand_cap;
     double* sc = p.cand_score + (size_t)q * p.cand_cap;
+    float4* sq = lds4;
+    for (int i = tid; i < D4; i += 256) sq[i] = ((const float4*)(p.qraw + (size_t)q * D4 * 4))[i];
     if (tid == 0) {
         n_valid = 0;
-        p.cand_cnt_out[q] = p.cand_cnt[q * kHot];  // uncapped: the host sizes a rerun from it
+        nsurv = 0;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < cnt; i += 256) {
-        const double s = sc[i];
-        if (!(s == s)) continue;  // NaN: undefined score or ruled out
+    if (tid == 255) {  // canonical |q|^2: f64, feature order (the other waves go on to the filter meanwhile)
+        double nq = 0.0;
+        const float* f = (const float*)sq;
+        for (int i = 0; i < p.D; ++i) nq += (double)f[i] * (double)f[i];
+        s_nq = nq;
+    }
+    const float thr_final = key_f32(ld_relaxed(&p.tau[q * kHot])) - p.margin32[q];
+    const double inf = __builtin_inf();
+    auto finish_score = [&](double dot, double nx, double nq) -> double {
+        if (p.metric == PCV_METRIC_DOT) return (dot < inf && dot > -inf && nq < inf) ? dot : __builtin_nan("");
+        if (nq >= 0x1p-126 && nq < inf && nx >= 0x1p-126 && nx < inf) {
+            const double cc = dot / (sqrt(nq) * sqrt(nx));
+            if (cc < inf && cc > -inf) return cc;
+        }
+        return __builtin_nan("");
+    };
+    auto keep = [&](uint32_t j, double score) {  // one survivor's canonical score
+        sc[j] = score;
+        if (!(score == score)) return;  // NaN: undefined score
         const uint32_t slot = atomicAdd(&n_valid, 1u);
         if (slot < (uint32_t)kSelCap) {
-            const uint64_t e = cand[i];
-            c_s[slot] = s;
+            const uint64_t e = cand[j];
+            c_s[slot] = score;
             c_p[slot] = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
-            c_i[slot] = i;
+            c_i[slot] = j;
         }
-    }
-    __syncthreads();
-    const uint32_t nv = n_valid;
-    const bool in_lds = nv <= (uint32_t)kSelCap;
-    const uint32_t n = in_lds ? nv : cnt;
-    for (int j = 0; j < p.k; ++j) {
-        double bs = -__builtin_inf();
-        int64_t bp = INT64_MAX;
-        uint32_t bi = 0xffffffffu;  // index into the LDS list (in_lds) or the global list
-        for (uint32_t i = tid; i < n; i += 256) {
-            double s;
-            int64_t pos;
-            if (in_lds) {
-                s = c_s[i];
-                pos = c_p[i];
-            } else {
-                s = sc[i];
-                const uint64_t e = cand[i];
-                pos = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
-            }
-            if (!(s == s)) continue;
-            if (bi == 0xffffffffu || better(s, pos, bs, bp)) {
-                bs = s;
-                bp = pos;
-                bi = i;
-            }
+    };
+    for (uint32_t base = 0; base < cnt; base += 1024) {
+        for (uint32_t j = base + tid; j < min(cnt, base + 1024u); j += 256) {
+            if (cs[j] < thr_final)
+                sc[j] = __builtin_nan("");
+            else
+                surv[atomicAdd(&nsurv, 1u)] = j;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double os = __shfl_xor(bs, off);
-            const int64_t op = __shfl_xor(bp, off);
-            const uint32_t oi = __shfl_xor(bi, off);
-            if (oi != 0xffffffffu && (bi == 0xffffffffu || better(os, op, bs, bp))) {
-                bs = os;
-                bp = op;
-                bi = oi;
-            }
-        }
-        if (lane == 0) {
-            r_s[wave] = bs;
-            r_p[wave] = bp;
-            r_i[wave] = bi;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (r_i[w] != 0xffffffffu && (bi == 0xffffffffu || better(r_s[w], r_p[w], bs, bp))) {
-                    bs = r_s[w];
-                    bp = r_p[w];
-                    bi = r_i[w];
+        __syncthreads();  // nsurv is final; s_nq is there
+        const uint32_t ns = nsurv;
+        const double nq = s_nq;
+        if constexpr (COOP) {
+            float4* rows = lds4 + D4 + (size_t)wave * 8 * (D4 + 1);
+            const int slot = lane >> 3, part = lane & 7;
+            for (uint32_t g = wave * 8; g < ns; g += 32) {
+                const uint32_t si = g + slot;
+                const bool live = si < ns;
+                const uint32_t j = live ? surv[si] : 0;
+                if (live) {
+                    const uint64_t e = cand[j];
+                    const SegDesc& sg = p.seg[(int)(e >> 32)];
+                    const uint32_t row = (uint32_t)e;
+                    const float4* src = sg.blk + (size_t)(row >> 5) * D4 * 32 + (row & 31);
+                    for (int f4 = part; f4 < D4; f4 += 8) rows[slot * (D4 + 1) + f4] = src[(size_t)f4 * 32];
                 }
-            pcv_hit_dev hit;
-            if (bi != 0xffffffffu) {
-                const uint32_t gi = in_lds ? c_i[bi] : bi;
-                const uint64_t e = cand[gi];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0);  // the row pieces of this wave are in LDS
+                if (live && part == 0) {
+                    const float4* r = rows + slot * (D4 + 1);
+                    double dot = 0.0, nx = 0.0;
+                    for (int f4 = 0; f4 < D4; ++f4) {
+                        const float4 v = r[f4];
+                        const float4 qv = sq[f4];
+                        dot += (double)qv.x * (double)v.x;
+                        nx += (double)v.x * (double)v.x;
+                        dot += (double)qv.y * (double)v.y;
+                        nx += (double)v.y * (double)v.y;
+                        dot += (double)qv.z * (double)v.z;
+                        nx += (double)v.z * (double)v.z;
+                        dot += (double)qv.w * (double)v.w;
+                        nx += (double)v.w * (double)v.w;
+                    }
+                    keep(j, finish_score(dot, nx, nq));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            for (uint32_t si = tid; si < ns; si += 256) {
+                const uint32_t j = surv[si];
+                const uint64_t e = cand[j];
                 const SegDesc& sg = p.seg[(int)(e >> 32)];
                 const uint32_t row = (uint32_t)e;
-                hit.score = bs;
-                hit.pos = bp;
-                hit.id = sg.ids ? sg.ids[row] : sg.id0 + (int64_t)row;
-                if (in_lds)
-                    c_s[bi] = __builtin_nan("");
-                else
-                    sc[bi] = __builtin_nan("");
-            } else {
-                hit.score = __builtin_nan("");
-                hit.pos = -1;
-                hit.id = -1;
+                const float4* src = sg.blk + (size_t)(row >> 5) * D4 * 32 + (row & 31);
+                double dot = 0.0, nx = 0.0;
+#pragma unroll 8
+                for (int f4 = 0; f4 < D4; ++f4) {
+                    const float4 v = src[(size_t)f4 * 32];
+                    const float4 qv = sq[f4];
+                    dot += (double)qv.x * (double)v.x;
+                    nx += (double)v.x * (double)v.x;
+                    dot += (double)qv.y * (double)v.y;
+                    nx += (double)v.y * (double)v.y;
+                    dot += (double)qv.z * (double)v.z;
+                    nx += (double)v.z * (double)v.z;
+                    dot += (double)qv.w * (double)v.w;
+                    nx += (double)v.w * (double)v.w;
+                }
+                keep(j, finish_score(dot, nx, nq));
             }
-            out[(size_t)q * p.k + j] = hit;
         }
         __syncthreads();
+        if (tid == 0) nsurv = 0;
+        __syncthreads();
     }
-}
-
-// One record after a shard's [B][k] hits says whether any of its candidate lists overflowed (the
-// pass then has to be repeated with larger lists): pos = 1 | 0.  It travels with the hits through the
-// all-gather so that every rank takes the same decision without a second collective.
-__global__ __launch_bounds__(64) void overflow_flag_kernel(const uint32_t* __restrict__ cnt, int B, uint32_t cap,
-                                                           pcv_hit_dev* __restrict__ rec) {
-    bool over = false;
-    for (int q = threadIdx.x; q < B; q += 64) over |= cnt[q] > cap;
-    over = __any(over);
-    if (threadIdx.x == 0) {
-        rec->score = 0.0;
-        rec->pos = over ? 1 : 0;
-        rec->id = 0;
+    const uint32_t nv = n_valid;
+    pcv_hit_dev* out = p.out + (size_t)q * p.k;
+    pcv_hit_dev* outh = p.out_host ? p.out_host + (size_t)q * p.k : nullptr;
+    auto put = [&](int j, const pcv_hit_dev& hit) {
+        out[j] = hit;
+        if (outh) outh[j] = hit;
+    };
+    auto make_hit = [&](uint32_t gi, double s, int64_t pos) {
+        const uint64_t e = cand[gi];
+        const SegDesc& sg = p.seg[(int)(e >> 32)];
+        const uint32_t row = (uint32_t)e;
+        pcv_hit_dev hit;
+        hit.score = s;
+        hit.pos = pos;
+        hit.id = sg.ids ? sg.ids[row] : sg.id0 + (int64_t)row;
+        return hit;
+    };
+    pcv_hit_dev none;
+    none.score = __builtin_nan("");
+    none.pos = -1;
+    none.id = -1;
+    if (nv <= (uint32_t)kSelCap) {
+        // rank by counting: positions are unique, so the ranks are a permutation
+        for (uint32_t i = tid; i < nv; i += 256) {
+            const double s = c_s[i];
+            const int64_t pos = c_p[i];
+            int rank = 0;
+            for (uint32_t j = 0; j < nv; ++j) rank += better(c_s[j], c_p[j], s, pos) ? 1 : 0;
+            if (rank < p.k) put(rank, make_hit(c_i[i], s, pos));
+        }
+        for (int j = (int)nv + tid; j < p.k; j += 256) put(j, none);
+    } else {
+        for (int j = 0; j < p.k; ++j) {
+            double bs = -__builtin_inf();
+            int64_t bp = INT64_MAX;
+            uint32_t bi = 0xffffffffu;
+            for (uint32_t i = tid; i < cnt; i += 256) {
+                const double s = sc[i];
+                if (!(s == s)) continue;
+                const uint64_t e = cand[i];
+                const int64_t pos = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
+                if (bi == 0xffffffffu || better(s, pos, bs, bp)) {
+                    bs = s;
+                    bp = pos;
+                    bi = i;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double os = __shfl_xor(bs, off);
+                const int64_t op = __shfl_xor(bp, off);
+                const uint32_t oi = __shfl_xor(bi, off);
+                if (oi != 0xffffffffu && (bi == 0xffffffffu || better(os, op, bs, bp))) {
+                    bs = os;
+                    bp = op;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) {
+                r_s[wave] = bs;
+                r_p[wave] = bp;
+                r_i[wave] = bi;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < 4; ++w)
+                    if (r_i[w] != 0xffffffffu && (bi == 0xffffffffu || better(r_s[w], r_p[w], bs, bp))) {
+                        bs = r_s[w];
+                        bp = r_p[w];
+                        bi = r_i[w];
+                    }
+                if (bi != 0xffffffffu) {
+                    put(j, make_hit(bi, bs, bp));
+                    sc[bi] = __builtin_nan("");
+                } else {
+                    put(j, none);
+                }
+            }
+            __syncthreads();
+        }
     }
+    // survivor count (uncapped: the host sizes a rerun from it), overflow record, clean state
+    if (tid == 0) {
+        if (p.cnt_host) p.cnt_host[q] = raw_cnt;
+        if (raw_cnt > p.cand_cap && p.flag_rec) p.flag_rec->pos = 1;
+        st_relaxed(&p.tau[q * kHot], kKeyNegInf);
+        st_relaxed(&p.cand_cnt[q * kHot], 0u);
+    }
+    for (int j = tid; j < p.k; j += 256) st_relaxed(&p.slots[(size_t)q * kMaxK + j], kKeyNegInf);
 }
 
 // merge of per-shard top-k lists after the all-gather: [n_shards][B][k] -> [B][k]; shards are `stride`
@@ -1139,39 +1116,51 @@ __global__ __launch_bounds__(256) void similarity_matrix_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------
 
 static inline unsigned cdiv64(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+#define PCV_LAUNCHED() PCV_HIP(hipGetLastError())
 
-void launch_pack_rows(hipStream_t st, const float* rows, int64_t n, int D, int D4, float4* blk, uint32_t nblocks,
-                      uint32_t row0) {
+void launch_pack_rows(hipStream_t st, const float* rows, int64_t n, int D, int D4, float4* blk, uint32_t row0) {
     if (n <= 0) return;
     const uint32_t first_blk = row0 >> 5;
     const uint32_t last_blk = (uint32_t)((row0 + n - 1) >> 5);
     const int64_t threads = (int64_t)(last_blk - first_blk + 1) * D4 * 32;
-    if (threads > (int64_t)0xffffff00u) abort();  // callers stage <= 2^18 rows per call
+    if (threads > (int64_t)0xffffff00u)
+        PCV_FAIL(PCV_ERR_INTERNAL, "pack_rows: %lld rows in one staging step (callers stage <= 2^18 rows per call)", (long long)n);
     pack_rows_kernel<<<cdiv64(threads, 256), 256, 0, st>>>(rows, n, D, D4, blk, row0);
+    PCV_LAUNCHED();
 }
 
-void launch_row_scales(hipStream_t st, const float4* blk, uint32_t nblocks, uint32_t nrows, int D4, int metric,
-                       float* scale, uint32_t* max_norm_bits) {
-    if (nblocks == 0) return;
-    row_scales_kernel<<<cdiv64((int64_t)nblocks * 32, 256), 256, 0, st>>>(blk, nblocks, nrows, D4, metric, scale,
-                                                                           max_norm_bits);
+void launch_iota_ids(hipStream_t st, int64_t* ids, int64_t first, int64_t n) {
+    if (n <= 0) return;
+    iota_ids_kernel<<<cdiv64(n, 256), 256, 0, st>>>(ids, first, n);
+    PCV_LAUNCHED();
 }
 
-void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nblocks, uint32_t nrows, uint32_t row0, int D, int D4,
-                       uint64_t seed, int64_t first_row, int normalize) {
+void launch_row_scales(hipStream_t st, const float4* blk, uint32_t first_block, uint32_t nblocks, uint32_t nrows, int D4,
+                       int metric, float* scale, uint32_t* max_norm_bits) {
+    if (nblocks <= first_block) return;
+    const uint32_t r0 = first_block * 32, r1 = nblocks * 32;
+    row_scales_kernel<<<cdiv64((int64_t)r1 - r0, 256), 256, 0, st>>>(blk, r0, r1, nrows, D4, metric, scale, max_norm_bits);
+    PCV_LAUNCHED();
+}
+
+void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nrows, uint32_t row0, int D, int D4, uint64_t seed,
+                       int64_t first_row, int normalize, uint32_t n_clusters, float noise) {
     if (nrows == 0) return;
     const int D4src = D / 4;
+    const SynthShape sh{n_clusters, noise, 1.0f / sqrtf((float)D)};
     float* inv = nullptr;
     if (normalize) {
-        hipMallocAsync((void**)&inv, (size_t)nrows * sizeof(float), st);
-        synth_inv_kernel<<<cdiv64(nrows, 256), 256, 0, st>>>(nrows, D4src, seed, first_row, inv);
+        PCV_HIP(hipMallocAsync((void**)&inv, (size_t)nrows * sizeof(float), st));
+        synth_inv_kernel<<<cdiv64(nrows, 256), 256, 0, st>>>(nrows, D4src, seed, first_row, sh, inv);
     }
     const uint32_t first_blk = row0 >> 5;
     const uint32_t last_blk = (uint32_t)(((uint64_t)row0 + nrows - 1) >> 5);
     const int64_t threads = (int64_t)(last_blk - first_blk + 1) * D4src * 32;
     const unsigned grid = (unsigned)std::min<int64_t>((threads + 255) / 256, 1 << 20);
-    synth_fill_kernel<<<grid, 256, 0, st>>>(blk, nrows, row0, D4src, D4, seed, first_row, inv, threads);
-    if (inv) hipFreeAsync(inv, st);
+    synth_fill_kernel<<<grid, 256, 0, st>>>(blk, nrows, row0, D4src, D4, seed, first_row, sh, inv, threads);
+    const hipError_t e = hipGetLastError();
+    if (inv) (void)hipFreeAsync(inv, st);
+    PCV_HIP(e);
 }
 
 void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const int64_t* d_pos, int64_t n, int D,
@@ -1179,27 +1168,24 @@ void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const i
     if (n <= 0) return;
     const int64_t threads = n * ((D + 3) / 4);
     gather_rows_kernel<<<cdiv64(threads, 256), 256, 0, st>>>(d_segs, nseg, d_pos, n, D, D4, out_rows, out_ids);
+    PCV_LAUNCHED();
 }
 
-void launch_prep_queries(hipStream_t st, const float* d_queries, int B, int D, int Dp, int metric, float eps_rel,
-                         float max_norm, int k, float* qf32, uint16_t* qbf16, float* qraw, double* qnorm2,
-                         float* margin, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt) {
-    const int grid = B > kMfmaQueries ? B : kMfmaQueries;
-    prep_queries_kernel<<<grid, 64, (size_t)Dp * sizeof(float), st>>>(d_queries, B, D, Dp, metric, eps_rel, max_norm, k, qf32, qbf16, qraw,
-                                             qnorm2, margin, tau, slots, cand_cnt);
+void launch_reset_scan_state(hipStream_t st, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt, uint32_t* ticket) {
+    reset_scan_state_kernel<<<kMfmaQueries * kMaxK / 256, 256, 0, st>>>(tau, slots, cand_cnt, ticket);
+    PCV_LAUNCHED();
 }
 
-void launch_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
-    if (p.seed_blocks == 0 || p.nseg == 0) return;
-    const int nparts = (int)((p.seed_blocks * 32u + kSeedPartRows - 1) / kSeedPartRows);
-    if (p.B <= 2) {
-        const size_t lds = (size_t)p.D4 * 4 * sizeof(float) + kSeedPartRows * sizeof(uint32_t);
-        seed_partial_kernel<1><<<dim3(nparts, p.B), 256, lds, st>>>(dp);
-    } else {
-        const size_t lds = 8 * ((size_t)p.D4 * 4 * sizeof(float) + kSeedPartRows * sizeof(uint32_t));
-        seed_partial_kernel<8><<<dim3(nparts, (p.B + 7) / 8), 256, lds, st>>>(dp);
+void launch_prep_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
+    const int nparts = std::max(1, (int)((p.seed_blocks * 32u + kSeedPartRows - 1) / kSeedPartRows));
+    const size_t Dp = (size_t)p.D4 * 4;
+    const size_t lds1 = Dp * sizeof(float) + kMaxK * sizeof(uint32_t);
+    if (p.B <= 2 || 8 * lds1 > 64 * 1024) {  // few queries, or very wide rows: one query per workgroup
+        prep_seed_kernel<1><<<dim3(nparts, p.B), 256, lds1, st>>>(dp);
+    } else {  // 8 queries share every seed row load
+        prep_seed_kernel<8><<<dim3(nparts, (p.B + 7) / 8), 256, 8 * lds1, st>>>(dp);
     }
-    seed_merge_kernel<<<p.B, 256, 0, st>>>(dp, nparts);
+    PCV_LAUNCHED();
 }
 
 void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
@@ -1210,6 +1196,20 @@ void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp,
     const unsigned need = (p.total_blocks + 3) / 4;
     if (grid > need) grid = need;
     const bool ntl = (p.flags & 1) == 0;  // non-temporal corpus loads unless flag bit 0 is set
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+    }
 #define PCV_WAVE(NB)                                                   \
     if (ntl)                                                           \
         scan_wave_kernel<NB, true><<<grid, 256, lds, st>>>(dp);         \
@@ -1222,6 +1222,7 @@ void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp,
         default: PCV_WAVE(4); break;
     }
 #undef PCV_WAVE
+    PCV_LAUNCHED();
 }
 
 // Largest query count one MFMA pass can take at this padded dim: the bf16 query tile
@@ -1232,13 +1233,15 @@ int mfma_pass_queries(int Dp) {
     return 0;
 }
 
+uint32_t mfma_tile_rows(int B) { return B <= 32 ? 32u : (B <= 64 ? 64u : 128u); }
+
 template <int NT, bool NTL, int WPB, int NBUF>
 static void launch_mfma_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
     if (lds > 64 * 1024) {
         static bool attr_set = false;  // one flag per instantiation
         if (!attr_set) {
-            hipFuncSetAttribute((const void*)scan_mfma_kernel<NT, NTL, WPB, NBUF>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma_kernel<NT, NTL, WPB, NBUF>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
     }
@@ -1272,31 +1275,29 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
         if (ntl) { launch_mfma_variant<4, true, 8, 3>(st, dp, grid, lds); } else { launch_mfma_variant<4, false, 8, 3>(st, dp, grid, lds); }
     }
 #undef PCV_MFMA
+    PCV_LAUNCHED();
 }
 
-void launch_rescore(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
+void launch_rescore_select(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
     if (p.D4 <= kCoopMaxD4) {
         const size_t lds = ((size_t)p.D4 + 4 * 8 * ((size_t)p.D4 + 1)) * sizeof(float4);
-        dim3 grid((p.cand_cap + 1023) / 1024, p.B);
-        rescore_coop_kernel<<<grid, 256, lds, st>>>(dp);
-        return;
+        static bool attr_set = false;
+        if (!attr_set) {  // static LDS (28 KB) + dynamic may pass 64 KB
+            PCV_HIP(hipFuncSetAttribute((const void*)rescore_select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+            attr_set = true;
+        }
+        rescore_select_kernel<true><<<p.B, 256, lds, st>>>(dp);
+    } else {
+        const size_t lds = (size_t)p.D4 * sizeof(float4);
+        rescore_select_kernel<false><<<p.B, 256, lds, st>>>(dp);
     }
-    const size_t lds = (size_t)p.D4 * 4 * sizeof(float);
-    dim3 grid((p.cand_cap + 255) / 256, p.B);
-    rescore_kernel<<<grid, 256, lds, st>>>(dp);
-}
-
-void launch_select(hipStream_t st, const ScanParams& p, const ScanParams* dp, pcv_hit_dev* out) {
-    select_kernel<<<p.B, 256, 0, st>>>(dp, out);
+    PCV_LAUNCHED();
 }
 
 void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out, int flagged) {
     const size_t stride = (size_t)B * k + (flagged ? 1 : 0);
     merge_kernel<<<B, 64, (size_t)n_shards * k, st>>>(lists, n_shards, B, k, stride, flagged, out);
-}
-
-void launch_overflow_flag(hipStream_t st, const uint32_t* cnt, int B, uint32_t cap, pcv_hit_dev* rec) {
-    overflow_flag_kernel<<<1, 64, 0, st>>>(cnt, B, cap, rec);
+    PCV_LAUNCHED();
 }
 
 void launch_similarity_matrix(hipStream_t st, const float* a, int B, const float* m, int64_t N, int D, int cosine,
@@ -1304,6 +1305,7 @@ void launch_similarity_matrix(hipStream_t st, const float* a, int B, const float
     if (N <= 0 || B <= 0) return;
     dim3 grid(cdiv64(N, 256), B);
     similarity_matrix_kernel<<<grid, 256, 0, st>>>(a, B, m, N, D, cosine, out);
+    PCV_LAUNCHED();
 }
 
 }  // namespace pcv

@@ -20,32 +20,29 @@ using namespace pcv;
 
 namespace {
 
+// One device allocation of corpus rows.  Rows are appended in place while there is room (cap_rows), so a
+// source that grows by many small adds stays a handful of segments; rows [scaled_rows, nrows) have been
+// uploaded but not yet given their scale (they become searchable at the next finalize).
 struct Segment {
     float4* blk = nullptr;
     float* scale = nullptr;
-    int64_t* ids = nullptr;  // nullptr -> implicit ids id0 + row
+    int64_t* ids = nullptr;  // nullptr -> implicit ids id0 + row (synthetic rows)
     int64_t id0 = 0;
     int64_t pos0 = 0;
-    uint32_t nrows = 0, nblocks = 0;
-};
-
-struct SynthSpec {
-    int64_t n;
-    uint64_t seed;
-    int64_t first_row;
-    int normalize;
+    uint32_t nrows = 0, cap_rows = 0, scaled_rows = 0;
+    uint32_t nblocks() const { return (nrows + kBlockRows - 1) / kBlockRows; }
 };
 
 struct Source {
     int64_t id = 0;
     std::vector<Segment> segs;
-    // rows waiting for finalize
-    std::vector<float> pend_rows;
-    std::vector<int64_t> pend_ids;
-    bool pend_ids_explicit = false;
-    int64_t pend_n = 0;
     int64_t next_implicit_id = 0;
-    std::vector<SynthSpec> pend_synth;
+    int64_t reserve = 0;  // rows the host announced it is going to add (pcv_searcher_reserve)
+    int64_t rows() const {
+        int64_t n = 0;
+        for (const Segment& g : segs) n += g.nrows;
+        return n;
+    }
 };
 
 template <class T>
@@ -61,11 +58,17 @@ struct DevBuf {
         n = want;
     }
     void release() {
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
     }
 };
+
+constexpr int64_t kStageRows = 1 << 18;                  // rows per H2D staging step (384-d: 400 MB)
+constexpr int64_t kMaxSegRows = (int64_t)0xffffffc0u;    // a candidate names its row in 32 bits
+constexpr int64_t kGrowCapRows = (int64_t)1 << 24;       // spare room a new segment gets at most
+constexpr size_t kPassAlign = 256;
+inline size_t align_up(size_t v) { return (v + kPassAlign - 1) / kPassAlign * kPassAlign; }
 
 }  // namespace
 
@@ -81,32 +84,35 @@ struct pcv_searcher {
     bool dirty = false;
     std::mutex mu;
     pcv_scan_stats stats{};
+    DevBuf<float> d_stage;  // ingestion staging (released by finalize)
 
-    // per-search workspace (sized for one pass of <= 64 queries)
-    DevBuf<float> d_queries, d_qf32, d_qraw, d_margin;
+    // per-search workspace (sized for one pass of <= 128 queries)
+    DevBuf<float> d_qf32, d_qraw, d_margin, d_margin32;
     DevBuf<uint16_t> d_qbf16;
-    DevBuf<double> d_qnorm2, d_cand_score;
+    DevBuf<double> d_cand_score;
     DevBuf<float> d_cand_s;
-    DevBuf<uint32_t> d_tau, d_slots, d_cnt, d_cnt_out, d_seed_part;
+    DevBuf<uint32_t> d_tau, d_slots, d_cnt, d_ticket;
     DevBuf<uint64_t> d_cand;
     DevBuf<pcv_hit_dev> d_hits;
-    DevBuf<ScanParams> d_params;
-    // pinned host staging of one pass: inputs go up and results come down with async copies that
-    // never bounce through a driver staging buffer
+    // what one pass takes up: ScanParams | SegDesc[nseg] | queries[B][D], built in pinned memory and
+    // sent with ONE copy into its device mirror
+    uint8_t* pin_pass = nullptr;
+    uint8_t* d_pass = nullptr;
+    size_t pass_cap = 0;
+    // what one pass brings back: written by rescore_select_kernel straight into pinned memory
     struct Pinned {
-        ScanParams params;
         uint32_t cnt[kMfmaQueries];
         pcv_hit_dev hits[kMfmaQueries * kMaxK];
     };
     Pinned* pin = nullptr;
-    float* pin_queries = nullptr;  // [64][D]
+    bool state_clean = false;  // tau / slots / counters are in the state a pass starts from
     uint32_t cand_cap = 8192;
     uint32_t scan_flags = 0;  // tuning knobs, PCV_SCAN_FLAGS
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // a pass queued by enqueue_pass and not yet collected by finish_pass
     struct Pending {
         bool active = false;
-        bool done = false;  // the work was finished synchronously (nothing to collect)
+        bool done = false;  // nothing was launched (no selected rows): only the stream has to drain
         int B = 0;
         int64_t rows = 0;
     } pending;
@@ -127,39 +133,37 @@ struct pcv_searcher {
 namespace {
 
 void free_segment(Segment& g) {
-    if (g.blk) hipFree(g.blk);
-    if (g.scale) hipFree(g.scale);
-    if (g.ids) hipFree(g.ids);
+    if (g.blk) (void)hipFree(g.blk);
+    if (g.scale) (void)hipFree(g.scale);
+    if (g.ids) (void)hipFree(g.ids);
     g = Segment();
 }
 
-// Allocate a segment for `nrows` rows; zero-filled so padding rows / features are exact zeros.
-Segment alloc_segment(pcv_searcher* s, int64_t nrows, bool with_ids) {
-    PCV_REQUIRE(nrows > 0 && nrows < (int64_t)0xffffffe0u, "segment of %lld rows is out of range", (long long)nrows);
+// Allocate a segment with room for `cap_rows` rows; zero-filled so padding rows / features are exact
+// zeros and no row is searchable before its scale has been computed.
+Segment alloc_segment(pcv_searcher* s, int64_t cap_rows, bool with_ids) {
+    PCV_REQUIRE(cap_rows > 0 && cap_rows <= kMaxSegRows, "segment of %lld rows is out of range", (long long)cap_rows);
     Segment g;
-    g.nrows = (uint32_t)nrows;
-    g.nblocks = (uint32_t)((nrows + kBlockRows - 1) / kBlockRows);
-    const size_t bytes = (size_t)g.nblocks * s->D4 * 32 * sizeof(float4);
+    const uint32_t nblk = (uint32_t)((cap_rows + kBlockRows - 1) / kBlockRows);
+    g.cap_rows = nblk * kBlockRows;
+    const size_t bytes = (size_t)nblk * s->D4 * 32 * sizeof(float4);
     hipError_t e = hipMalloc((void**)&g.blk, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         PCV_FAIL(PCV_ERR_DEVICE, "hipMalloc of %.2f GB for %lld corpus rows failed: %s", bytes / 1e9,
-                 (long long)nrows, hipGetErrorString(e));
+                 (long long)cap_rows, hipGetErrorString(e));
     }
     try {
-        PCV_HIP(hipMalloc((void**)&g.scale, (size_t)g.nblocks * 32 * sizeof(float)));
-        if (with_ids) PCV_HIP(hipMalloc((void**)&g.ids, (size_t)g.nblocks * 32 * sizeof(int64_t)));
+        PCV_HIP(hipMalloc((void**)&g.scale, (size_t)g.cap_rows * sizeof(float)));
+        if (with_ids) PCV_HIP(hipMalloc((void**)&g.ids, (size_t)g.cap_rows * sizeof(int64_t)));
         PCV_HIP(hipMemsetAsync(g.blk, 0, bytes, s->ctx->stream));
-        if (with_ids) PCV_HIP(hipMemsetAsync(g.ids, 0xff, (size_t)g.nblocks * 32 * sizeof(int64_t), s->ctx->stream));
+        PCV_HIP(hipMemsetAsync(g.scale, 0, (size_t)g.cap_rows * sizeof(float), s->ctx->stream));
+        if (with_ids) PCV_HIP(hipMemsetAsync(g.ids, 0xff, (size_t)g.cap_rows * sizeof(int64_t), s->ctx->stream));
     } catch (...) {
         free_segment(g);
         throw;
     }
     return g;
-}
-
-void finish_segment(pcv_searcher* s, Segment& g) {
-    launch_row_scales(s->ctx->stream, g.blk, g.nblocks, g.nrows, s->D4, s->metric, g.scale, s->d_max_norm_bits);
 }
 
 void assign_positions(pcv_searcher* s) {
@@ -171,56 +175,92 @@ void assign_positions(pcv_searcher* s) {
         }
 }
 
+// Where the next `n` rows of a source go: the spare room of its last segment first, then new segments.
+// A new segment is sized for what is announced (pcv_searcher_reserve) or, failing that, for as many rows
+// again as the source already holds, so that a source fed by many small adds ends up in O(log n)
+// segments (search.rs:138-140 sizes its per-source index from the row count the same way).
+struct Piece {
+    size_t seg;  // index into src.segs
+    int64_t n;
+};
+std::vector<Piece> place_rows(pcv_searcher* s, Source& src, int64_t n, bool with_ids) {
+    std::vector<Piece> out;
+    int64_t remaining = n;
+    if (!src.segs.empty()) {
+        Segment& tail = src.segs.back();
+        if ((tail.ids != nullptr) == with_ids && tail.nrows < tail.cap_rows) {
+            const int64_t m = std::min<int64_t>(remaining, (int64_t)tail.cap_rows - tail.nrows);
+            out.push_back({src.segs.size() - 1, m});
+            remaining -= m;
+        }
+    }
+    int64_t have = src.rows() + (n - remaining);
+    while (remaining > 0) {
+        const int64_t announced = std::max<int64_t>(0, src.reserve - have);
+        const int64_t spare = std::min<int64_t>(std::max<int64_t>(have, announced), std::max<int64_t>(kGrowCapRows, announced));
+        int64_t cap = std::min<int64_t>(std::max<int64_t>(remaining, spare), kMaxSegRows);
+        const int64_t need = std::min<int64_t>(remaining, kMaxSegRows);
+        Segment g;
+        try {
+            g = alloc_segment(s, cap, with_ids);
+        } catch (const Error& e) {
+            if (e.status != PCV_ERR_DEVICE || cap == need) throw;
+            g = alloc_segment(s, need, with_ids);  // no room for the spare rows: take exactly what is needed
+        }
+        src.segs.push_back(g);
+        const int64_t m = std::min<int64_t>(remaining, (int64_t)g.cap_rows);
+        out.push_back({src.segs.size() - 1, m});
+        remaining -= m;
+        have += m;
+    }
+    return out;
+}
+
+// build_sources row insert (search.rs:87-113,146-148): rows go to the device as they arrive — staged in
+// steps of kStageRows and packed into the blocked layout — so the host never holds more than the caller's
+// own buffer.  `rows` is row-major f32 or, equivalently on this little-endian host, the blob bytes.
+void append_rows(pcv_searcher* s, Source& src, const int64_t* ids, const void* rows, int64_t n) {
+    hipStream_t st = s->ctx->stream;
+    const size_t row_bytes = (size_t)s->D * sizeof(float);
+    s->dirty = true;
+    int64_t done = 0;
+    for (const Piece& pc : place_rows(s, src, n, true)) {
+        for (int64_t off = 0; off < pc.n;) {
+            Segment& g = src.segs[pc.seg];
+            const int64_t m = std::min<int64_t>(kStageRows, pc.n - off);
+            s->d_stage.ensure((size_t)std::min<int64_t>(kStageRows, std::max<int64_t>(m, std::min<int64_t>(n, kStageRows))) * s->D);
+            PCV_HIP(hipMemcpyAsync(s->d_stage.p, (const uint8_t*)rows + (size_t)done * row_bytes, (size_t)m * row_bytes,
+                                   hipMemcpyHostToDevice, st));
+            launch_pack_rows(st, s->d_stage.p, m, s->D, s->D4, g.blk, g.nrows);
+            if (ids)
+                PCV_HIP(hipMemcpyAsync(g.ids + g.nrows, ids + done, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, st));
+            else
+                launch_iota_ids(st, g.ids + g.nrows, src.next_implicit_id + done, m);
+            PCV_HIP(hipStreamSynchronize(st));  // the staging buffer (and the caller's memory) are free again
+            g.nrows += (uint32_t)m;
+            off += m;
+            done += m;
+        }
+    }
+    src.next_implicit_id += n;
+}
+
 void do_finalize(pcv_searcher* s) {
     hipStream_t st = s->ctx->stream;
-    constexpr int64_t kStageRows = 1 << 18;  // rows per H2D staging step (384-d: 400 MB)
     for (auto& src : s->sources) {
-        if (src.pend_n > 0) {
-            Segment g = alloc_segment(s, src.pend_n, src.pend_ids_explicit);
-            g.id0 = src.pend_ids_explicit ? 0 : src.pend_ids.empty() ? 0 : src.pend_ids[0];
-            float* d_stage = nullptr;
-            try {
-                const int64_t stage_rows = std::min<int64_t>(kStageRows, src.pend_n);
-                PCV_HIP(hipMalloc((void**)&d_stage, (size_t)stage_rows * s->D * sizeof(float)));
-                for (int64_t r0 = 0; r0 < src.pend_n; r0 += stage_rows) {
-                    const int64_t n = std::min(stage_rows, src.pend_n - r0);
-                    PCV_HIP(hipMemcpyAsync(d_stage, src.pend_rows.data() + (size_t)r0 * s->D,
-                                           (size_t)n * s->D * sizeof(float), hipMemcpyHostToDevice, st));
-                    launch_pack_rows(st, d_stage, n, s->D, s->D4, g.blk, g.nblocks, (uint32_t)r0);
-                    PCV_HIP(hipStreamSynchronize(st));  // d_stage is reused
-                }
-                if (src.pend_ids_explicit)
-                    PCV_HIP(hipMemcpyAsync(g.ids, src.pend_ids.data(), (size_t)src.pend_n * sizeof(int64_t),
-                                           hipMemcpyHostToDevice, st));
-                finish_segment(s, g);
-                PCV_HIP(hipStreamSynchronize(st));
-            } catch (...) {
-                if (d_stage) hipFree(d_stage);
-                free_segment(g);
-                throw;
-            }
-            hipFree(d_stage);
-            src.segs.push_back(g);
-            std::vector<float>().swap(src.pend_rows);
-            std::vector<int64_t>().swap(src.pend_ids);
-            src.pend_n = 0;
-            src.pend_ids_explicit = false;
+        for (auto& g : src.segs) {
+            if (g.scaled_rows >= g.nrows) continue;
+            launch_row_scales(st, g.blk, g.scaled_rows / kBlockRows, g.nblocks(), g.nrows, s->D4, s->metric, g.scale,
+                              s->d_max_norm_bits);
+            g.scaled_rows = g.nrows;
         }
-        for (const SynthSpec& sp : src.pend_synth) {
-            Segment g = alloc_segment(s, sp.n, false);
-            g.id0 = sp.first_row;
-            try {
-                launch_synth_fill(st, g.blk, g.nblocks, g.nrows, 0, s->D, s->D4, sp.seed, sp.first_row, sp.normalize);
-                finish_segment(s, g);
-                PCV_HIP(hipStreamSynchronize(st));
-                PCV_HIP(hipGetLastError());
-            } catch (...) {
-                free_segment(g);
-                throw;
-            }
-            src.segs.push_back(g);
+        // a reserved but never filled tail is given back
+        while (!src.segs.empty() && src.segs.back().nrows == 0) {
+            PCV_HIP(hipStreamSynchronize(st));
+            free_segment(src.segs.back());
+            src.segs.pop_back();
         }
-        src.pend_synth.clear();
+        src.reserve = 0;
     }
     // sources emptied by clear_source and never refilled disappear (rebuild_source, search.rs:67-69)
     s->sources.erase(std::remove_if(s->sources.begin(), s->sources.end(),
@@ -228,8 +268,11 @@ void do_finalize(pcv_searcher* s) {
                      s->sources.end());
     assign_positions(s);
     uint32_t bits = 0;
-    PCV_HIP(hipMemcpy(&bits, s->d_max_norm_bits, 4, hipMemcpyDeviceToHost));
+    PCV_HIP(hipMemcpyAsync(&bits, s->d_max_norm_bits, 4, hipMemcpyDeviceToHost, st));
+    PCV_HIP(hipStreamSynchronize(st));
+    PCV_HIP(hipGetLastError());
     std::memcpy(&s->max_norm, &bits, 4);
+    s->d_stage.release();
     s->dirty = false;
 }
 
@@ -237,114 +280,145 @@ struct SelSeg {
     const Segment* g;
 };
 
+// source_ids == NULL: every source; otherwise exactly the n_sources listed ones (search.rs:166 — an
+// empty list matches nothing)
 std::vector<SelSeg> select_segments(pcv_searcher* s, const int64_t* source_ids, int n_sources) {
     std::vector<SelSeg> out;
+    const bool all = source_ids == nullptr;
     for (const auto& src : s->sources) {
-        bool sel = (n_sources <= 0 || source_ids == nullptr);
+        bool sel = all;
         for (int i = 0; i < n_sources && !sel; ++i) sel = (source_ids[i] == src.id);  // search.rs:166
         if (!sel) continue;
-        for (const auto& g : src.segs) out.push_back({&g});
+        for (const auto& g : src.segs)
+            if (g.nrows > 0) out.push_back({&g});
     }
     return out;
 }
 
 void ensure_workspace(pcv_searcher* s) {
     const size_t Q = kMfmaQueries;
-    s->d_queries.ensure(Q * s->D);
     s->d_qf32.ensure(Q * s->Dp);
     s->d_qraw.ensure(Q * s->Dp);
     s->d_qbf16.ensure(Q * s->Dp);
     s->d_margin.ensure(Q);
-    s->d_qnorm2.ensure(Q);
+    s->d_margin32.ensure(Q);
     s->d_tau.ensure(Q * kHot);
     s->d_slots.ensure(Q * kMaxK);
     s->d_cnt.ensure(Q * kHot);
-    s->d_cnt_out.ensure(Q);
+    s->d_ticket.ensure(64);
     s->d_cand.ensure(Q * s->cand_cap);
     s->d_cand_score.ensure(Q * s->cand_cap);
     s->d_cand_s.ensure(Q * s->cand_cap);
-    s->d_seed_part.ensure(Q * kSeedParts * kMaxK);
     s->d_hits.ensure(Q * kMaxK);
-    s->d_params.ensure(1);
     if (!s->pin) PCV_HIP(hipHostMalloc((void**)&s->pin, sizeof(pcv_searcher::Pinned), hipHostMallocDefault));
-    if (!s->pin_queries) PCV_HIP(hipHostMalloc((void**)&s->pin_queries, Q * s->D * sizeof(float), hipHostMallocDefault));
     for (auto& e : s->ev)
         if (!e) PCV_HIP(hipEventCreate(&e));
 }
 
-// Queue one pass (<= pass_queries() queries over <= kMaxSeg segments) on the context stream without
-// waiting for it: H2D of the queries and parameters, prep, seed, scan, rescore, select into `d_out`
-// ([B][k] hits; nullptr = s->d_hits), the candidate counts' way back into pinned memory and, if
-// `download`, the hits' too.  `d_flag` != nullptr receives the overflow record (scan.h).
+// offsets inside the pass block
+struct PassLayout {
+    size_t off_seg, off_q, total;
+};
+PassLayout pass_layout(const pcv_searcher* s, size_t nseg) {
+    PassLayout L;
+    L.off_seg = align_up(sizeof(ScanParams));
+    L.off_q = align_up(L.off_seg + nseg * sizeof(SegDesc));
+    L.total = L.off_q + (size_t)kMfmaQueries * s->D * sizeof(float);
+    return L;
+}
+void ensure_pass_block(pcv_searcher* s, size_t nseg) {
+    const size_t want = pass_layout(s, nseg).total;
+    if (want <= s->pass_cap) return;
+    PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+    if (s->pin_pass) (void)hipHostFree(s->pin_pass);
+    if (s->d_pass) (void)hipFree(s->d_pass);
+    s->pin_pass = s->d_pass = nullptr;
+    s->pass_cap = 0;
+    const size_t cap = want + want / 2;
+    PCV_HIP(hipHostMalloc((void**)&s->pin_pass, cap, hipHostMallocDefault));
+    PCV_HIP(hipMalloc((void**)&s->d_pass, cap));
+    s->pass_cap = cap;
+}
+
+// Queue one pass (<= pass_queries() queries over any number of segments) on the context stream without
+// waiting for it: one H2D of (parameters, segment table, queries), then prep_seed, scan and
+// rescore_select, which writes the [B][k] hits into `d_out` (nullptr = s->d_hits) and — if `download` —
+// into pinned host memory as well; the survivor counts always come back that way.  `d_flag` != nullptr
+// receives the overflow record (scan.h).
 void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel,
                   pcv_hit_dev* d_out, bool download, pcv_hit_dev* d_flag) {
     const auto t_begin = std::chrono::steady_clock::now();
     hipStream_t st = s->ctx->stream;
     ensure_workspace(s);
-    if (queries_host) {  // nullptr: the queries of the previous attempt are still on the device
-        std::memcpy(s->pin_queries, queries_host, (size_t)B * s->D * sizeof(float));
-        PCV_HIP(hipMemcpyAsync(s->d_queries.p, s->pin_queries, (size_t)B * s->D * sizeof(float), hipMemcpyHostToDevice, st));
-    }
-    ScanParams& p = s->pin->params;
+    ensure_pass_block(s, (size_t)nseg);
+    if (!s->state_clean) launch_reset_scan_state(st, s->d_tau.p, s->d_slots.p, s->d_cnt.p, s->d_ticket.p);
+    s->state_clean = false;  // until finish_pass has seen the pass through
+    const PassLayout L = pass_layout(s, (size_t)nseg);
+    ScanParams& p = *reinterpret_cast<ScanParams*>(s->pin_pass);
+    SegDesc* tab = reinterpret_cast<SegDesc*>(s->pin_pass + L.off_seg);
     p = ScanParams{};
     uint32_t blk0 = 0;
     int64_t rows = 0;
     for (int i = 0; i < nseg; ++i) {
         const Segment& g = *segs[i].g;
-        p.seg[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks, blk0, 0};
-        blk0 += g.nblocks;
+        tab[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), blk0, 0};
+        PCV_REQUIRE((uint64_t)blk0 + g.nblocks() < 0xffffff00ull, "search: more than 2^32 row blocks in one launch");
+        blk0 += g.nblocks();
         rows += g.nrows;
     }
+    p.seg = reinterpret_cast<const SegDesc*>(s->d_pass + L.off_seg);
     p.nseg = nseg;
     p.total_blocks = blk0;
+    p.D = s->D;
     p.D4 = s->D4;
     p.B = B;
     p.k = k;
     p.metric = s->metric;
+    p.tile_rows = kernel == PCV_KERNEL_MFMA ? mfma_tile_rows(B) : 0u;
+    p.queries = reinterpret_cast<const float*>(s->d_pass + L.off_q);
     p.qf32 = s->d_qf32.p;
     p.qbf16 = s->d_qbf16.p;
     p.qraw = s->d_qraw.p;
-    p.qnorm2 = s->d_qnorm2.p;
     p.margin = s->d_margin.p;
+    p.margin32 = s->d_margin32.p;
     p.tau = s->d_tau.p;
     p.slots = s->d_slots.p;
     p.cand_cnt = s->d_cnt.p;
-    p.cand_cnt_out = s->d_cnt_out.p;
     p.cand = s->d_cand.p;
-    p.cand_score = s->d_cand_score.p;
     p.cand_s = s->d_cand_s.p;
-    p.seed_part = s->d_seed_part.p;
+    p.cand_score = s->d_cand_score.p;
+    p.ticket = s->d_ticket.p;
+    p.out = d_out ? d_out : s->d_hits.p;
+    p.out_host = download ? s->pin->hits : nullptr;
+    p.cnt_host = s->pin->cnt;
+    p.flag_rec = d_flag;
     p.cand_cap = s->cand_cap;
     p.flags = s->scan_flags;
     const uint32_t seed_parts = ((s->scan_flags >> 16) & 0xff) ? ((s->scan_flags >> 16) & 0xff) : kSeedParts;  // tuning
-    p.seed_blocks =
-        nseg > 0 ? std::min<uint32_t>(std::min<uint32_t>(seed_parts, kSeedParts) * kSeedPartRows / kBlockRows, segs[0].g->nblocks) : 0;
+    p.seed_blocks = std::min<uint32_t>(std::min<uint32_t>(seed_parts, kSeedParts) * kSeedPartRows / kBlockRows, segs[0].g->nblocks());
+    // |s - c| bounds of the screening scores, relative to |q||x| (DESIGN.md §screening error): an f32 FMA
+    // chain in any order, and one bf16 rounding per operand on top of it
+    p.eps32 = (float)(s->Dp + 16) * 1.2e-7f;
+    p.eps16 = 0.0039101f + 2.0f * p.eps32;
+    p.max_norm = s->max_norm;
 
-    // |s - c| bound of the screening score, relative to |q||x| (DESIGN.md §screening error)
-    const float eps_f32 = (float)(s->Dp + 16) * 1.2e-7f;
-    const float eps_rel = (kernel == PCV_KERNEL_MFMA) ? 0.0039101f + 2.0f * eps_f32 : eps_f32;
-
-    const ScanParams* dp = s->d_params.p;
-    pcv_hit_dev* out = d_out ? d_out : s->d_hits.p;
-    PCV_HIP(hipMemcpyAsync(s->d_params.p, &p, sizeof(ScanParams), hipMemcpyHostToDevice, st));
+    size_t bytes = L.off_q;
+    if (queries_host) {  // nullptr: the queries of the previous attempt are still on the device
+        std::memcpy(s->pin_pass + L.off_q, queries_host, (size_t)B * s->D * sizeof(float));
+        bytes += (size_t)B * s->D * sizeof(float);
+    }
+    const ScanParams* dp = reinterpret_cast<const ScanParams*>(s->d_pass);
     PCV_HIP(hipEventRecord(s->ev[0], st));
-    launch_prep_queries(st, s->d_queries.p, B, s->D, s->Dp, s->metric, eps_rel, s->max_norm, k, s->d_qf32.p,
-                        s->d_qbf16.p, s->d_qraw.p, s->d_qnorm2.p, s->d_margin.p, s->d_tau.p, s->d_slots.p,
-                        s->d_cnt.p);
-    launch_seed(st, p, dp);
+    PCV_HIP(hipMemcpyAsync(s->d_pass, s->pin_pass, bytes, hipMemcpyHostToDevice, st));
+    launch_prep_seed(st, p, dp);
     PCV_HIP(hipEventRecord(s->ev[1], st));
     if (kernel == PCV_KERNEL_MFMA)
         launch_scan_mfma(st, p, dp, s->ctx->num_cus);
     else
         launch_scan_wave(st, p, dp, s->ctx->num_cus);
     PCV_HIP(hipEventRecord(s->ev[2], st));
-    launch_rescore(st, p, dp);
-    launch_select(st, p, dp, out);
+    launch_rescore_select(st, p, dp);
     PCV_HIP(hipEventRecord(s->ev[3], st));
-    if (d_flag) launch_overflow_flag(st, s->d_cnt_out.p, B, s->cand_cap, d_flag);
-    PCV_HIP(hipMemcpyAsync(s->pin->cnt, s->d_cnt_out.p, (size_t)B * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    if (download)
-        PCV_HIP(hipMemcpyAsync(s->pin->hits, out, (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
     s->pending.active = true;
     s->pending.done = false;
     s->pending.B = B;
@@ -359,16 +433,17 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
 bool finish_pass(pcv_searcher* s) {
     PCV_REQUIRE(s->pending.active, "no pass is pending");
     s->pending.active = false;
-    if (s->pending.done) return false;
     const auto t_begin = std::chrono::steady_clock::now();
-    PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+    PCV_HIP(hipStreamSynchronize(s->ctx->stream));  // also when nothing was launched: the caller's exchange may be queued
     s->stats.host_wait_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     PCV_HIP(hipGetLastError());
+    if (s->pending.done) return false;
+    s->state_clean = true;  // rescore_select_kernel left the scan state as a pass expects it
     const int B = s->pending.B;
     const int64_t rows = s->pending.rows;
     float ms_scan = 0, ms_total = 0;
-    hipEventElapsedTime(&ms_scan, s->ev[1], s->ev[2]);
-    hipEventElapsedTime(&ms_total, s->ev[0], s->ev[3]);
+    (void)hipEventElapsedTime(&ms_scan, s->ev[1], s->ev[2]);
+    (void)hipEventElapsedTime(&ms_total, s->ev[0], s->ev[3]);
     s->stats.scan_ms += ms_scan;
     s->stats.total_ms += ms_total;
     s->stats.scan_launches += 1;
@@ -396,10 +471,11 @@ bool finish_pass(pcv_searcher* s) {
     return true;
 }
 
-// One pass, synchronously.  Leaves [B][k] hits in s->d_hits and in s->pin->hits.
-void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel) {
+// One pass, synchronously.  Leaves [B][k] hits in `d_out` (nullptr = s->d_hits) and, if `download`, in s->pin->hits.
+void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel,
+              pcv_hit_dev* d_out, bool download) {
     for (int attempt = 0;; ++attempt) {
-        enqueue_pass(s, attempt == 0 ? queries_host : nullptr, B, segs, nseg, k, kernel, nullptr, true, nullptr);
+        enqueue_pass(s, attempt == 0 ? queries_host : nullptr, B, segs, nseg, k, kernel, d_out, download, nullptr);
         if (!finish_pass(s)) return;
         PCV_REQUIRE(attempt < 6, "candidate lists still overflow after %d reruns", attempt + 1);
     }
@@ -422,12 +498,16 @@ int pass_queries(const pcv_searcher* s, int kernel) {
     return kernel == PCV_KERNEL_WAVE ? kMaxWaveQueries : mfma_pass_queries(s->Dp);
 }
 
+void check_search_args(const pcv_searcher* s, const float* queries, int n_queries, int k, const char* who) {
+    PCV_REQUIRE(!s->dirty, "%s: rows were added or cleared without pcv_searcher_finalize", who);
+    PCV_REQUIRE(queries != nullptr && n_queries > 0, "%s: no queries", who);
+    PCV_REQUIRE(k > 0 && k <= kMaxK, "%s: num_results %d outside [1,%d]", who, k, kMaxK);
+}
+
 // Full search: any number of queries / segments; result [n_queries][k] hits on the host.
 void search_hits(pcv_searcher* s, const float* queries, int n_queries, const int64_t* source_ids, int n_sources,
                  int k, std::vector<pcv_hit_dev>& out) {
-    PCV_REQUIRE(!s->dirty, "search: rows were added or cleared without pcv_searcher_finalize");
-    PCV_REQUIRE(queries != nullptr && n_queries > 0, "search: no queries");
-    PCV_REQUIRE(k > 0 && k <= kMaxK, "search: num_results %d outside [1,%d]", k, kMaxK);
+    check_search_args(s, queries, n_queries, k, "search");
     PCV_HIP(hipSetDevice(s->ctx->device));
     std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
     const pcv_hit_dev none{NAN, -1, -1};
@@ -437,28 +517,10 @@ void search_hits(pcv_searcher* s, const float* queries, int n_queries, const int
     s->stats.kernel_used = kernel;
     if (segs.empty()) return;
     const int qstep = pass_queries(s, kernel);
-    std::vector<pcv_hit_dev> tmp((size_t)qstep * k);
     for (int q0 = 0; q0 < n_queries; q0 += qstep) {
         const int B = std::min(qstep, n_queries - q0);
-        for (size_t g0 = 0; g0 < segs.size(); g0 += kMaxSeg) {
-            const int nseg = (int)std::min<size_t>(kMaxSeg, segs.size() - g0);
-            run_pass(s, queries + (size_t)q0 * s->D, B, segs.data() + g0, nseg, k, kernel);
-            std::memcpy(tmp.data(), s->pin->hits, (size_t)B * k * sizeof(pcv_hit_dev));  // came down with the pass
-            for (int b = 0; b < B; ++b) {
-                pcv_hit_dev* dst = out.data() + (size_t)(q0 + b) * k;
-                if (g0 == 0) {
-                    std::copy(tmp.begin() + (size_t)b * k, tmp.begin() + (size_t)(b + 1) * k, dst);
-                } else {  // more than kMaxSeg segments: merge this group's list into the running one
-                    std::vector<pcv_hit_dev> m;
-                    for (int j = 0; j < k; ++j) {
-                        if (dst[j].pos >= 0) m.push_back(dst[j]);
-                        if (tmp[(size_t)b * k + j].pos >= 0) m.push_back(tmp[(size_t)b * k + j]);
-                    }
-                    std::sort(m.begin(), m.end(), hit_better);
-                    for (int j = 0; j < k; ++j) dst[j] = j < (int)m.size() ? m[j] : none;
-                }
-            }
-        }
+        run_pass(s, queries + (size_t)q0 * s->D, B, segs.data(), (int)segs.size(), k, kernel, nullptr, true);
+        std::memcpy(out.data() + (size_t)q0 * k, s->pin->hits, (size_t)B * k * sizeof(pcv_hit_dev));  // came down with the pass
     }
 }
 
@@ -489,6 +551,36 @@ void hits_to_outputs(int metric, int D, const pcv_hit_dev* hits, int n_queries, 
     }
 }
 
+// The per-shard pass of the begin/end protocol; the caller holds s->mu.
+void device_begin(pcv_searcher* s, const float* queries, int n_queries, const int64_t* source_ids, int n_sources, int k,
+                  pcv_hit_dev* out) {
+    check_search_args(s, queries, n_queries, k, "search_device_begin");
+    PCV_REQUIRE(!s->pending.active, "search_device_begin: the previous pass was not collected (search_device_end)");
+    PCV_HIP(hipSetDevice(s->ctx->device));
+    std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
+    const int kernel = pick_kernel(s, n_queries);
+    // Only a condition every rank evaluates alike may refuse: the ranks of a sharded search must all
+    // take the same protocol (the exchanged payload differs by the overflow record).
+    if (n_queries > pass_queries(s, kernel))
+        PCV_FAIL(PCV_ERR_UNSUPPORTED, "search_device_begin: %d queries need more than one pass", n_queries);
+    const size_t n = (size_t)n_queries * k;
+    s->stats = pcv_scan_stats{};
+    s->stats.kernel_used = kernel;
+    if (segs.empty()) {
+        // this shard holds none of the selected rows: hand over the same layout — empty lists and a clear
+        // overflow record — from pinned memory; search_device_end waits for the copy like for a pass
+        ensure_workspace(s);
+        const pcv_hit_dev none{NAN, -1, -1};
+        for (size_t i = 0; i < n; ++i) s->pin->hits[i] = none;
+        s->pin->hits[n] = pcv_hit_dev{0.0, 0, 0};
+        PCV_HIP(hipMemcpyAsync(out, s->pin->hits, (n + 1) * sizeof(pcv_hit_dev), hipMemcpyHostToDevice, s->ctx->stream));
+        s->pending.active = true;
+        s->pending.done = true;
+        return;
+    }
+    enqueue_pass(s, queries, n_queries, segs.data(), (int)segs.size(), k, kernel, out, false, out + n);
+}
+
 }  // namespace
 
 extern "C" {
@@ -501,52 +593,63 @@ pcv_status pcv_searcher_create(pcv_ctx* ctx, int dim, int metric, pcv_searcher**
         PCV_REQUIRE(metric == PCV_METRIC_COSINE || metric == PCV_METRIC_DOT, "searcher_create: unknown metric %d",
                     metric);
         PCV_HIP(hipSetDevice(ctx->device));
-        auto* s = new pcv_searcher();
+        auto s = std::make_unique<pcv_searcher>();
         s->ctx = ctx;
         s->D = dim;
         s->Dp = (dim + 63) / 64 * 64;
         s->D4 = s->Dp / 4;
         s->metric = metric;
         if (const char* f = getenv("PCV_SCAN_FLAGS")) s->scan_flags = (uint32_t)strtoul(f, nullptr, 0);
-        hipError_t e = hipMalloc((void**)&s->d_max_norm_bits, 4);
+        PCV_HIP(hipMalloc((void**)&s->d_max_norm_bits, 4));
+        // on the stream the row_scales atomics will run on (the context stream does not wait for the null stream)
+        hipError_t e = hipMemsetAsync(s->d_max_norm_bits, 0, 4, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
-            delete s;
-            PCV_FAIL(PCV_ERR_DEVICE, "searcher_create: hipMalloc failed: %s", hipGetErrorString(e));
+            (void)hipFree(s->d_max_norm_bits);
+            PCV_FAIL(PCV_ERR_DEVICE, "searcher_create: %s", hipGetErrorString(e));
         }
-        hipMemset(s->d_max_norm_bits, 0, 4);
-        *out = s;
+        *out = s.release();
     });
 }
 
 pcv_status pcv_searcher_destroy(pcv_searcher* s) {
     return guarded([&] {
         if (!s) return;
-        hipSetDevice(s->ctx->device);
-        hipStreamSynchronize(s->ctx->stream);
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
         for (auto& src : s->sources)
             for (auto& g : src.segs) free_segment(g);
-        s->d_queries.release();
+        s->d_stage.release();
         s->d_qf32.release();
         s->d_qraw.release();
         s->d_margin.release();
+        s->d_margin32.release();
         s->d_qbf16.release();
-        s->d_qnorm2.release();
         s->d_cand_score.release();
         s->d_cand_s.release();
-        s->d_seed_part.release();
         s->d_tau.release();
         s->d_slots.release();
         s->d_cnt.release();
-        s->d_cnt_out.release();
+        s->d_ticket.release();
         s->d_cand.release();
         s->d_hits.release();
-        s->d_params.release();
-        if (s->pin) hipHostFree(s->pin);
-        if (s->pin_queries) hipHostFree(s->pin_queries);
-        if (s->d_max_norm_bits) hipFree(s->d_max_norm_bits);
+        if (s->pin) (void)hipHostFree(s->pin);
+        if (s->pin_pass) (void)hipHostFree(s->pin_pass);
+        if (s->d_pass) (void)hipFree(s->d_pass);
+        if (s->d_max_norm_bits) (void)hipFree(s->d_max_norm_bits);
         for (auto& e : s->ev)
-            if (e) hipEventDestroy(e);
+            if (e) (void)hipEventDestroy(e);
         delete s;
+    });
+}
+
+pcv_status pcv_searcher_reserve(pcv_searcher* s, int64_t source_id, int64_t n_rows) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "reserve: searcher is NULL");
+        PCV_REQUIRE(n_rows >= 0, "reserve: negative row count");
+        std::lock_guard<std::mutex> lk(s->mu);
+        Source& src = s->get_or_add_source(source_id);
+        src.reserve = src.rows() + n_rows;
     });
 }
 
@@ -558,15 +661,8 @@ pcv_status pcv_searcher_add_rows(pcv_searcher* s, int64_t source_id, const int64
         std::lock_guard<std::mutex> lk(s->mu);
         Source& src = s->get_or_add_source(source_id);
         if (n == 0) return;
-        if (ids && !src.pend_ids_explicit) {
-            // earlier implicit ids of this pending batch become explicit
-            src.pend_ids_explicit = true;
-        }
-        src.pend_rows.insert(src.pend_rows.end(), rows, rows + (size_t)n * s->D);
-        for (int64_t i = 0; i < n; ++i) src.pend_ids.push_back(ids ? ids[i] : src.next_implicit_id + i);
-        src.next_implicit_id += n;
-        src.pend_n += n;
-        s->dirty = true;
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        append_rows(s, src, ids, rows, n);
     });
 }
 
@@ -575,31 +671,60 @@ pcv_status pcv_searcher_add_blobs(pcv_searcher* s, int64_t source_id, const int6
     return guarded([&] {
         PCV_REQUIRE(s != nullptr, "add_blobs: searcher is NULL");
         PCV_REQUIRE(n >= 0 && (blobs != nullptr || n == 0), "add_blobs: bad blobs/n");
-        std::vector<float> rows((size_t)n * s->D);
-        for (size_t i = 0; i < rows.size(); ++i) {  // deserialize_embedding, search.rs:281-286
-            const uint8_t* b = blobs + 4 * i;
-            const uint32_t u = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
-            std::memcpy(&rows[i], &u, 4);
+        // deserialize_embedding (search.rs:281-286) reads little-endian f32; this library only runs on
+        // little-endian hosts (x86-64 + gfx950), where that is the identity on the bytes
+        const uint32_t probe = 1;
+        PCV_REQUIRE(*reinterpret_cast<const uint8_t*>(&probe) == 1, "add_blobs: big-endian host");
+        std::lock_guard<std::mutex> lk(s->mu);
+        Source& src = s->get_or_add_source(source_id);
+        if (n == 0) return;
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        append_rows(s, src, ids, blobs, n);
+    });
+}
+
+static pcv_status add_synthetic(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed, int64_t first_row,
+                                int normalize, int n_clusters, float noise) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "add_synthetic: searcher is NULL");
+        PCV_REQUIRE(n >= 0, "add_synthetic: negative row count");
+        PCV_REQUIRE(n_clusters >= 0 && noise >= 0.0f && std::isfinite(noise), "add_synthetic: bad cluster shape");
+        PCV_REQUIRE(s->D % 4 == 0, "add_synthetic: dim %d is not a multiple of 4", s->D);
+        std::lock_guard<std::mutex> lk(s->mu);
+        Source& src = s->get_or_add_source(source_id);
+        if (n == 0) return;
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        hipStream_t st = s->ctx->stream;
+        // one segment per <= 2^31 rows, generated in place
+        const int64_t kMaxRows = (int64_t)1 << 31;
+        for (int64_t r0 = 0; r0 < n; r0 += kMaxRows) {
+            const int64_t m = std::min(kMaxRows, n - r0);
+            Segment g = alloc_segment(s, m, false);
+            g.id0 = first_row + r0;
+            try {
+                launch_synth_fill(st, g.blk, (uint32_t)m, 0, s->D, s->D4, seed, first_row + r0, normalize,
+                                  (uint32_t)n_clusters, noise);
+                PCV_HIP(hipStreamSynchronize(st));
+                PCV_HIP(hipGetLastError());
+            } catch (...) {
+                free_segment(g);
+                throw;
+            }
+            g.nrows = (uint32_t)m;
+            src.segs.push_back(g);
+            s->dirty = true;
         }
-        pcv_status st = pcv_searcher_add_rows(s, source_id, ids, rows.data(), n);
-        if (st != PCV_OK) throw Error{st};
     });
 }
 
 pcv_status pcv_searcher_add_synthetic(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
                                       int64_t first_row, int normalize) {
-    return guarded([&] {
-        PCV_REQUIRE(s != nullptr, "add_synthetic: searcher is NULL");
-        PCV_REQUIRE(n >= 0, "add_synthetic: negative row count");
-        PCV_REQUIRE(s->D % 4 == 0, "add_synthetic: dim %d is not a multiple of 4", s->D);
-        std::lock_guard<std::mutex> lk(s->mu);
-        Source& src = s->get_or_add_source(source_id);
-        // one segment per <= 2^31 rows
-        const int64_t kMaxRows = (int64_t)1 << 31;
-        for (int64_t r0 = 0; r0 < n; r0 += kMaxRows)
-            src.pend_synth.push_back({std::min(kMaxRows, n - r0), seed, first_row + r0, normalize});
-        if (n > 0) s->dirty = true;
-    });
+    return add_synthetic(s, source_id, n, seed, first_row, normalize, 0, 0.0f);
+}
+
+pcv_status pcv_searcher_add_synthetic_clustered(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
+                                                int64_t first_row, int normalize, int n_clusters, float noise) {
+    return add_synthetic(s, source_id, n, seed, first_row, normalize, n_clusters, noise);
 }
 
 pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id) {
@@ -612,12 +737,8 @@ pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id) {
         PCV_HIP(hipStreamSynchronize(s->ctx->stream));
         for (auto& g : src->segs) free_segment(g);
         src->segs.clear();
-        std::vector<float>().swap(src->pend_rows);
-        std::vector<int64_t>().swap(src->pend_ids);
-        src->pend_synth.clear();
-        src->pend_n = 0;
-        src->pend_ids_explicit = false;
         src->next_implicit_id = 0;
+        src->reserve = 0;
         s->dirty = true;
     });
 }
@@ -636,9 +757,18 @@ pcv_status pcv_searcher_num_rows(pcv_searcher* s, int64_t* out_rows) {
         PCV_REQUIRE(s != nullptr && out_rows != nullptr, "num_rows: NULL argument");
         std::lock_guard<std::mutex> lk(s->mu);
         int64_t n = 0;
-        for (auto& src : s->sources)
-            for (auto& g : src.segs) n += g.nrows;
+        for (auto& src : s->sources) n += src.rows();
         *out_rows = n;
+    });
+}
+
+pcv_status pcv_searcher_num_segments(pcv_searcher* s, int* out_n) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && out_n != nullptr, "num_segments: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        int n = 0;
+        for (auto& src : s->sources) n += (int)src.segs.size();
+        *out_n = n;
     });
 }
 
@@ -665,8 +795,7 @@ pcv_status pcv_searcher_source_num_rows(pcv_searcher* s, int64_t source_id, int6
         std::lock_guard<std::mutex> lk(s->mu);
         PCV_REQUIRE(!s->dirty, "source_num_rows: pending rows; call pcv_searcher_finalize first");
         *out_rows = 0;
-        if (Source* src = s->find_source(source_id))
-            for (const Segment& g : src->segs) *out_rows += g.nrows;
+        if (Source* src = s->find_source(source_id)) *out_rows = src->rows();
     });
 }
 
@@ -682,7 +811,7 @@ pcv_status pcv_searcher_get_rows(pcv_searcher* s, const int64_t* positions, int6
         std::vector<SegDesc> segs;
         for (auto& src : s->sources)
             for (auto& g : src.segs)
-                segs.push_back(SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks, 0, 0});
+                segs.push_back(SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), 0, 0});
         DevBuf<SegDesc> d_segs;
         DevBuf<int64_t> d_pos, d_ids;
         DevBuf<float> d_rows;
@@ -735,6 +864,7 @@ pcv_status pcv_searcher_search(pcv_searcher* s, const float* queries, int n_quer
     return guarded([&] {
         PCV_REQUIRE(s != nullptr, "search: searcher is NULL");
         std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->pending.active, "search: a pass queued by search_device_begin has not been collected");
         std::vector<pcv_hit_dev> hits;
         search_hits(s, queries, n_queries, source_ids, n_sources, k, hits);
         hits_to_outputs(s->metric, s->D, hits.data(), n_queries, k, out_ids, out_scores, out_counts);
@@ -746,31 +876,28 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
     return guarded([&] {
         PCV_REQUIRE(s != nullptr && d_out != nullptr, "search_device: NULL argument");
         std::lock_guard<std::mutex> lk(s->mu);
-        PCV_REQUIRE(!s->dirty, "search_device: rows were added or cleared without pcv_searcher_finalize");
-        PCV_REQUIRE(queries != nullptr && n_queries > 0, "search_device: no queries");
-        PCV_REQUIRE(k > 0 && k <= kMaxK, "search_device: num_results %d outside [1,%d]", k, kMaxK);
+        check_search_args(s, queries, n_queries, k, "search_device");
+        PCV_REQUIRE(!s->pending.active, "search_device: a pass queued by search_device_begin has not been collected");
         PCV_HIP(hipSetDevice(s->ctx->device));
         std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
         const int kernel = pick_kernel(s, n_queries);
         const int qstep = pass_queries(s, kernel);
         s->stats = pcv_scan_stats{};
         s->stats.kernel_used = kernel;
-        if (segs.size() <= (size_t)kMaxSeg && !segs.empty()) {
-            // fast path: results stay on the device
-            for (int q0 = 0; q0 < n_queries; q0 += qstep) {
-                const int B = std::min(qstep, n_queries - q0);
-                run_pass(s, queries + (size_t)q0 * s->D, B, segs.data(), (int)segs.size(), k, kernel);
-                PCV_HIP(hipMemcpyAsync((pcv_hit_dev*)d_out + (size_t)q0 * k, s->d_hits.p,
-                                       (size_t)B * k * sizeof(pcv_hit_dev), hipMemcpyDeviceToDevice, s->ctx->stream));
-            }
-        } else {
-            std::vector<pcv_hit_dev> hits;
-            search_hits(s, queries, n_queries, source_ids, n_sources, k, hits);
-            PCV_HIP(hipMemcpyAsync(d_out, hits.data(), hits.size() * sizeof(pcv_hit_dev), hipMemcpyHostToDevice,
-                                   s->ctx->stream));
-            async = 0;  // `hits` dies with this scope
+        pcv_hit_dev* out = (pcv_hit_dev*)d_out;
+        if (segs.empty()) {
+            const pcv_hit_dev none{NAN, -1, -1};
+            std::vector<pcv_hit_dev> hits((size_t)n_queries * k, none);
+            PCV_HIP(hipMemcpyAsync(out, hits.data(), hits.size() * sizeof(pcv_hit_dev), hipMemcpyHostToDevice, s->ctx->stream));
+            PCV_HIP(hipStreamSynchronize(s->ctx->stream));  // `hits` dies with this scope
+            return;
         }
-        if (!async) PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+        // results stay on the device: every pass writes its slice of the caller's list
+        for (int q0 = 0; q0 < n_queries; q0 += qstep) {
+            const int B = std::min(qstep, n_queries - q0);
+            run_pass(s, queries + (size_t)q0 * s->D, B, segs.data(), (int)segs.size(), k, kernel, out + (size_t)q0 * k, false);
+        }
+        (void)async;  // every pass has been collected: nothing is left in flight
     });
 }
 
@@ -779,34 +906,7 @@ pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* querie
     return guarded([&] {
         PCV_REQUIRE(s != nullptr && d_out != nullptr, "search_device_begin: NULL argument");
         std::lock_guard<std::mutex> lk(s->mu);
-        PCV_REQUIRE(!s->dirty, "search_device_begin: rows were added or cleared without pcv_searcher_finalize");
-        PCV_REQUIRE(!s->pending.active, "search_device_begin: the previous pass was not collected (search_device_end)");
-        PCV_REQUIRE(queries != nullptr && n_queries > 0, "search_device_begin: no queries");
-        PCV_REQUIRE(k > 0 && k <= kMaxK, "search_device_begin: num_results %d outside [1,%d]", k, kMaxK);
-        PCV_HIP(hipSetDevice(s->ctx->device));
-        std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
-        const int kernel = pick_kernel(s, n_queries);
-        // Only a condition every rank evaluates alike may refuse: the ranks of a sharded search must all
-        // take the same protocol (the exchanged payload differs by the overflow record).
-        if (n_queries > pass_queries(s, kernel))
-            PCV_FAIL(PCV_ERR_UNSUPPORTED, "search_device_begin: %d queries need more than one pass", n_queries);
-        pcv_hit_dev* out = (pcv_hit_dev*)d_out;
-        const size_t n = (size_t)n_queries * k;
-        if (segs.empty() || segs.size() > (size_t)kMaxSeg) {
-            // this shard holds none of the selected rows, or more segments than one launch takes: finish
-            // here (host-merged groups), hand over the same layout with a clear overflow record
-            std::vector<pcv_hit_dev> hits;
-            search_hits(s, queries, n_queries, source_ids, n_sources, k, hits);
-            hits.push_back(pcv_hit_dev{0.0, 0, 0});
-            PCV_HIP(hipMemcpyAsync(out, hits.data(), (n + 1) * sizeof(pcv_hit_dev), hipMemcpyHostToDevice, s->ctx->stream));
-            PCV_HIP(hipStreamSynchronize(s->ctx->stream));  // `hits` dies with this scope
-            s->pending.active = true;
-            s->pending.done = true;
-            return;
-        }
-        s->stats = pcv_scan_stats{};
-        s->stats.kernel_used = kernel;
-        enqueue_pass(s, queries, n_queries, segs.data(), (int)segs.size(), k, kernel, out, false, out + n);
+        device_begin(s, queries, n_queries, source_ids, n_sources, k, (pcv_hit_dev*)d_out);
     });
 }
 
@@ -825,8 +925,8 @@ namespace {
 void ensure_merge_scratch(pcv_ctx* ctx, size_t n) {
     if (ctx->merge_cap >= n) return;
     PCV_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->merge_dev) hipFree(ctx->merge_dev);
-    if (ctx->merge_pin) hipHostFree(ctx->merge_pin);
+    if (ctx->merge_dev) (void)hipFree(ctx->merge_dev);
+    if (ctx->merge_pin) (void)hipHostFree(ctx->merge_pin);
     ctx->merge_dev = ctx->merge_pin = nullptr;
     ctx->merge_cap = 0;
     PCV_HIP(hipMalloc(&ctx->merge_dev, n * sizeof(pcv_hit_dev)));
@@ -1006,8 +1106,11 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
     return guarded([&] {
         PCV_REQUIRE(s != nullptr && c != nullptr, "search_sharded: NULL argument");
         PCV_REQUIRE(s->ctx == c->ctx, "search_sharded: searcher and communicator live on different contexts");
-        PCV_REQUIRE(queries != nullptr && n_queries > 0, "search_sharded: no queries");
-        PCV_REQUIRE(k > 0 && k <= kMaxK, "search_sharded: num_results %d outside [1,%d]", k, kMaxK);
+        // the whole step — local pass, exchange, merge, collection — is one critical section of the searcher:
+        // it shares the pass workspace, the pinned blocks and the stream with plain searches
+        std::lock_guard<std::mutex> lk(s->mu);
+        check_search_args(s, queries, n_queries, k, "search_sharded");
+        PCV_REQUIRE(!s->pending.active, "search_sharded: a pass queued by search_device_begin has not been collected");
         const size_t n = (size_t)n_queries * k;
         hipStream_t st = s->ctx->stream;
         PCV_HIP(hipSetDevice(s->ctx->device));
@@ -1015,45 +1118,56 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
         c->d_gathered.ensure((n + 1) * c->world);
         c->d_merged.ensure(n + 1);
         if (c->pin_cap < n + 1) {
-            if (c->pin_hits) hipHostFree(c->pin_hits);
+            if (c->pin_hits) (void)hipHostFree(c->pin_hits);
             c->pin_hits = nullptr;
             c->pin_cap = 0;
             PCV_HIP(hipHostMalloc((void**)&c->pin_hits, (n + 1) * sizeof(pcv_hit_dev), hipHostMallocDefault));
             c->pin_cap = n + 1;
         }
-        auto exchange = [&](int flagged) {  // all-gather + merge + download, queued behind the local pass
-            const size_t rec = n + flagged;
-            rccl_check(rccl().AllGather(c->d_local.p, c->d_gathered.p, rec * sizeof(pcv_hit_dev), /*ncclInt8*/ 0, c->comm, st),
+        auto exchange = [&](const pcv_hit_dev* local, size_t nq, int flagged) {  // all-gather + merge + download, queued behind the local pass
+            const size_t rec = nq * k + flagged;
+            rccl_check(rccl().AllGather(local, c->d_gathered.p, rec * sizeof(pcv_hit_dev), /*ncclInt8*/ 0, c->comm, st),
                        "ncclAllGather");
-            launch_merge(st, c->d_gathered.p, c->world, n_queries, k, c->d_merged.p, flagged);
+            launch_merge(st, c->d_gathered.p, c->world, (int)nq, k, c->d_merged.p, flagged);
             PCV_HIP(hipMemcpyAsync(c->pin_hits, c->d_merged.p, rec * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
         };
-        // One pass fits: everything is queued back to back and the host waits once.  Whether a list
-        // overflowed somewhere is part of the exchanged payload, so all ranks repeat (or not) together.
-        for (int attempt = 0;; ++attempt) {
-            pcv_status rc = pcv_searcher_search_device_begin(s, queries, n_queries, source_ids, n_sources, k, c->d_local.p);
-            if (rc == PCV_ERR_UNSUPPORTED && attempt == 0) break;  // several passes: the sequential form below
-            if (rc != PCV_OK) throw Error{rc};
-            try {
-                exchange(1);
-            } catch (...) {
-                pcv_searcher_search_device_end(s, nullptr);  // collect the queued pass before reporting
-                throw;
+        const int qstep = pass_queries(s, pick_kernel(s, n_queries));  // every rank computes the same split
+        std::vector<pcv_hit_dev> all(n);
+        pcv_scan_stats total{};
+        for (int q0 = 0; q0 < n_queries; q0 += qstep) {
+            const int B = std::min(qstep, n_queries - q0);
+            const size_t nb = (size_t)B * k;
+            // One pass: everything is queued back to back and the host waits once.  Whether a list
+            // overflowed somewhere is part of the exchanged payload, so all ranks repeat (or not) together.
+            for (int attempt = 0;; ++attempt) {
+                device_begin(s, queries + (size_t)q0 * s->D, B, source_ids, n_sources, k, c->d_local.p);
+                try {
+                    exchange(c->d_local.p, (size_t)B, 1);
+                } catch (...) {
+                    try {
+                        finish_pass(s);  // collect the queued pass before reporting
+                    } catch (...) {
+                    }
+                    throw;
+                }
+                finish_pass(s);  // waits for the stream (pass, all-gather, merge, download); grows this rank's lists if needed
+                if (c->pin_hits[nb].pos == 0) break;
+                PCV_REQUIRE(attempt < 6, "search_sharded: candidate lists still overflow after %d reruns", attempt + 1);
             }
-            rc = pcv_searcher_search_device_end(s, nullptr);  // waits for the stream; grows this rank's lists if needed
-            if (rc != PCV_OK) throw Error{rc};
-            if (c->pin_hits[n].pos == 0) {
-                hits_to_outputs(s->metric, s->D, c->pin_hits, n_queries, k, out_ids, out_scores, out_counts);
-                return;
-            }
-            PCV_REQUIRE(attempt < 6, "search_sharded: candidate lists still overflow after %d reruns", attempt + 1);
+            std::memcpy(all.data() + (size_t)q0 * k, c->pin_hits, nb * sizeof(pcv_hit_dev));
+            total.rows_scanned += s->stats.rows_scanned;
+            total.bytes_algorithmic += s->stats.bytes_algorithmic;
+            total.scan_ms += s->stats.scan_ms;
+            total.total_ms += s->stats.total_ms;
+            total.candidates += s->stats.candidates;
+            total.scan_launches += s->stats.scan_launches;
+            total.overflow_reruns += s->stats.overflow_reruns;
+            total.host_enqueue_ms += s->stats.host_enqueue_ms;
+            total.host_wait_ms += s->stats.host_wait_ms;
+            total.kernel_used = s->stats.kernel_used;
         }
-        pcv_status rc = pcv_searcher_search_device(s, queries, n_queries, source_ids, n_sources, k, c->d_local.p, 0);
-        if (rc != PCV_OK) throw Error{rc};
-        exchange(0);
-        PCV_HIP(hipStreamSynchronize(st));
-        PCV_HIP(hipGetLastError());
-        hits_to_outputs(s->metric, s->D, c->pin_hits, n_queries, k, out_ids, out_scores, out_counts);
+        s->stats = total;
+        hits_to_outputs(s->metric, s->D, all.data(), n_queries, k, out_ids, out_scores, out_counts);
     });
 }
 

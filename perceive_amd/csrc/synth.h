@@ -46,4 +46,20 @@ __device__ static inline float4 synth_piece(uint64_t seed, int64_t row, uint32_t
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// Clustered variant (bench.py --clustered, DESIGN.md §synthetic data): row = centroid(cluster(row)) / sqrt(D)
+// + noise * synth_row(seed, row), cluster(row) = hash(row) mod n_clusters, centroid(j) = synth row j of
+// the stream `seed ^ kClusterSeedXor`.  Members of one cluster are then within a few `noise` of each
+// other in cosine — the shape of real sentence embeddings that a fixed-width screen has to survive.
+constexpr uint64_t kClusterSeedXor = 0xC1057E25EED5ull;
+__host__ __device__ static inline uint32_t synth_cluster_of(int64_t row, uint32_t n_clusters) {
+    return (uint32_t)(((uint64_t)row * 0x9E3779B97F4A7C15ull) >> 33) % n_clusters;
+}
+__device__ static inline float4 synth_piece_clustered(uint64_t seed, int64_t row, uint32_t f4, uint32_t n_clusters,
+                                                      float noise, float inv_sqrt_d) {
+    const float4 c = synth_piece(seed ^ kClusterSeedXor, (int64_t)synth_cluster_of(row, n_clusters), f4);
+    const float4 n = synth_piece(seed, row, f4);
+    return make_float4(fmaf(noise, n.x, c.x * inv_sqrt_d), fmaf(noise, n.y, c.y * inv_sqrt_d),
+                       fmaf(noise, n.z, c.z * inv_sqrt_d), fmaf(noise, n.w, c.w * inv_sqrt_d));
+}
+
 }  // namespace pcv

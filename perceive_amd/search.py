@@ -40,6 +40,19 @@ def deserialize_embedding(value):
     return out[: n.value]
 
 
+def _source_filter(sources):
+    """(pointer, count, keep-alive) of a source filter for the C ABI: None -> NULL (all sources); a list ->
+    exactly those, an empty list matching nothing (search.rs:166).  The pointer of an empty list is still
+    non-NULL."""
+    if sources is None:
+        return None, 0, None
+    sa = np.ascontiguousarray(list(sources), dtype=np.int64)
+    n = int(sa.size)
+    if n == 0:
+        sa = np.zeros(1, dtype=np.int64)
+    return _ffi.i64p(sa), n, sa
+
+
 class Searcher:
     """search.rs:29-35.  One exact, GPU-resident index per process; sources are kept apart so
     `search_vector(sources=...)` filters like search.rs:166 and `rebuild_source` replaces one.
@@ -113,10 +126,16 @@ class Searcher:
             idp = _ffi.i64p(ids)
         _ffi.check(_ffi.lib().pcv_searcher_add_blobs(self._handle, int(source_id), idp, _ffi.u8p(b), int(n)))
 
-    def add_synthetic(self, source_id, n, seed, first_row=0, normalize=False):
+    def reserve(self, source_id, n_rows):
+        """Announce that `n_rows` more rows are about to be added to `source_id` (one device segment for them)."""
+        _ffi.check(_ffi.lib().pcv_searcher_reserve(self._handle, int(source_id), int(n_rows)))
+
+    def add_synthetic(self, source_id, n, seed, first_row=0, normalize=False, n_clusters=0, noise=0.0):
+        """Rows generated on the device.  n_clusters > 0: clustered rows (centroid/sqrt(dim) + noise * row)."""
         _ffi.check(
-            _ffi.lib().pcv_searcher_add_synthetic(
-                self._handle, int(source_id), int(n), int(seed), int(first_row), 1 if normalize else 0
+            _ffi.lib().pcv_searcher_add_synthetic_clustered(
+                self._handle, int(source_id), int(n), int(seed), int(first_row), 1 if normalize else 0,
+                int(n_clusters), float(noise)
             )
         )
 
@@ -138,12 +157,7 @@ class Searcher:
         ids = np.full((B, k), -1, dtype=np.int64)
         scores = np.full((B, k), np.nan, dtype=np.float32)
         counts = np.zeros(B, dtype=np.int32)
-        src, nsrc = None, 0
-        if sources is not None:
-            sa = np.ascontiguousarray(list(sources), dtype=np.int64)
-            if sa.size == 0:
-                return ids, scores, counts  # search.rs:166 with an empty filter matches nothing
-            src, nsrc = _ffi.i64p(sa), sa.size
+        src, nsrc, _keep = _source_filter(sources)
         _ffi.check(
             _ffi.lib().pcv_searcher_search(
                 self._handle, _ffi.f32p(q), B, src, nsrc, k, _ffi.i64p(ids), _ffi.f32p(scores),
@@ -159,10 +173,7 @@ class Searcher:
     def search_device(self, sources, num_results, vectors, d_out, async_=False):
         """Per-shard exact top-k left on the device: d_out = device pointer to [B][k] pcv_hit."""
         q = np.ascontiguousarray(vectors, dtype=np.float32)
-        src, nsrc = None, 0
-        if sources is not None:
-            sa = np.ascontiguousarray(list(sources), dtype=np.int64)
-            src, nsrc = _ffi.i64p(sa), sa.size
+        src, nsrc, _keep = _source_filter(sources)
         _ffi.check(
             _ffi.lib().pcv_searcher_search_device(
                 self._handle, _ffi.f32p(q), q.shape[0], src, nsrc, int(num_results), C.c_void_p(d_out),
@@ -174,10 +185,7 @@ class Searcher:
         """Queue the per-shard pass without waiting (pcv_searcher_search_device_begin): d_out receives
         B*k hits + one overflow record.  Raises PcvError(status 3) if it needs more than one pass."""
         q = np.ascontiguousarray(vectors, dtype=np.float32)
-        src, nsrc = None, 0
-        if sources is not None:
-            sa = np.ascontiguousarray(list(sources), dtype=np.int64)
-            src, nsrc = _ffi.i64p(sa), sa.size
+        src, nsrc, _keep = _source_filter(sources)
         _ffi.check(
             _ffi.lib().pcv_searcher_search_device_begin(
                 self._handle, _ffi.f32p(q), q.shape[0], src, nsrc, int(num_results), C.c_void_p(d_out)
@@ -195,10 +203,7 @@ class Searcher:
         RCCL all-gather of the hit lists, merge.  Returns (ids[B,k], scores[B,k], counts[B])."""
         q = np.ascontiguousarray(vectors, dtype=np.float32)
         B, k = q.shape[0], int(num_results)
-        src, nsrc = None, 0
-        if sources is not None:
-            sa = np.ascontiguousarray(list(sources), dtype=np.int64)
-            src, nsrc = _ffi.i64p(sa), sa.size
+        src, nsrc, _keep = _source_filter(sources)
         ids = np.full((B, k), -1, dtype=np.int64)
         scores = np.full((B, k), np.nan, dtype=np.float32)
         counts = np.zeros(B, dtype=np.int32)
@@ -221,6 +226,12 @@ class Searcher:
     def num_rows(self):
         n = C.c_int64()
         _ffi.check(_ffi.lib().pcv_searcher_num_rows(self._handle, C.byref(n)))
+        return n.value
+
+    @property
+    def num_segments(self):
+        n = C.c_int()
+        _ffi.check(_ffi.lib().pcv_searcher_num_segments(self._handle, C.byref(n)))
         return n.value
 
     @property

@@ -333,3 +333,34 @@ def test_graph_replay_matches_eager(ctx, oracle):
     oout, _ = oracle.encode_tokens(desc, sd, ids, np.ones_like(ids))
     assert np.abs(out - oout).max() < 2e-5
     m.close()
+
+
+def test_workspace_reuse_across_shapes(ctx, oracle):
+    # one Model, shapes that share a padded token count but not a token count (B=4,L=33 then B=4,L=60:
+    # both pad to 4*64), then a smaller and a larger batch: every buffer must fit every call
+    desc = dict(vocab=400, hidden=128, layers=2, heads=4, inter=256, max_pos=128, eps=1e-12, pooling=0, normalize=1)
+    m = make_model(ctx, desc, seed=11)
+    sd = m.state_dict()
+    rng = np.random.default_rng(5)
+    for B, L in [(4, 33), (4, 60), (1, 64), (4, 33), (9, 100), (2, 7)]:
+        toks = [list(rng.integers(1, 400, L if i == 0 else int(rng.integers(1, L + 1)))) for i in range(B)]
+        ids, mask = m.generate_token_tensors(toks)
+        assert ids.shape == (B, L)
+        out = m.encode_tokens(ids, mask)
+        oout, ohid = oracle.encode_tokens(desc, sd, ids, mask, want_hidden=True)
+        np.testing.assert_allclose(out, oout, atol=2e-5, err_msg=f"B={B} L={L}")
+        np.testing.assert_allclose(m.debug_hidden(2, B, L), ohid[-1], atol=1e-4)
+    m.close()
+
+
+def test_token_ids_outside_the_vocabulary_are_refused(ctx):
+    m = make_model(ctx, dict(vocab=300, hidden=128, layers=1, heads=4, inter=256, max_pos=64), seed=1)
+    ids = np.array([[5, 299, 7]], np.int64)
+    m.encode_tokens(ids, np.ones_like(ids))
+    for bad in (300, -1, 10**9):
+        ids2 = ids.copy()
+        ids2[0, 1] = bad
+        with pytest.raises(pa.ModelError) as e:
+            m.encode_tokens(ids2, np.ones_like(ids2))
+        assert "vocabulary" in str(e.value)
+    m.close()

@@ -97,3 +97,93 @@ def test_sharded_equals_whole(ctx, big, oracle):
     for b in range(4):
         small = [i for i in ids[b] if i < n]
         assert small == [i for i in w_ids[b] if i in set(small)]
+
+
+def _verify_topk(searcher, oracle, q, ids, sc, k, n_total, rng, sample=256):
+    """Size-independent checks of one result: scores re-derived by the oracle from the rows read back,
+    list sorted, and a random sample of other rows never beats the k-th score unless it is in the list."""
+    rows, rid = searcher.get_rows(ids.reshape(-1))
+    np.testing.assert_array_equal(rid, ids.reshape(-1))
+    samp = rng.integers(0, n_total, sample)
+    srows, _ = searcher.get_rows(samp)
+    for b in range(q.shape[0]):
+        ref = np.array([oracle.canonical_score(q[b], rows[b * k + j]) for j in range(k)])
+        np.testing.assert_allclose(sc[b], ref.astype(np.float32), atol=1e-7)
+        assert (np.diff(ref) <= 0).all()
+        others = np.array([oracle.canonical_score(q[b], r) for r in srows])
+        assert set(samp[others > ref[-1]]) <= set(ids[b])
+
+
+def test_headline_config_100m_b64_k10_mfma(big, oracle):
+    # BASELINE configs[2], the benchmarked tuple and kernel instantiation (scan_mfma_kernel<2,...>):
+    # 100M x 384, batch 64, top-10.  8 of the 64 queries are rows planted by value at block / 2^32-work-item /
+    # tail positions; every score is re-derived; the wave kernel must return the same ids for all 64.
+    rng = np.random.default_rng(64)
+    B, k = 64, 10
+    q = oracle.synth_rows(SEED + 7, 0, B, D)
+    pos = np.array([0, 31, 32, 10_485_760, 44_444_444, 99_999_967, N - 33, N - 1], np.int64)
+    slots = np.array([0, 5, 17, 31, 32, 40, 55, 63])
+    for sl, p_ in zip(slots, pos):
+        q[sl] = oracle.synth_rows(SEED, int(p_), 1, D)[0]
+    big.set_kernel("mfma")
+    ids, sc, cnt = big.search_vectors(None, k, q)
+    st = big.last_stats()
+    assert st["kernel_used"] == 2 and st["scan_launches"] == 1 and st["rows_scanned"] == N
+    assert st["overflow_reruns"] == 0 and (cnt == k).all()
+    np.testing.assert_array_equal(ids[slots, 0], pos)
+    np.testing.assert_allclose(sc[slots, 0], 1.0, atol=1e-6)
+    _verify_topk(big, oracle, q, ids, sc, k, N, rng)
+    big.set_kernel("wave")  # 16 passes of 4 queries through the independent f32 kernel
+    ids_w, sc_w, _ = big.search_vectors(None, k, q)
+    big.set_kernel("auto")
+    np.testing.assert_array_equal(ids, ids_w)
+    np.testing.assert_array_equal(sc, sc_w)
+
+
+def test_config2_10m_b1_k10_wave(ctx, oracle):
+    # BASELINE configs[1]: 10M x 384, batch 1, top-10, the wave-reduction kernel
+    n = 10_000_000
+    s = pa.Searcher(ctx, D, "cosine")
+    s.add_synthetic(1, n, 0x5EED)
+    s.finalize()
+    rng = np.random.default_rng(10)
+    q = oracle.synth_rows(0x5EED + 1, 0, 1, D)
+    ids, sc, cnt = s.search_vectors(None, 10, q)
+    st = s.last_stats()
+    assert st["kernel_used"] == 1 and st["scan_launches"] == 1 and st["rows_scanned"] == n and cnt[0] == 10
+    _verify_topk(s, oracle, q, ids, sc, 10, n, rng, sample=1024)
+    # a planted row, and agreement with the MFMA kernel on the same query
+    qp = oracle.synth_rows(0x5EED, 9_999_999, 1, D)
+    got, gsc, _ = s.search_vectors(None, 10, qp)
+    assert got[0, 0] == 9_999_999 and abs(gsc[0, 0] - 1.0) < 1e-6
+    s.set_kernel("mfma")
+    ids_m, sc_m, _ = s.search_vectors(None, 10, q)
+    np.testing.assert_array_equal(ids, ids_m)
+    np.testing.assert_array_equal(sc, sc_m)
+    s.close()
+
+
+def test_config5_encode_256x256_then_search(ctx, big, oracle):
+    # BASELINE configs[4] on one GPU: all-MiniLM-L6-v2 shape, 256 documents x 256 tokens in f32, sampled rows
+    # against the C oracle (padding invariance makes single-row oracle runs valid), then the 256
+    # embeddings searched over the 100M-row corpus.
+    m = pa.Model(ctx, synthetic_seed=7)
+    rng = np.random.default_rng(256)
+    lens = rng.integers(32, 257, 256)
+    lens[0] = 256
+    toks = [list(rng.integers(1000, 30000, int(n))) for n in lens]
+    ids, mask = m.generate_token_tensors(toks)
+    assert ids.shape == (256, 256)
+    emb = m.encode_tokens(ids, mask)
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
+    desc = dict(vocab=30522, hidden=384, layers=6, heads=12, inter=1536, max_pos=512, eps=1e-12, pooling=0, normalize=1)
+    sd = m.state_dict()
+    for i in (0, 1, 100, 255):
+        ids1, mask1 = m.generate_token_tensors([toks[i]])
+        oout, _ = oracle.encode_tokens(desc, sd, ids1, mask1)
+        assert np.abs(emb[i] - oout[0]).max() < 1e-4, i
+    m.close()
+    got, sc, cnt = big.search_vectors(None, 10, emb)  # two passes of 128 queries
+    st = big.last_stats()
+    assert st["scan_launches"] == 2 and (cnt == 10).all() and st["overflow_reruns"] == 0
+    _verify_topk(big, oracle, emb[[0, 100, 255]], got[[0, 100, 255]], sc[[0, 100, 255]], 10, N, rng, sample=128)

@@ -263,8 +263,8 @@ def test_candidate_overflow_reruns_and_stays_exact(ctx, oracle):
         s.close()
 
 
-def test_many_sources_more_than_one_launch_group(ctx, oracle):
-    # 11 sources -> 11 segments > kMaxSeg(8): two scan groups merged on the host
+def test_many_sources_one_launch(ctx, oracle):
+    # 11 sources -> 11 segments: one launch walks them all through the device segment table
     rng = np.random.default_rng(21)
     s = pa.Searcher(ctx, 128, "cosine")
     parts = []
@@ -279,6 +279,139 @@ def test_many_sources_more_than_one_launch_group(ctx, oracle):
     ids, scores, _ = s.search_vectors(None, 12, q)
     opos, osc, _ = oracle.topk(q, allm, 12)
     np.testing.assert_array_equal(ids, allids[opos])
+    assert s.last_stats()["scan_launches"] == 1
+    s.close()
+
+
+@pytest.mark.parametrize("kernel,B", [("wave", 2), ("mfma", 40)])
+def test_forty_sources_three_incremental_adds_one_launch(ctx, oracle, kernel, B):
+    # the reference keeps one index per source (search.rs:24-27,134-155) and a real database grows by
+    # repeated scans: 40 sources x 3 add+finalize rounds.  Adds append in place while a segment has room,
+    # one launch walks every segment, and the begin/end protocol works on the same searcher.
+    rng = np.random.default_rng(1234)
+    D, k = 128, 10
+    s = pa.Searcher(ctx, D, "cosine")
+    s.set_kernel(kernel)
+    per_source = {src: [] for src in range(40)}
+    next_id = 0
+    for rnd in range(3):
+        for src in range(40):
+            n = int(rng.integers(5, 90)) * (rnd + 1)
+            m = rng.standard_normal((n, D)).astype(np.float32)
+            s.add_rows(src, m, np.arange(next_id, next_id + n))
+            per_source[src].append((m, np.arange(next_id, next_id + n)))
+            next_id += n
+        s.finalize()
+    allm = np.concatenate([m for src in range(40) for m, _ in per_source[src]])
+    allids = np.concatenate([i for src in range(40) for _, i in per_source[src]])
+    assert s.num_rows == allm.shape[0] and len(s.source_ids) == 40
+    assert 40 <= s.num_segments <= 100  # not 120: later adds went into the spare room of earlier segments
+    q = rng.standard_normal((B, D)).astype(np.float32)
+    ids, sc, _ = s.search_vectors(None, k, q)
+    opos, osc, _ = oracle.topk(q, allm, k)
+    np.testing.assert_array_equal(ids, allids[opos])
+    np.testing.assert_allclose(sc, osc.astype(np.float32), atol=1e-7)
+    st = s.last_stats()
+    assert st["scan_launches"] == (B + 3) // 4 if kernel == "wave" else st["scan_launches"] == 1
+    # a source filter picks that source's segments only
+    sub = [3, 17, 39]
+    ids, _, _ = s.search_vectors(sub, k, q)
+    subm = np.concatenate([m for src in sub for m, _ in per_source[src]])
+    subids = np.concatenate([i for src in sub for _, i in per_source[src]])
+    np.testing.assert_array_equal(ids, subids[oracle.topk(q, subm, k)[0]])
+    # begin/end on all segments: queued without a host round trip, one launch
+    if B <= 4 or kernel == "mfma":
+        rec = B * k + 1
+        d = ctx.alloc(rec * 24)
+        s.search_device_begin(None, k, q, d)
+        assert s.search_device_end() is False
+        assert s.last_stats()["scan_launches"] == 1
+        got, _, _, over = pa.merge_topk(ctx, "cosine", D, d, 1, B, k, flagged=True)
+        assert over is False
+        np.testing.assert_array_equal(got, allids[opos])
+        ctx.free(d)
+    s.close()
+
+
+def test_reserve_gives_one_segment_and_tail_append(ctx, oracle):
+    rng = np.random.default_rng(8)
+    D = 64
+    m = rng.standard_normal((5000, D)).astype(np.float32)
+    s = pa.Searcher(ctx, D, "dot")
+    s.reserve(7, 5000)
+    for lo in range(0, 5000, 777):  # ragged chunks, block boundaries inside and across chunks
+        s.add_rows(7, m[lo:lo + 777], 10_000 + np.arange(lo, min(lo + 777, 5000)))
+    s.finalize()
+    assert s.num_segments == 1 and s.num_rows == 5000
+    rows, ids = s.get_rows(np.array([0, 31, 32, 776, 777, 778, 4999]))
+    np.testing.assert_array_equal(rows, m[[0, 31, 32, 776, 777, 778, 4999]])
+    np.testing.assert_array_equal(ids, 10_000 + np.array([0, 31, 32, 776, 777, 778, 4999]))
+    q = rng.standard_normal((3, D)).astype(np.float32)
+    got, _, _ = s.search_vectors([7], 9, q)
+    np.testing.assert_array_equal(got, 10_000 + oracle.topk(q, m, 9, metric=1)[0])
+    # implicit ids keep counting across adds
+    s2 = pa.Searcher(ctx, D, "cosine")
+    s2.add_rows(1, m[:100])
+    s2.add_rows(1, m[100:250])
+    s2.finalize()
+    got, _, _ = s2.search_vectors(None, 5, q)
+    np.testing.assert_array_equal(got, oracle.topk(q, m[:250], 5)[0])
+    s.close()
+    s2.close()
+
+
+def test_streaming_ingest_keeps_host_memory_bounded(ctx):
+    # Searcher::build streams rows out of SQLite (search.rs:87-113); the library must not keep a host copy:
+    # 20M x 384 rows (30.7 GB) pushed through one 131072-row buffer, peak RSS of the process < 2 GB
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, resource, numpy as np; sys.path.insert(0, %r); import perceive_amd as pa\n"
+        "ctx = pa.Context(0); s = pa.Searcher(ctx, 384, 'cosine')\n"
+        "rng = np.random.default_rng(1); chunk = rng.standard_normal((131072, 384)).astype(np.float32)\n"
+        "blob = chunk.tobytes(); N = 20_000_000; done = 0\n"
+        "while done < N:\n"
+        "    n = min(131072, N - done)\n"
+        "    s.add_blobs(1 + done // 5_000_000, blob[: n * 1536], n, ids=np.arange(done, done + n))\n"
+        "    done += n\n"
+        "s.finalize()\n"
+        "q = chunk[77:78] + 0.0\n"
+        "ids, sc, cnt = s.search_vectors(None, 3, q)\n"
+        "print('RESULT', s.num_rows, s.num_segments, int(ids[0, 0]) %% 131072, float(sc[0, 0]), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)\n"
+    ) % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    rows, nseg, hit, score, maxrss_kb = int(line[1]), int(line[2]), int(line[3]), float(line[4]), int(line[5])
+    assert rows == 20_000_000 and hit == 77 and abs(score - 1.0) < 1e-6
+    assert nseg <= 4 * 12, nseg  # 4 sources, each a short chain of doubling segments
+    assert maxrss_kb < 2 * 1024 * 1024, f"peak RSS {maxrss_kb / 1e6:.2f} GB"
+
+
+def test_clustered_rows_stay_exact_and_selective(ctx, oracle):
+    # clustered corpus (centroid + small noise): thousands of rows sit inside the bf16 margin of the k-th
+    # best.  The exact-f32 second screen keeps the lists short, nothing overflows, results are exact.
+    N, D, B, k = 300_000, 384, 64, 10
+    ncl, noise = 30, 0.0015  # ~10^4 rows per cluster, members within ~0.01 cosine of each other
+    ref = oracle.synth_rows_clustered(0xABCD, 0, N, D, ncl, noise)
+    s = pa.Searcher(ctx, D, "cosine")
+    s.add_synthetic(1, N, 0xABCD, n_clusters=ncl, noise=noise)
+    s.finalize()
+    rows, _ = s.get_rows(np.array([0, 12345, N - 1]))
+    np.testing.assert_array_equal(rows.view(np.uint32), ref[[0, 12345, N - 1]].view(np.uint32))
+    q = oracle.synth_rows_clustered(0xABCD, N + 5, B, D, ncl, noise)  # unseen members of the same clusters
+    opos, osc, _ = oracle.topk(q, ref, k)
+    in_margin = ((ref @ (q[0] / np.linalg.norm(q[0]))) / np.linalg.norm(ref, axis=1) > osc[0, -1] - 0.0078).sum()
+    assert in_margin > 3000, in_margin  # the situation the test is about
+    for kernel in ("mfma", "wave"):
+        s.set_kernel(kernel)
+        ids, sc, _ = s.search_vectors(None, k, q)
+        np.testing.assert_array_equal(ids, opos)
+        np.testing.assert_allclose(sc, osc.astype(np.float32), atol=1e-7)
+        st = s.last_stats()
+        assert st["overflow_reruns"] == 0
+        assert st["candidates"] < 2500 * B, st  # early, loose-threshold survivors included
     s.close()
 
 
@@ -476,6 +609,66 @@ def test_native_rccl_exchange_single_rank(ctx, oracle):
     hard = (t * qa + 0.01 * rng.standard_normal((40_000, 64)).astype(np.float32)).astype(np.float32)
     s = build(ctx, hard)
     np.testing.assert_array_equal(s.search_sharded(comm, None, k, qa)[0], oracle.topk(qa, hard, k)[0])
+    comm.close()
+    s.close()
+
+
+def test_native_sharded_with_filters_and_many_segments(ctx, oracle):
+    # pcv_searcher_search_sharded at world=1: a source filter that matches nothing on this shard (the
+    # pass is skipped, the exchange still runs and must be waited for), more than 8 segments, an empty filter
+    rng = np.random.default_rng(77)
+    D, k = 64, 6
+    s = pa.Searcher(ctx, D, "cosine")
+    parts = []
+    for src in range(12):
+        m = rng.standard_normal((50 + 11 * src, D)).astype(np.float32)
+        parts.append(m)
+        s.add_rows(src, m, 1000 * src + np.arange(m.shape[0]))
+    s.finalize()
+    allm = np.concatenate(parts)
+    allids = np.concatenate([1000 * i + np.arange(p.shape[0]) for i, p in enumerate(parts)])
+    comm = pa.NativeComm(ctx, 1, 0, pa.NativeComm.unique_id())
+    q = rng.standard_normal((5, D)).astype(np.float32)
+    for _ in range(3):  # stale pinned results of an earlier call must never be returned
+        ids, sc, cnt = s.search_sharded(comm, None, k, q)
+        np.testing.assert_array_equal(ids, allids[oracle.topk(q, allm, k)[0]])
+        ids, sc, cnt = s.search_sharded(comm, [999], k, q)
+        assert (cnt == 0).all() and (ids == -1).all()
+        ids, sc, cnt = s.search_sharded(comm, [], k, q)
+        assert (cnt == 0).all() and (ids == -1).all()
+        ids, sc, cnt = s.search_sharded(comm, [4, 9], k, q)
+        sub = np.concatenate([parts[4], parts[9]])
+        subids = np.concatenate([4000 + np.arange(parts[4].shape[0]), 9000 + np.arange(parts[9].shape[0])])
+        np.testing.assert_array_equal(ids, subids[oracle.topk(q, sub, k)[0]])
+    # the device wrappers treat an empty filter like search_vectors does (search.rs:166)
+    d = ctx.alloc((5 * k + 1) * 24)
+    s.search_device([], k, q, d)
+    got = ctx.to_host(d, 5 * k * 24).view(pa.HIT_DTYPE)
+    assert (got["pos"] == -1).all()
+    s.search_device_begin([], k, q, d)
+    assert s.search_device_end() is False
+    assert (ctx.to_host(d, 5 * k * 24).view(pa.HIT_DTYPE)["pos"] == -1).all()
+    ctx.free(d)
+    # concurrent plain and sharded searches on one searcher serialise on its mutex
+    import threading
+
+    errs = []
+
+    def plain():
+        try:
+            for _ in range(20):
+                got, _, _ = s.search_vectors(None, k, q)
+                np.testing.assert_array_equal(got, allids[oracle.topk(q, allm, k)[0]])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    t = threading.Thread(target=plain)
+    t.start()
+    for _ in range(20):
+        ids, _, _ = s.search_sharded(comm, None, k, q)
+        np.testing.assert_array_equal(ids, allids[oracle.topk(q, allm, k)[0]])
+    t.join()
+    assert not errs, errs
     comm.close()
     s.close()
 
