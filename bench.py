@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--collective", default=os.environ.get("PCV_BENCH_COLLECTIVE", "torch"), choices=["torch", "native"],
                     help="N>1 hit-list exchange: torch.distributed's RCCL group, or the library's own RCCL communicator")
     ap.add_argument("--normalized", action="store_true", help="store unit-norm rows (MiniLM-like)")
+    ap.add_argument("--clustered", action="store_true",
+                    help="main leg on clustered rows (centroid + noise: ~2e4 rows within 0.01 cosine of every query's top-k)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (config 2, shard, encoder, end to end, clustered)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = --rows is the whole corpus, sharded (BASELINE configs[3]); weak = --rows per GPU")
     return ap.parse_args()
@@ -96,6 +99,121 @@ def cpu_baseline(args):
                   f"{total:.1f} s on {threads} threads = the job's CPU quota of {orc.hardware_threads()} hardware threads (oracle/baseline.c)",
         "queries_per_s": args.batch * reps / total,
         "reference_shaped_vectors_per_s": ns / shaped_s,
+    }
+
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # exact-f32 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md); the reference computes in f32
+CLUSTER_ROWS = 20_000         # rows per cluster of the clustered corpus
+CLUSTER_NOISE = 0.0015        # members of a cluster then sit within ~0.01 cosine of each other
+
+
+def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, clustered=False, searcher=None, dim=384):
+    """One single-GPU scan measurement: `steps` exact top-k searches of `batch` fresh queries over `rows`
+    synthetic rows resident in HBM.  Returns the record that goes under `extra` (same fields as the headline)."""
+    own = searcher is None
+    if own:
+        searcher = pa.Searcher(ctx, dim, "cosine")
+        ncl = max(1, rows // CLUSTER_ROWS) if clustered else 0
+        searcher.add_synthetic(1, rows, seed, n_clusters=ncl, noise=CLUSTER_NOISE if clustered else 0.0)
+        searcher.finalize()
+    searcher.set_kernel(kernel)
+    rng = np.random.default_rng(seed + 17)
+    if clustered:
+        # queries = unseen members of the corpus' clusters (the oracle's twin generator is test infrastructure;
+        # the same construction in numpy: centroid rows come back from the device)
+        probe = searcher.get_rows(rng.integers(0, rows, (warmup + steps) * batch))[0]
+        q = probe + CLUSTER_NOISE * rng.standard_normal(probe.shape).astype(np.float32)
+        queries = q.reshape(warmup + steps, batch, dim).astype(np.float32)
+    else:
+        queries = rng.standard_normal((warmup + steps, batch, dim)).astype(np.float32)
+    for i in range(warmup):
+        searcher.search_vectors(None, k, queries[i])
+    ctx.synchronize()
+    scan_ms, pass_ms, cands, reruns, launches = [], [], [], 0, 0
+    t0 = time.perf_counter()
+    for i in range(steps):
+        searcher.search_vectors(None, k, queries[warmup + i])
+        st = searcher.last_stats()
+        scan_ms.append(st["scan_ms"])
+        pass_ms.append(st["total_ms"])
+        cands.append(st["candidates"])
+        reruns += st["overflow_reruns"]
+        launches += st["scan_launches"]
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    kname = "scan_mfma_kernel" if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel"
+    kernel_ms = float(np.sum(scan_ms)) / max(launches, 1)
+    gbps = rows * dim * 4 / (kernel_ms * 1e-3) / 1e9
+    rec = {
+        "workload": f"{rows} x {dim} f32 synthetic" + (" clustered" if clustered else "") + f" corpus, batch={batch}, top-{k}, 1 MI355X",
+        "kernel": kname, "ms_per_step": 1e3 * wall / steps, "kernel_ms": kernel_ms,
+        "pass_ms": float(np.sum(pass_ms)) / max(launches, 1),
+        "fixed_cost_us": 1e3 * (float(np.sum(pass_ms)) - float(np.sum(scan_ms))) / max(launches, 1),
+        "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
+        "vectors_per_s": rows * steps / wall, "queries_per_s": batch * steps / wall,
+        "candidates_per_query": float(np.mean(cands)) / batch, "overflow_reruns": reruns, "steps": steps,
+    }
+    if own:
+        searcher.close()
+    return rec
+
+
+def encoder_leg(pa, ctx, compute, steps=5, warmup=2, batch=256, seq=256):
+    """BASELINE configs[4]'s encoder: all-MiniLM-L6-v2 shape, 256 documents x 256 tokens, seeded synthetic weights."""
+    m = pa.Model(ctx, pa.minilm_l6_desc(compute), synthetic_seed=1)
+    rng = np.random.default_rng(0)
+    ids = rng.integers(1000, 30000, (batch, seq)).astype(np.int64)
+    mask = np.ones((batch, seq), np.int64)
+    for _ in range(warmup):
+        m.encode_tokens(ids, mask)
+    ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.encode_tokens(ids, mask)
+        ms.append(m.last_stats()["total_ms"])
+    wall = time.perf_counter() - t0
+    flops = m.last_stats()["flops"]
+    m.close()
+    dev_ms = float(np.mean(ms))
+    tf = flops / (dev_ms * 1e-3) / 1e12
+    return {
+        "workload": f"encode batch={batch} x seq_len={seq}, all-MiniLM-L6-v2 shape, synthetic weights",
+        "compute": {"f32": "f32 (exact-f32 MFMA; the reference's dtype)",
+                    "bf16x3": "split precision: 3 bf16 terms per f32 operand, 6 bf16 MFMAs per product, f32 accumulate",
+                    "f16x2": "split precision: 2 f16 terms per f32 operand, 3 f16 MFMAs per product, f32 accumulate"}[compute],
+        "device_ms": dev_ms, "ms_per_step": 1e3 * wall / steps, "tokens_per_s": batch * seq * steps / wall,
+        "flops_per_step": flops, "effective_TFLOPps": tf,
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / F32_MFMA_PEAK_TFLOPS} if compute == "f32" else None,
+    }
+
+
+def e2e_leg(pa, ctx, searcher, rows, steps=3, warmup=1, batch=256, seq=256, k=10):
+    """BASELINE configs[4] on one GPU: encode 256 x 256 tokens (f32), then search the 256 embeddings over the
+    resident corpus (two passes of 128 queries)."""
+    m = pa.Model(ctx, pa.minilm_l6_desc("f32"), synthetic_seed=1)
+    rng = np.random.default_rng(1)
+    ids = rng.integers(1000, 30000, (batch, seq)).astype(np.int64)
+    mask = np.ones((batch, seq), np.int64)
+    searcher.set_kernel("auto")
+    enc, scan = [], []
+    for i in range(warmup + steps):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        emb = m.encode_tokens(ids, mask)
+        t1 = time.perf_counter()
+        out = searcher.search_vectors(None, k, emb)
+        t2 = time.perf_counter()
+        if i >= warmup:
+            enc.append(1e3 * (t1 - t0))
+            scan.append(1e3 * (t2 - t1))
+    m.close()
+    e, s_ = float(np.mean(enc)), float(np.mean(scan))
+    return {
+        "workload": f"encode batch={batch} x seq_len={seq} (MiniLM-L6 shape, f32) + exact top-{k} scan of the {batch} embeddings "
+                    f"over {rows} x 384, 1 MI355X",
+        "ms_per_step": e + s_, "encode_ms": e, "scan_ms": s_, "queries_per_s": batch / ((e + s_) * 1e-3),
+        "sample_ids": [int(x) for x in out[0][0][:3]],
     }
 
 
@@ -163,7 +281,9 @@ def main():
     hi = total_rows * (rank + 1) // world
     searcher = pa.Searcher(ctx, args.dim, "cosine")
     t0 = time.time()
-    searcher.add_synthetic(1, hi - lo, 0x5EED, first_row=lo, normalize=args.normalized)
+    ncl = max(1, total_rows // CLUSTER_ROWS) if args.clustered else 0
+    searcher.add_synthetic(1, hi - lo, 0x5EED, first_row=lo, normalize=args.normalized, n_clusters=ncl,
+                           noise=CLUSTER_NOISE if args.clustered else 0.0)
     searcher.finalize()
     searcher.set_shard_offset(lo)
     searcher.set_kernel(args.kernel)
@@ -173,6 +293,13 @@ def main():
     # tiny, so they are generated with numpy from a fixed seed instead)
     rng = np.random.default_rng(0x5EED + 1)
     queries = rng.standard_normal((args.warmup + args.steps, args.batch, args.dim)).astype(np.float32)
+    if args.clustered:  # unseen members of the corpus' clusters: a stored row of this shard + fresh noise
+        probe = searcher.get_rows(lo + rng.integers(0, hi - lo, queries.shape[0] * args.batch))[0]
+        queries = (probe + CLUSTER_NOISE * queries.reshape(-1, args.dim)).reshape(queries.shape).astype(np.float32)
+        if use_dist:  # every rank must search the same queries: rank 0's
+            qt = torch.from_numpy(queries).to("cpu" if rehearse else "cuda")
+            dist.broadcast(qt, src=0)
+            queries = qt.cpu().numpy()
 
     B, k = args.batch, args.k
     if use_dist:
@@ -254,13 +381,16 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "screen": "rows are read as f32 (1536 B/vector); bf16 MFMA coarse screen + exact-f32 fine screen with certified margins, "
+                      "survivors ranked in f64: exact top-k" if searcher.last_stats()["kernel_used"] == 2 else
+                      "f32 FMA screen with a certified margin, survivors ranked in f64: exact top-k",
+            "data": "synthetic clustered" if args.clustered else "synthetic",
             "config": {
                 "workload": f"{total_rows} x {args.dim} f32 synthetic corpus, batch={B} queries, top-{k}, "
                             f"{world} MI355X" + (" (rows sharded, RCCL all-gather of per-shard top-k)" if world > 1 else ""),
                 "rows": total_rows, "dim": args.dim, "batch": B, "k": k,
                 "kernel": {1: "wave", 2: "mfma"}[searcher.last_stats()["kernel_used"]],
-                "rows_normalized": bool(args.normalized),
+                "rows_normalized": bool(args.normalized), "clustered": bool(args.clustered),
                 "collective": (args.collective if use_dist else None),
             },
             "queries_per_s": B * args.steps / elapsed,
@@ -278,7 +408,8 @@ def main():
                 "kernel_ms_median": float(np.median(scan_ms)),
                 "kernel_ms_min": float(np.min(scan_ms)),
                 "read_ceiling_measured": measured_read_ceiling(),  # GB/s, profiles/r01_ubench_hbm_read*.txt
-                "pass_ms": float(np.mean(pass_ms)),  # prep + seed + scan + rescore + select on the device
+                "pass_ms": float(np.mean(pass_ms)),  # H2D + prep_seed + scan + rescore_select on the device
+                "fixed_cost_us": 1e3 * (float(np.mean(pass_ms)) - mean_scan_ms),
                 "host_enqueue_ms": float(np.mean([h[0] for h in host_ms])),
                 "host_wait_ms": float(np.mean([h[1] for h in host_ms])),
             },
@@ -287,6 +418,20 @@ def main():
             "build_s": t_build,
             "sample_result": {"ids": [int(x) for x in ids[0][:3]], "scores": [float(x) for x in scores[0][:3]]},
         }
+        if world == 1 and not args.no_extra:
+            # the other legs BASELINE.json names, measured in the same run (single GPU only)
+            extra = {}
+            es, ew = max(3, min(args.steps, 20)), max(1, min(args.warmup, 3))
+            extra["config5_end_to_end"] = e2e_leg(pa, ctx, searcher, total_rows)
+            searcher.set_kernel(args.kernel)
+            extra["config2_10m_b1"] = scan_leg(pa, ctx, 10_000_000, 1, k, "auto", es, ew)
+            extra["shard_12p5m_b64"] = scan_leg(pa, ctx, 12_500_000, 64, k, "auto", es, ew)
+            extra["encoder_256x256"] = encoder_leg(pa, ctx, "f32")
+            extra["encoder_256x256_split_precision"] = [encoder_leg(pa, ctx, "bf16x3"), encoder_leg(pa, ctx, "f16x2")]
+            if not args.clustered and args.rows >= 1_000_000:
+                searcher.close()  # two 153.6 GB corpora do not fit: the clustered one replaces the headline one
+                extra["clustered_b64"] = scan_leg(pa, ctx, args.rows, B, k, args.kernel, es, ew, clustered=True)
+            out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

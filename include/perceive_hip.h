@@ -140,6 +140,10 @@ pcv_status pcv_searcher_get_rows(pcv_searcher* s, const int64_t* positions, int6
 enum { PCV_KERNEL_AUTO = 0, PCV_KERNEL_WAVE = 1, PCV_KERNEL_MFMA = 2 };
 pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel);
 
+/* Tuning: rows per query the candidate lists of a pass hold at first (default 8192; 20 bytes each, 128
+ * lists).  A pass that needs more repeats itself with larger lists (pcv_scan_stats.overflow_reruns). */
+pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candidates);
+
 /* Searcher::search_vector (search.rs:157-182), batched over `n_queries` query vectors.
  *   queries      [n_queries][dim] f32
  *   source_ids   sources to search (search.rs:166 filter): NULL = all sources (n_sources ignored);

@@ -66,7 +66,8 @@ struct DevBuf {
 
 constexpr int64_t kStageRows = 1 << 18;                  // rows per H2D staging step (384-d: 400 MB)
 constexpr int64_t kMaxSegRows = (int64_t)0xffffffc0u;    // a candidate names its row in 32 bits
-constexpr int64_t kGrowCapRows = (int64_t)1 << 24;       // spare room a new segment gets at most
+constexpr int64_t kGrowCapRows = (int64_t)1 << 22;       // spare room a new segment gets at most (6 GB at 384-d)
+constexpr int64_t kMinSpareRows = 1024;                  // ... and at least
 constexpr size_t kPassAlign = 256;
 inline size_t align_up(size_t v) { return (v + kPassAlign - 1) / kPassAlign * kPassAlign; }
 
@@ -196,9 +197,12 @@ std::vector<Piece> place_rows(pcv_searcher* s, Source& src, int64_t n, bool with
     }
     int64_t have = src.rows() + (n - remaining);
     while (remaining > 0) {
+        // room for the rows at hand plus, for later adds, as many again as the source holds by then (at least
+        // kMinSpareRows, at most kGrowCapRows) — or exactly what the host announced
         const int64_t announced = std::max<int64_t>(0, src.reserve - have);
-        const int64_t spare = std::min<int64_t>(std::max<int64_t>(have, announced), std::max<int64_t>(kGrowCapRows, announced));
-        int64_t cap = std::min<int64_t>(std::max<int64_t>(remaining, spare), kMaxSegRows);
+        const int64_t spare = announced > 0 ? std::max<int64_t>(0, announced - remaining)
+                                            : std::min<int64_t>(std::max<int64_t>(have + remaining, kMinSpareRows), kGrowCapRows);
+        int64_t cap = std::min<int64_t>(remaining + spare, kMaxSegRows);
         const int64_t need = std::min<int64_t>(remaining, kMaxSegRows);
         Segment g;
         try {
@@ -850,6 +854,21 @@ pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel) {
     });
 }
 
+pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candidates) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "set_candidate_capacity: searcher is NULL");
+        PCV_REQUIRE(n_candidates >= 16 && n_candidates <= (1u << 24), "set_candidate_capacity: %u outside [16, 2^24]", n_candidates);
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->pending.active, "set_candidate_capacity: a queued pass has not been collected");
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+        s->cand_cap = n_candidates;  // the lists are (re)sized to it by the next pass; a pass that needs more grows them
+        s->d_cand.release();
+        s->d_cand_s.release();
+        s->d_cand_score.release();
+    });
+}
+
 pcv_status pcv_searcher_set_shard_offset(pcv_searcher* s, int64_t first_global_pos) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr, "set_shard_offset: searcher is NULL");
@@ -1134,6 +1153,18 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
         const int qstep = pass_queries(s, pick_kernel(s, n_queries));  // every rank computes the same split
         std::vector<pcv_hit_dev> all(n);
         pcv_scan_stats total{};
+        auto accumulate = [&] {  // every attempt starts its own statistics (device_begin)
+            total.rows_scanned += s->stats.rows_scanned;
+            total.bytes_algorithmic += s->stats.bytes_algorithmic;
+            total.scan_ms += s->stats.scan_ms;
+            total.total_ms += s->stats.total_ms;
+            total.candidates += s->stats.candidates;
+            total.scan_launches += s->stats.scan_launches;
+            total.overflow_reruns += s->stats.overflow_reruns;
+            total.host_enqueue_ms += s->stats.host_enqueue_ms;
+            total.host_wait_ms += s->stats.host_wait_ms;
+            total.kernel_used = s->stats.kernel_used;
+        };
         for (int q0 = 0; q0 < n_queries; q0 += qstep) {
             const int B = std::min(qstep, n_queries - q0);
             const size_t nb = (size_t)B * k;
@@ -1151,20 +1182,12 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
                     throw;
                 }
                 finish_pass(s);  // waits for the stream (pass, all-gather, merge, download); grows this rank's lists if needed
-                if (c->pin_hits[nb].pos == 0) break;
+                const bool again = c->pin_hits[nb].pos != 0;
+                if (!again) std::memcpy(all.data() + (size_t)q0 * k, c->pin_hits, nb * sizeof(pcv_hit_dev));
+                accumulate();
+                if (!again) break;
                 PCV_REQUIRE(attempt < 6, "search_sharded: candidate lists still overflow after %d reruns", attempt + 1);
             }
-            std::memcpy(all.data() + (size_t)q0 * k, c->pin_hits, nb * sizeof(pcv_hit_dev));
-            total.rows_scanned += s->stats.rows_scanned;
-            total.bytes_algorithmic += s->stats.bytes_algorithmic;
-            total.scan_ms += s->stats.scan_ms;
-            total.total_ms += s->stats.total_ms;
-            total.candidates += s->stats.candidates;
-            total.scan_launches += s->stats.scan_launches;
-            total.overflow_reruns += s->stats.overflow_reruns;
-            total.host_enqueue_ms += s->stats.host_enqueue_ms;
-            total.host_wait_ms += s->stats.host_wait_ms;
-            total.kernel_used = s->stats.kernel_used;
         }
         s->stats = total;
         hits_to_outputs(s->metric, s->D, all.data(), n_queries, k, out_ids, out_scores, out_counts);

@@ -219,6 +219,10 @@ class Searcher:
     def set_kernel(self, kernel="auto"):
         _ffi.check(_ffi.lib().pcv_searcher_set_kernel(self._handle, _KERNELS[kernel]))
 
+    def set_candidate_capacity(self, n_candidates):
+        """Initial rows per query of a pass's candidate lists (tuning; a pass that needs more repeats itself)."""
+        _ffi.check(_ffi.lib().pcv_searcher_set_candidate_capacity(self._handle, int(n_candidates)))
+
     def set_shard_offset(self, first_global_pos):
         _ffi.check(_ffi.lib().pcv_searcher_set_shard_offset(self._handle, int(first_global_pos)))
 

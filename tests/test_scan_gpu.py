@@ -255,11 +255,16 @@ def test_candidate_overflow_reruns_and_stays_exact(ctx, oracle):
     m = (t * q[None, :] + 0.01 * noise).astype(np.float32)
     for kernel in ("wave", "mfma"):
         s = build(ctx, m, kernel=kernel)
+        s.set_candidate_capacity(64)  # a massively parallel scan raises the threshold fast: start with short lists
         ids, scores, counts = s.search_vectors(None, 10, q[None, :])
         opos, osc, _ = oracle.topk(q[None, :], m, 10)
         np.testing.assert_array_equal(ids, opos)
         st = s.last_stats()
-        assert st["overflow_reruns"] >= 1, st
+        assert st["overflow_reruns"] >= 1 and st["scan_launches"] == 1 + st["overflow_reruns"], st
+        # the grown lists stay: the same search now fits
+        ids2, _, _ = s.search_vectors(None, 10, q[None, :])
+        np.testing.assert_array_equal(ids2, opos)
+        assert s.last_stats()["overflow_reruns"] == 0
         s.close()
 
 
@@ -305,7 +310,7 @@ def test_forty_sources_three_incremental_adds_one_launch(ctx, oracle, kernel, B)
     allm = np.concatenate([m for src in range(40) for m, _ in per_source[src]])
     allids = np.concatenate([i for src in range(40) for _, i in per_source[src]])
     assert s.num_rows == allm.shape[0] and len(s.source_ids) == 40
-    assert 40 <= s.num_segments <= 100  # not 120: later adds went into the spare room of earlier segments
+    assert s.num_segments == 40  # not 120: the later adds went into the spare room of each source's first segment
     q = rng.standard_normal((B, D)).astype(np.float32)
     ids, sc, _ = s.search_vectors(None, k, q)
     opos, osc, _ = oracle.topk(q, allm, k)
@@ -385,7 +390,7 @@ def test_streaming_ingest_keeps_host_memory_bounded(ctx):
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
     rows, nseg, hit, score, maxrss_kb = int(line[1]), int(line[2]), int(line[3]), float(line[4]), int(line[5])
     assert rows == 20_000_000 and hit == 77 and abs(score - 1.0) < 1e-6
-    assert nseg <= 4 * 12, nseg  # 4 sources, each a short chain of doubling segments
+    assert nseg <= 4 * 8, nseg  # 4 sources of 5M rows, each a short chain of growing segments
     assert maxrss_kb < 2 * 1024 * 1024, f"peak RSS {maxrss_kb / 1e6:.2f} GB"
 
 
@@ -411,7 +416,9 @@ def test_clustered_rows_stay_exact_and_selective(ctx, oracle):
         np.testing.assert_allclose(sc, osc.astype(np.float32), atol=1e-7)
         st = s.last_stats()
         assert st["overflow_reruns"] == 0
-        assert st["candidates"] < 2500 * B, st  # early, loose-threshold survivors included
+        # a bf16-only screen would keep the whole cluster (in_margin ~ 10^4 rows per query); at this small N the
+        # scan is over after ~3 blocks per wave, so most survivors are early, loose-threshold ones
+        assert st["candidates"] < 0.6 * in_margin * B, (st, in_margin)
     s.close()
 
 
@@ -567,6 +574,7 @@ def test_begin_end_overflow_is_repeated_by_all_shards(ctx, oracle):
         s.finalize()
         s.set_shard_offset(lo)
         shards.append(s)
+    shards[1].set_candidate_capacity(64)
     ids, scores, counts, attempts = _two_shard_step(ctx, shards, q, k, D)
     opos, osc, _ = oracle.topk(q, m, k)
     np.testing.assert_array_equal(ids, opos)
@@ -608,7 +616,9 @@ def test_native_rccl_exchange_single_rank(ctx, oracle):
     t = np.linspace(-1, 1, 40_000, dtype=np.float32)[:, None]
     hard = (t * qa + 0.01 * rng.standard_normal((40_000, 64)).astype(np.float32)).astype(np.float32)
     s = build(ctx, hard)
+    s.set_candidate_capacity(64)
     np.testing.assert_array_equal(s.search_sharded(comm, None, k, qa)[0], oracle.topk(qa, hard, k)[0])
+    assert s.last_stats()["overflow_reruns"] >= 1
     comm.close()
     s.close()
 

@@ -1,11 +1,28 @@
-# Kernel-trace statistics of the encoder (f32, bf16x3) and of the default bench, as committed under profiles/.
-# Run on the GPU box:  gpurun -- "bash tools/profile_round.sh"  then copy gpurun_out/prof/*.csv to profiles/.
+# Round profiles, as committed under profiles/ by tools/summarize_profiles.py <tag>:
+#   kernel-trace statistics of the default bench (100M x 384, batch 64), of BASELINE configs[1]
+#   (10M rows, one query) and of the encoder in its three compute modes; FETCH_SIZE / WRITE_SIZE PMC
+#   passes of the two scan kernels (counters in their own runs, kernel-trace only).
+# Run on the GPU box:  gpurun --timeout 1100 -- "bash tools/profile_round.sh"
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_enc -o enc -- python3 $R/tools/bench_encode.py --steps 5 --warmup 2 > $R/gpurun_out/prof_enc.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_enc3 -o enc3 -- python3 $R/tools/bench_encode.py --compute bf16x3 --steps 5 --warmup 2 > $R/gpurun_out/prof_enc3.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_enc2 -o enc2 -- python3 $R/tools/bench_encode.py --compute f16x2 --steps 5 --warmup 2 > $R/gpurun_out/prof_enc2.log 2>&1 || exit 1
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_scan -o scan -- python3 $R/bench.py --steps 10 --no-cpu-baseline > $R/gpurun_out/prof_scan.log 2>&1 || exit 1
-mkdir -p $R/gpurun_out/prof
-find /tmp/prof_enc /tmp/prof_enc3 /tmp/prof_enc2 /tmp/prof_scan -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/prof/ \;
-ls $R/gpurun_out/prof; tail -1 $R/gpurun_out/prof_scan.log | cut -c1-400
+G=$R/gpurun_out
+mkdir -p $G
+run() {  # run <dir under gpurun_out> <rocprof args...> -- <program...>
+  d=$1; shift
+  rm -rf $G/$d
+  timeout -k 10 400 rocprofv3 "$@" > $G/$d.log 2>&1 || { echo "FAILED: $d"; tail -5 $G/$d.log; exit 1; }
+}
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-extra"
+run prof_default     --kernel-trace --stats --output-format csv -d $G/prof_default     -o p -- $BENCH --steps 10
+run prof_10m_b1      --kernel-trace --stats --output-format csv -d $G/prof_10m_b1      -o p -- $BENCH --steps 20 --rows 10000000 --batch 1
+run pmc_fetch        --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/pmc_fetch        -o p -- $BENCH --steps 3 --warmup 1
+run pmc_write        --pmc WRITE_SIZE --kernel-trace --output-format csv -d $G/pmc_write        -o p -- $BENCH --steps 3 --warmup 1
+run pmc_fetch_10m_b1 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/pmc_fetch_10m_b1 -o p -- $BENCH --steps 3 --warmup 1 --rows 10000000 --batch 1
+run pmc_write_10m_b1 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $G/pmc_write_10m_b1 -o p -- $BENCH --steps 3 --warmup 1 --rows 10000000 --batch 1
+for c in f32 bf16x3 f16x2; do
+  run prof_enc_$c --kernel-trace --stats --output-format csv -d $G/prof_enc_$c -o p -- python3 $R/tools/bench_encode.py --compute $c --steps 7 --warmup 2
+done
+# keep only the summaries (the traces themselves are large)
+find $G/prof_* $G/pmc_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete 2>/dev/null
+find $G/prof_* $G/pmc_* -name "*.csv" | head -40
+tail -1 $G/prof_default.log | cut -c1-300

@@ -21,7 +21,8 @@ GO = os.path.join(ROOT, "gpurun_out")
 
 def newest(pattern):
     """gpurun merges every call's files into gpurun_out/: keep only the latest run of a directory."""
-    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    files = sorted(glob.glob(pattern) + glob.glob(pattern.replace(os.sep + "*" + os.sep, os.sep + "*" + os.sep + "*" + os.sep)),
+                   key=os.path.getmtime)
     return files[-1:]
 
 
@@ -49,8 +50,11 @@ def main():
     cases = [
         # (label, stats dir, fetch dir, write dir, kernel, rows, dim)
         ("100m_b64_mfma", "prof_default", "pmc_fetch", "pmc_write", "scan_mfma_kernel", 100_000_000, 384),
-        ("10m_b1_wave", "prof_10m_b1", "pmc_fetch_10m_b1", None, "scan_wave_kernel", 10_000_000, 384),
+        ("10m_b1_wave", "prof_10m_b1", "pmc_fetch_10m_b1", "pmc_write_10m_b1", "scan_wave_kernel", 10_000_000, 384),
     ]
+    for c in ("f32", "bf16x3", "f16x2"):  # encoder forward per kernel
+        for f in newest(os.path.join(GO, f"prof_enc_{c}", "*", "*_kernel_stats.csv")):
+            shutil.copy(f, os.path.join(OUT, f"{tag}_encode_b256_l256_{c}_kernel_stats.csv"))
     for label, sdir, fdir, wdir, kern, rows, dim in cases:
         for f in newest(os.path.join(GO, sdir, "*", "*_kernel_stats.csv")):
             shutil.copy(f, os.path.join(OUT, f"{tag}_{label}_kernel_stats.csv"))
