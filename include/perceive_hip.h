@@ -109,8 +109,8 @@ pcv_status pcv_searcher_add_blobs(pcv_searcher* s, int64_t source_id, const int6
 pcv_status pcv_searcher_add_synthetic(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
                                       int64_t first_row, int normalize);
 /* Clustered synthetic rows (what a fixed-width screen has to survive on real sentence embeddings):
- * row = centroid(cluster(row)) / sqrt(dim) + noise * synth_row(seed, row) with n_clusters seeded centroids;
- * members of a cluster sit within a few `noise` of each other in cosine.  n_clusters = 0: plain rows. */
+ * row = centroid(cluster(row)) / sqrt(dim) + noise * u(row) * synth_row(seed, row), u uniform in [0.5, 1.5), with
+ * n_clusters seeded centroids; the cosines inside a cluster spread over ~noise^2 * dim.  n_clusters = 0: plain rows. */
 pcv_status pcv_searcher_add_synthetic_clustered(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
                                                 int64_t first_row, int normalize, int n_clusters, float noise);
 /* Capacity hint (search.rs:138-140 sizes each source's index from its row count before inserting): the

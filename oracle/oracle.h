@@ -59,7 +59,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
  * divides by the f64-accumulated L2 norm. */
 void orc_synth_row(uint64_t seed, int64_t row, int D, int normalize, float* out);
 void orc_synth_rows(uint64_t seed, int64_t first_row, int64_t n, int D, int normalize, float* out);
-/* Clustered rows: centroid(cluster(row))/sqrt(D) + noise * synth_row(seed,row) (bench.py --clustered). */
+/* Clustered rows: centroid(cluster(row))/sqrt(D) + noise * u(row) * synth_row(seed,row), u in [0.5,1.5) (bench.py --clustered). */
 void orc_synth_rows_clustered(uint64_t seed, int64_t first_row, int64_t n, int D, int normalize, int n_clusters,
                               float noise, float* out);
 

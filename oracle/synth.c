@@ -71,6 +71,10 @@ static uint32_t cluster_of(int64_t row, uint32_t n_clusters) {
     return (uint32_t)(((uint64_t)row * 0x9E3779B97F4A7C15ull) >> 33) % n_clusters;
 }
 
+static float amplitude_of(int64_t row) { /* uniform in [0.5, 1.5), 24 bits */
+    return 0.5f + (float)(uint32_t)((((uint64_t)row * 0xD6E8FEB86659FD93ull) >> 40) & 0xffffffu) * (1.0f / 16777216.0f);
+}
+
 void orc_synth_rows_clustered(uint64_t seed, int64_t first_row, int64_t n, int D, int normalize, int n_clusters,
                               float noise, float* out) {
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
@@ -78,11 +82,12 @@ void orc_synth_rows_clustered(uint64_t seed, int64_t first_row, int64_t n, int D
         float* o = out + (size_t)r * D;
         const int64_t row = first_row + r;
         const int64_t cl = (int64_t)cluster_of(row, (uint32_t)n_clusters);
+        const float a = noise * amplitude_of(row);
         for (int f4 = 0; f4 < D / 4; ++f4) {
             float c[4], v[4];
             synth_piece(seed ^ CLUSTER_SEED_XOR, cl, (uint32_t)f4, c);
             synth_piece(seed, row, (uint32_t)f4, v);
-            for (int j = 0; j < 4; ++j) o[4 * f4 + j] = fmaf(noise, v[j], c[j] * inv_sqrt_d);
+            for (int j = 0; j < 4; ++j) o[4 * f4 + j] = fmaf(a, v[j], c[j] * inv_sqrt_d);
         }
         if (normalize) {
             double nx = 0.0;

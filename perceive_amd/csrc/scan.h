@@ -17,8 +17,8 @@ namespace pcv {
 
 constexpr int kBlockRows = 32;      // rows per corpus block
 constexpr int kMaxK = 128;          // largest num_results the running top-k slots hold
-constexpr int kSeedPartRows = 512;   // rows one seed workgroup ranks
-constexpr int kSeedParts = 32;       // seed workgroups per query group -> up to 16384 seed rows
+constexpr int kSeedPartRows = 256;   // rows one seed workgroup ranks (one per thread)
+constexpr int kSeedParts = 64;       // seed workgroups per query group -> up to 16384 seed rows
 constexpr int kMaxWaveQueries = 4;  // wave-reduction kernel handles 1..4 queries per pass
 constexpr int kHot = 256;            // uint32 words between per-query hot words (tau, cand_cnt): 1 KB apart,
                                      // so the device-wide atomics on them do not queue on one HBM channel
@@ -69,8 +69,6 @@ struct ScanParams {
     uint32_t* cand_cnt;      // [B*kHot]  survivors emitted per query (word q*kHot)
     uint64_t* cand;          // [B][cand_cap]  (segment index << 32) | row
     float* cand_s;           // [B][cand_cap]  f32 screening score the row was emitted with
-    double* cand_score;      // [B][cand_cap]  canonical score (only used when a list outgrows the LDS path)
-    uint32_t* ticket;        // arrival counter of the seed workgroups (left at 0)
     pcv_hit_dev* out;        // [B][k] device results
     pcv_hit_dev* out_host;   // pinned host mirror of `out`, or nullptr
     uint32_t* cnt_host;      // [B] pinned host: survivors per query, uncapped (the host sizes a rerun from it)
@@ -104,13 +102,14 @@ void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nrows, uint32_t row
 void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const int64_t* d_pos, int64_t n, int D,
                         int D4, float* out_rows, int64_t* out_ids);
 // `p` is the host copy (shapes for the launch geometry), `dp` the same struct resident in device memory.
-void launch_prep_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp);
+void launch_upload(hipStream_t st, const void* src_pinned, void* dst, size_t bytes);  // pinned host -> device, on the compute queue
+void launch_prep_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp, const SegDesc& seg0);
 void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);
 void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);
 int mfma_pass_queries(int Dp);   // queries one MFMA pass can take at this padded dim (LDS-limited), 0 = none
 uint32_t mfma_tile_rows(int B);  // rows of the bf16 query tile the MFMA kernel stages for B queries
 void launch_rescore_select(hipStream_t st, const ScanParams& p, const ScanParams* dp);
-void launch_reset_scan_state(hipStream_t st, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt, uint32_t* ticket);
+void launch_reset_scan_state(hipStream_t st, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt);
 void launch_merge(hipStream_t st, const pcv_hit_dev* lists, int n_shards, int B, int k, pcv_hit_dev* out,
                   int flagged = 0);
 void launch_similarity_matrix(hipStream_t st, const float* a, int B, const float* m, int64_t N, int D, int cosine,

@@ -322,68 +322,249 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const SegDesc* __restr
 
 // The clean state every pass starts from and rescore_select_kernel leaves behind.
 __global__ __launch_bounds__(256) void reset_scan_state_kernel(uint32_t* __restrict__ tau, uint32_t* __restrict__ slots,
-                                                               uint32_t* __restrict__ cand_cnt,
-                                                               uint32_t* __restrict__ ticket) {
+                                                               uint32_t* __restrict__ cand_cnt) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < kMfmaQueries * kMaxK) slots[t] = kKeyNegInf;
     if (t < kMfmaQueries) {
         tau[t * kHot] = kKeyNegInf;
         cand_cnt[t * kHot] = 0;
     }
-    if (t == 0) *ticket = 0;
+}
+
+// min over the k slots of query q = the threshold the seed rows alone justify.  Four threads per query.
+// Every consumer of a threshold takes max(this, tau): the seed kernel only fills the slots (no hand-off
+// inside a launch), and tau is raised by the scan's offers.
+__device__ __forceinline__ uint32_t seed_threshold_key(const ScanParams& p, int q, int sub /*0..3*/) {
+    uint32_t mn = 0xffffffffu;
+    if (q < p.B)
+        for (int j = sub; j < p.k; j += 4) mn = min(mn, ld_relaxed(&p.slots[(size_t)q * kMaxK + j]));
+    mn = min(mn, (uint32_t)__shfl_xor(mn, 1));
+    mn = min(mn, (uint32_t)__shfl_xor(mn, 2));
+    return q < p.B ? mn : kKeyNegInf;
+}
+
+// Host block -> device mirror (parameters, segment table, queries) by the compute queue itself: a
+// hipMemcpyAsync of this size goes through the SDMA engine and costs two queue hand-offs (~15 us).
+__global__ __launch_bounds__(256) void upload_kernel(const uint4* __restrict__ src_pinned, uint4* __restrict__ dst, uint32_t n16) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src_pinned[i];
 }
 
 // prep + seed in one launch.  Workgroup (part, query group) first brings its QG queries into scan form
 // (x / |x| for cosine; |q|^2 by a lane-parallel f64 sum — the canonical feature-order sum is only needed
 // for the exact scores and is made by rescore_select_kernel) — the `part == 0` workgroups also publish
-// them (f32, bf16, raw, margins) for the scan — then ranks rows [part*512, +512) of segment 0 against
+// them (f32, bf16, raw, margins) for the scan — then ranks rows [part*256, +256) of segment 0 against
 // them with f32 FMA chains.  Seed rows are split in k disjoint groups (row mod k); the best score of
 // each group goes to slot j: k distinct rows, so min(slots) is a valid running k-th best, without any
-// selection step.  The last workgroup to arrive turns the slots into the initial thresholds.  The
+// selection step and without any hand-off between workgroups (the atomics are fire-and-forget).  The
 // streaming kernels thus start with a useful threshold: with W waves in flight the first round screens
 // 32*W rows against it.
 template <int QG>
-__global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __restrict__ pp) {
+__global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __restrict__ pp, const float4* __restrict__ seg0_blk,
+                                                        const float* __restrict__ seg0_scale, uint32_t nseed) {
     const ScanParams& p = *pp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Dp = p.D4 * 4, D = p.D;
     float* sq = smem;                                // [QG][Dp]
     uint32_t* gmax = (uint32_t*)(smem + QG * Dp);    // [QG][kMaxK]
-    __shared__ uint32_t s_last;
-    const int part = blockIdx.x, q0 = blockIdx.y * QG, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int part = blockIdx.x, q0 = blockIdx.y * QG, tid = threadIdx.x;
     const bool writer = part == 0;
+    // thread t owns seed row part*256 + t.  16 pieces (256 B of the row) are requested per step before any
+    // of them is used: the phase is latency-bound (a workgroup reads 384 KB once), so what counts is bytes
+    // in flight — 64 KB per workgroup.  The first step's loads go out before the queries are prepared.
+    static_assert(kSeedPartRows == 256, "one seed row per thread");
+    const uint32_t row = part * kSeedPartRows + tid;
+    const uint32_t rowc = min(row, nseed ? nseed - 1 : 0u);
+    const float4* base = seg0_blk + (size_t)(rowc >> 5) * p.D4 * 32 + (rowc & 31);
+    float4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = gld4(base + (size_t)j * 32);
+    const float sc = row < nseed ? gld(&seg0_scale[row]) : 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+
     for (int i = tid; i < QG * kMaxK; i += 256) gmax[i] = kKeyNegInf;
-    for (int g = wave; g < QG; g += 4) {
+#ifdef PCV_DIAG
+    if (!(p.flags & 0x40))
+#endif
+    {
+        // all QG queries at once: LPQ lanes per query, each with every LPQ-th element, loads issued eight at a
+        // time (one query per wave after the other cost ~10 us each in dependent round trips)
+        constexpr int LPQ = QG >= 4 ? 256 / QG : 64;
+        const int g = tid / LPQ, sub = tid % LPQ;
         const int q = q0 + g;
-        float* dst = sq + g * Dp;
-        if (q >= p.B) {
-            for (int i = lane; i < Dp; i += 64) dst[i] = 0.0f;
-            continue;
-        }
-        const float* src = p.queries + (size_t)q * D;
+        const bool mine = g < QG;
+        const bool have = mine && q < p.B;
+        float* dst = sq + (mine ? g : 0) * Dp;
+        const float* src = p.queries + (size_t)(have ? q : 0) * D;
         double sum = 0.0;
-        for (int i = lane; i < Dp; i += 64) {
-            const float v = i < D ? gld(&src[i]) : 0.0f;
-            dst[i] = v;
-            sum += (double)v * (double)v;
+        for (int i0 = sub; i0 < Dp; i0 += 8 * LPQ) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * LPQ;
+                x[j] = (have && i < D) ? gld(&src[i]) : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * LPQ;
+                if (mine && i < Dp) dst[i] = x[j];
+                sum += (double)x[j] * (double)x[j];
+            }
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        for (int off = LPQ / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
         const bool ok = sum >= 0x1p-126 && sum < __builtin_inf();
         const float inv = (p.metric == PCV_METRIC_DOT) ? 1.0f : (ok ? (float)(1.0 / sqrt(sum)) : 0.0f);
         const bool live = (p.metric == PCV_METRIC_DOT) ? (sum < __builtin_inf()) : ok;
-        for (int i = lane; i < Dp; i += 64) {  // each lane rewrites the elements it wrote
+        if (mine) {
+            for (int i = sub; i < Dp; i += LPQ) {  // each lane rewrites the elements it wrote
+                const float raw = dst[i];
+                const float qh = (have && live) ? raw * inv : 0.0f;
+                dst[i] = qh;
+                if (writer && have) {
+                    gst(&p.qraw[(size_t)q * Dp + i], raw);
+                    gst(&p.qf32[(size_t)q * Dp + i], qh);
+                    const __bf16 hb = (__bf16)qh;
+                    gst(&p.qbf16[(size_t)q * Dp + i], __builtin_bit_cast(uint16_t, hb));
+                }
+            }
+            if (writer && have && sub == 0) {
+                // cosine: scores are O(1); dot: |s - c| <= eps * |q| * max|x|
+                float unit = 1.0f;
+                if (p.metric == PCV_METRIC_DOT) unit = (float)sqrt(sum) * p.max_norm * 1.0001f;
+                gst(&p.margin[q], (p.eps16 + p.eps32) * unit);
+                gst(&p.margin32[q], 2.0f * p.eps32 * unit);
+            }
+        }
+    }
+    if (writer && blockIdx.y == 0) {
+        // tile rows the scan kernel stages but no query fills
+        uint16_t* z = p.qbf16 + (size_t)p.B * Dp;
+        const int nz = ((int)p.tile_rows > p.B) ? ((int)p.tile_rows - p.B) * Dp : 0;
+        for (int i = tid; i < nz; i += 256) gst(&z[i], (uint16_t)0);
+        if (tid == 0 && p.flag_rec) {
+            pcv_hit_dev f;
+            f.score = 0.0;
+            f.pos = 0;
+            f.id = 0;
+            *p.flag_rec = f;
+        }
+    }
+    __syncthreads();
+
+    float acc[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) acc[g] = 0.0f;
+#ifdef PCV_DIAG
+    if (!(p.flags & 0x20))
+#endif
+    for (int f0 = 0; f0 < p.D4; f0 += 16) {  // D4 is a multiple of 16
+        if (f0 > 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = gld4(base + (size_t)(f0 + j) * 32);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                const float4 qv = *(const float4*)&sq[g * Dp + (f0 + j) * 4];
+                acc[g] = fmaf(qv.x, v[j].x, acc[g]);
+                acc[g] = fmaf(qv.y, v[j].y, acc[g]);
+                acc[g] = fmaf(qv.z, v[j].z, acc[g]);
+                acc[g] = fmaf(qv.w, v[j].w, acc[g]);
+            }
+    }
+    {
+        const uint32_t grp = row % (uint32_t)p.k;
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            const float s = acc[g] * sc;
+            if (sc != 0.0f && isfinite(s)) atomicMax(&gmax[g * kMaxK + grp], f32_key(s));
+        }
+    }
+    __syncthreads();
+#ifdef PCV_DIAG
+    if (!(p.flags & 0x10))
+#endif
+    for (int i = tid; i < QG * p.k; i += 256) {
+        const int g = i / p.k, j = i - g * p.k, q = q0 + g;
+        const uint32_t key = gmax[g * kMaxK + j];
+        if (q < p.B && key != kKeyNegInf) g_atomic_max(&p.slots[(size_t)q * kMaxK + j], key);
+    }
+}
+
+// The same prep + seed with the contraction on the exact-f32 matrix instruction (dim <= 1024, the normal
+// case): a workgroup takes 128 seed rows (four corpus blocks, one per wave) against a group of 32 queries;
+// v_mfma_f32_32x32x2_f32 is bitwise an fmaf chain, so the slots still hold f32-accurate scores.  The VALU
+// form above reads every query value from LDS once per row and is bound by that (12 us of LDS cycles + the
+// exposed load latency); here a query value is read once per 32 rows and the next 16 row pieces are in
+// flight while 64 MFMAs run.  Lane (r = lane&31, h = lane>>5) holds the pieces 2m+h of row r — the wave
+// kernel's register layout — so one 16-byte load feeds four MFMAs (k-pair j: features 8m+j | 8m+4+j).
+__global__ __launch_bounds__(256) void prep_seed_mfma_kernel(const ScanParams* __restrict__ pp, const float4* __restrict__ seg0_blk,
+                                                             const float* __restrict__ seg0_scale, uint32_t nseed) {
+    const ScanParams& p = *pp;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Dp = p.D4 * 4, D = p.D, LD = Dp + 4;  // padded query rows: the 16-lane ds_read_b128 groups hit 16 bank quads
+    float* sq = smem;                            // [32][LD]
+    uint32_t* gmax = (uint32_t*)(smem + 32 * LD);  // [32][k]
+    const int part = blockIdx.x, q0 = blockIdx.y * 32, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const bool writer = part == 0;
+    const uint32_t lb = part * 4 + wave;           // this wave's corpus block of segment 0
+    const bool active = lb * 32u < nseed;
+    const int P = p.D4 >> 1;                       // pieces per lane
+    const float4* base = seg0_blk + (size_t)(active ? lb : 0) * p.D4 * 32 + h * 32 + r;
+    float4 va[16], vb[16];
+    auto load16 = [&](float4 (&v)[16], int m0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (active && m0 + j < P) ? gld4(base + (size_t)(m0 + j) * 64) : make_float4(0, 0, 0, 0);
+    };
+    load16(va, 0);  // in flight while the queries are prepared
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int i = tid; i < 32 * p.k; i += 256) gmax[i] = kKeyNegInf;
+    {
+        // 32 queries at once, 8 lanes per query, loads issued eight at a time
+        const int g = tid >> 3, sub = tid & 7;
+        const int q = q0 + g;
+        const bool have = q < p.B;
+        float* dst = sq + g * LD;
+        const float* src = p.queries + (size_t)(have ? q : 0) * D;
+        double sum = 0.0;
+        for (int i0 = sub; i0 < Dp; i0 += 64) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + 8 * j;
+                x[j] = (have && i < D) ? gld(&src[i]) : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + 8 * j;
+                if (i < Dp) dst[i] = x[j];
+                sum += (double)x[j] * (double)x[j];
+            }
+        }
+        sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 1);
+        const bool ok = sum >= 0x1p-126 && sum < __builtin_inf();
+        const float inv = (p.metric == PCV_METRIC_DOT) ? 1.0f : (ok ? (float)(1.0 / sqrt(sum)) : 0.0f);
+        const bool live = have && ((p.metric == PCV_METRIC_DOT) ? (sum < __builtin_inf()) : ok);
+        for (int i = sub; i < Dp; i += 8) {  // each lane rewrites the elements it wrote
             const float raw = dst[i];
             const float qh = live ? raw * inv : 0.0f;
             dst[i] = qh;
-            if (writer) {
+            if (writer && have) {
                 gst(&p.qraw[(size_t)q * Dp + i], raw);
                 gst(&p.qf32[(size_t)q * Dp + i], qh);
                 const __bf16 hb = (__bf16)qh;
                 gst(&p.qbf16[(size_t)q * Dp + i], __builtin_bit_cast(uint16_t, hb));
             }
         }
-        if (writer && lane == 0) {
+        if (writer && have && sub == 0) {
             // cosine: scores are O(1); dot: |s - c| <= eps * |q| * max|x|
             float unit = 1.0f;
             if (p.metric == PCV_METRIC_DOT) unit = (float)sqrt(sum) * p.max_norm * 1.0001f;
@@ -406,72 +587,50 @@ __global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __rest
     }
     __syncthreads();
 
-    const SegDesc& sg = p.seg[0];
-    const uint32_t nseed = min(sg.nrows, p.seed_blocks * 32u);
-    // thread t owns rows base + t + 256*u, u = 0..RPT-1
-    const uint32_t row0 = part * kSeedPartRows + tid;
-    constexpr int RPT = kSeedPartRows / 256;
-    const float4* base[RPT];
-    float acc[RPT][QG];
+    f32x16 acc;
 #pragma unroll
-    for (int u = 0; u < RPT; ++u) {
-        const uint32_t row = min(row0 + 256u * u, nseed ? nseed - 1 : 0u);
-        base[u] = sg.blk + (size_t)(row >> 5) * p.D4 * 32 + (row & 31);
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const float* qrow = sq + r * LD + h * 4;  // lane (c = r, h): B operand of k-half h
+    auto mma16 = [&](const float4 (&v)[16], int m0) {
 #pragma unroll
-        for (int g = 0; g < QG; ++g) acc[u][g] = 0.0f;
-    }
-    for (int f0 = 0; f0 < p.D4; f0 += 4) {  // D4 is a multiple of 16
-        // all 4*RPT row loads of this step are issued before any of them is used (left to itself the
-        // compiler sinks each load next to its FMAs and the loop runs at one L2 latency per piece)
-        float4 v[4][RPT];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int u = 0; u < RPT; ++u) v[j][u] = gld4(base[u] + (size_t)(f0 + j) * 32);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int g = 0; g < QG; ++g) {
-                const float4 qv = *(const float4*)&sq[g * Dp + (f0 + j) * 4];
-#pragma unroll
-                for (int u = 0; u < RPT; ++u) {
-                    acc[u][g] = fmaf(qv.x, v[j][u].x, acc[u][g]);
-                    acc[u][g] = fmaf(qv.y, v[j][u].y, acc[u][g]);
-                    acc[u][g] = fmaf(qv.z, v[j][u].z, acc[u][g]);
-                    acc[u][g] = fmaf(qv.w, v[j][u].w, acc[u][g]);
-                }
+        for (int j = 0; j < 16; ++j) {
+            if (m0 + j < P) {  // wave-uniform
+                const float4 qv = *(const float4*)&qrow[(m0 + j) * 8];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].x, qv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].y, qv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].z, qv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j].w, qv.w, acc, 0, 0, 0);
             }
+        }
+    };
+    for (int m0 = 0; m0 < P; m0 += 32) {
+        if (m0 + 16 < P) load16(vb, m0 + 16);
+        __builtin_amdgcn_sched_barrier(0);
+        mma16(va, m0);
+        if (m0 + 32 < P) load16(va, m0 + 32);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m0 + 16 < P) mma16(vb, m0 + 16);
     }
+    // lane (c = r, h) holds query c's scores of the block rows (i&3) + 8(i>>2) + 4h
+    if (active) {
+        float sc[16];
 #pragma unroll
-    for (int u = 0; u < RPT; ++u) {
-        const uint32_t row = row0 + 256u * u;
-        const float sc = row < nseed ? gld(&sg.scale[row]) : 0.0f;
-        const uint32_t grp = row % (uint32_t)p.k;
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t row = lb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            sc[i] = row < nseed ? gld(&seg0_scale[row]) : 0.0f;
+        }
 #pragma unroll
-        for (int g = 0; g < QG; ++g) {
-            const float s = acc[u][g] * sc;
-            if (sc != 0.0f && isfinite(s)) atomicMax(&gmax[g * kMaxK + grp], f32_key(s));
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t row = lb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float s = acc[i] * sc[i];
+            if (sc[i] != 0.0f && isfinite(s)) atomicMax(&gmax[r * p.k + row % (uint32_t)p.k], f32_key(s));
         }
     }
     __syncthreads();
-    for (int i = tid; i < QG * p.k; i += 256) {
+    for (int i = tid; i < 32 * p.k; i += 256) {
         const int g = i / p.k, j = i - g * p.k, q = q0 + g;
-        const uint32_t key = gmax[g * kMaxK + j];
+        const uint32_t key = gmax[i];
         if (q < p.B && key != kKeyNegInf) g_atomic_max(&p.slots[(size_t)q * kMaxK + j], key);
-    }
-    // arrival: every atomic of this workgroup has been performed before its ticket is drawn
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) s_last = g_atomic_add(p.ticket, 1u) == gridDim.x * gridDim.y - 1u;
-    __syncthreads();
-    if (s_last) {
-        for (int q = tid; q < p.B; q += 256) {
-            uint32_t mn = 0xffffffffu;
-            for (int j = 0; j < p.k; ++j) mn = min(mn, ld_relaxed(&p.slots[(size_t)q * kMaxK + j]));
-            st_relaxed(&p.tau[q * kHot], mn);
-        }
-        if (tid == 0) st_relaxed(p.ticket, 0u);
     }
 }
 
@@ -489,8 +648,12 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     float mrg[NB];
+    uint32_t tau0[NB];  // what the seed rows alone justify (see seed_threshold_key)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) mrg[b] = gld(&p.margin32[b]);
+    for (int b = 0; b < NB; ++b) {
+        mrg[b] = gld(&p.margin32[b]);
+        tau0[b] = seed_threshold_key(p, b, lane & 3);
+    }
     const uint32_t total_waves = gridDim.x * 4;
     const int NCH = p.D4 >> 4;  // chunks of 8 pieces per lane (64 features of the row, both halves)
     if (blockIdx.x * 4 + wave >= p.total_blocks) return;
@@ -534,7 +697,7 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
     auto consume = [&](const float4 (&bf)[8]) {
         if (cons.ch == (NCH >= 2 ? NCH - 2 : 0)) {  // thresholds one chunk ahead of the epilogue
 #pragma unroll
-            for (int b = 0; b < NB; ++b) tk[b] = ld_relaxed(&p.tau[b * kHot]);
+            for (int b = 0; b < NB; ++b) tk[b] = max(tau0[b], ld_relaxed(&p.tau[b * kHot]));
         }
         const float* qb = sq + h * 4 + cons.ch * 64;
 #pragma unroll
@@ -636,13 +799,22 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
         const int q = i / P8, pc = i - q * P8;
         lq[q * P8 + ((pc & ~15) | ((pc ^ q) & 15))] = __builtin_bit_cast(uint4, gld4((const float4*)p.qbf16 + i));
     }
+    __shared__ uint32_t ltau0[NT * 32];  // what the seed rows alone justify, per query (see seed_threshold_key)
+    for (int q = threadIdx.x >> 2; q < NT * 32; q += WPB * 16) {
+        const uint32_t key = seed_threshold_key(p, q, threadIdx.x & 3);
+        if ((threadIdx.x & 3) == 0) ltau0[q] = key;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     float mrg[NT];
+    uint32_t tau0[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) mrg[t] = (32 * t + c < p.B) ? gld(&p.margin[32 * t + c]) : 0.0f;
+    for (int t = 0; t < NT; ++t) {
+        mrg[t] = (32 * t + c < p.B) ? gld(&p.margin[32 * t + c]) : 0.0f;
+        tau0[t] = ltau0[32 * t + c];
+    }
 
     const uint32_t total_waves = gridDim.x * WPB;
     if (blockIdx.x * WPB + wave >= p.total_blocks) return;
@@ -688,7 +860,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
     uint32_t tauk[NT];
     auto tau_prefetch = [&]() {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? ld_relaxed(&p.tau[(32 * t + c) * kHot]) : 0u;
+        for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? max(tau0[t], ld_relaxed(&p.tau[(32 * t + c) * kHot])) : 0u;
     };
 
     auto epilogue = [&](const SegCursor& esc, uint32_t elb) {
@@ -730,7 +902,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
                         const float sc = gld(&scp[rib]);
                         if (sc == 0.0f) continue;  // padding / unsearchable row
                         const float s32 = wave_dot_f32(p.qf32 + (size_t)q * Dp, bbase + rib, D4, lane) * sc;
-                        const float taun = key_f32(ld_relaxed(&p.tau[q * kHot]));
+                        const float taun = key_f32(max(ltau0[q], ld_relaxed(&p.tau[q * kHot])));
                         if (s32 < taun - m32) continue;
                         if (lane == 0) {
                             const uint32_t at = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
@@ -808,12 +980,15 @@ __device__ __forceinline__ bool better(double sa, int64_t pa, double sb, int64_t
 //      8 lanes fetch a row's pieces together into LDS (all loads in flight at once) and one lane per
 //      row runs the feature-order sums from there; otherwise a thread per survivor reads its row
 //      from global memory;
-//   3. rank: descending score, ties -> lower global position.  Up to kSelCap valid survivors (the normal
-//      case is a few dozen) are ranked in LDS by counting, each thread the rows that beat its own;
-//      longer lists fall back to k rounds of argmax over the scores kept in global memory;
+//   3. rank: descending score, ties -> lower global position.  Scored survivors collect in an LDS buffer
+//      of kSelCap entries (the normal case is a few dozen) and are ranked there by counting, each thread
+//      the rows that beat its own.  A list longer than the buffer (thousands of rows within 1e-4 of the
+//      k-th best, or an adversarial row order) is consumed in slices of 1024: when the next slice might
+//      not fit, the buffer is cut down to its k best, whose last entry becomes an exact admission
+//      threshold for everything scored later;
 //   4. write the k hits to the device list and, if asked, straight into pinned host memory; report the
 //      uncapped survivor count; leave the per-query scan state clean for the next pass.
-constexpr int kSelCap = 1024;
+constexpr int kSelCap = 2048;
 constexpr int kCoopMaxD4 = 112;  // LDS: (D4 + 32*(D4+1)) * 16 B <= 58 KB
 template <bool COOP>
 __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* __restrict__ pp) {
@@ -821,34 +996,45 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
     extern __shared__ float4 lds4[];  // [D4] raw query | COOP: 4 waves x 8 slots x (D4+1) row pieces
     __shared__ double c_s[kSelCap];
     __shared__ int64_t c_p[kSelCap];
-    __shared__ uint32_t c_i[kSelCap];
-    __shared__ uint32_t surv[1024];
+    __shared__ uint64_t c_e[kSelCap];   // (segment << 32) | row of the entry
+    __shared__ double k_s[kMaxK];
+    __shared__ int64_t k_p[kMaxK];
+    __shared__ uint64_t k_e[kMaxK];
+    __shared__ uint64_t surv[1024];  // candidates of the current slice that pass the final threshold
     __shared__ uint32_t nsurv, n_valid;
-    __shared__ double s_nq;
-    __shared__ double r_s[4];
-    __shared__ int64_t r_p[4];
-    __shared__ uint32_t r_i[4];
+    __shared__ double s_nq, t_s;  // canonical |q|^2; score of the admission threshold
+    __shared__ int64_t t_p;       // ... and its position
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D4 = p.D4;
     const uint32_t raw_cnt = ld_relaxed(&p.cand_cnt[q * kHot]);
     const uint32_t cnt = min(raw_cnt, p.cand_cap);
     const uint64_t* cand = p.cand + (size_t)q * p.cand_cap;
     const float* cs = p.cand_s + (size_t)q * p.cand_cap;
-    double* sc = p.cand_score + (size_t)q * p.cand_cap;
     float4* sq = lds4;
     for (int i = tid; i < D4; i += 256) sq[i] = ((const float4*)(p.qraw + (size_t)q * D4 * 4))[i];
+    __shared__ uint32_t s_tau0;
+    if (tid >= 64 && tid < 68) {  // (not wave 0: it initialises, not wave 3: it sums the query norm)
+        const uint32_t key = seed_threshold_key(p, q, tid & 3);
+        if (tid == 64) s_tau0 = key;
+    }
     if (tid == 0) {
         n_valid = 0;
         nsurv = 0;
+        t_s = -__builtin_inf();
+        t_p = INT64_MAX;
     }
     __syncthreads();
+    const float thr_final = key_f32(max(s_tau0, ld_relaxed(&p.tau[q * kHot]))) - p.margin32[q];
+#ifdef PCV_DIAG
+    if (!(p.flags & 0x100))
+#endif
     if (tid == 255) {  // canonical |q|^2: f64, feature order (the other waves go on to the filter meanwhile)
         double nq = 0.0;
         const float* f = (const float*)sq;
+#pragma unroll 16
         for (int i = 0; i < p.D; ++i) nq += (double)f[i] * (double)f[i];
         s_nq = nq;
     }
-    const float thr_final = key_f32(ld_relaxed(&p.tau[q * kHot])) - p.margin32[q];
     const double inf = __builtin_inf();
     auto finish_score = [&](double dot, double nx, double nq) -> double {
         if (p.metric == PCV_METRIC_DOT) return (dot < inf && dot > -inf && nq < inf) ? dot : __builtin_nan("");
@@ -858,23 +1044,54 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
         }
         return __builtin_nan("");
     };
-    auto keep = [&](uint32_t j, double score) {  // one survivor's canonical score
-        sc[j] = score;
+    auto keep = [&](uint64_t e, double score) {  // one survivor's canonical score
         if (!(score == score)) return;  // NaN: undefined score
-        const uint32_t slot = atomicAdd(&n_valid, 1u);
-        if (slot < (uint32_t)kSelCap) {
-            const uint64_t e = cand[j];
-            c_s[slot] = score;
-            c_p[slot] = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
-            c_i[slot] = j;
-        }
+        const int64_t pos = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
+        if (!better(score, pos, t_s, t_p)) return;  // k rows seen earlier are all ahead of it
+        const uint32_t slot = atomicAdd(&n_valid, 1u);  // < kSelCap: the buffer had room for a whole slice
+        c_s[slot] = score;
+        c_p[slot] = pos;
+        c_e[slot] = e;
     };
+    // rank of buffer entry i among the nv entries (positions are unique: the ranks are a permutation)
+    auto rank_of = [&](uint32_t i, uint32_t nv) {
+        const double s = c_s[i];
+        const int64_t pos = c_p[i];
+        int rank = 0;
+        for (uint32_t j = 0; j < nv; ++j) rank += better(c_s[j], c_p[j], s, pos) ? 1 : 0;
+        return rank;
+    };
+#ifdef PCV_DIAG
+    if (!(p.flags & 0x80))
+#endif
     for (uint32_t base = 0; base < cnt; base += 1024) {
+        if (n_valid + 1024u > (uint32_t)kSelCap) {  // same value in every thread: read after a barrier
+            const uint32_t nv = n_valid;
+            for (uint32_t i = tid; i < nv; i += 256) {
+                const int r = rank_of(i, nv);
+                if (r < p.k) {
+                    k_s[r] = c_s[i];
+                    k_p[r] = c_p[i];
+                    k_e[r] = c_e[i];
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < p.k; i += 256) {  // nv > kSelCap - 1024 >= k
+                c_s[i] = k_s[i];
+                c_p[i] = k_p[i];
+                c_e[i] = k_e[i];
+            }
+            if (tid == 0) {
+                n_valid = (uint32_t)p.k;
+                t_s = k_s[p.k - 1];
+                t_p = k_p[p.k - 1];
+            }
+            __syncthreads();
+        }
         for (uint32_t j = base + tid; j < min(cnt, base + 1024u); j += 256) {
-            if (cs[j] < thr_final)
-                sc[j] = __builtin_nan("");
-            else
-                surv[atomicAdd(&nsurv, 1u)] = j;
+            const float sj = cs[j];
+            const uint64_t ej = cand[j];  // fetched with the score, not after the test
+            if (!(sj < thr_final)) surv[atomicAdd(&nsurv, 1u)] = ej;
         }
         __syncthreads();  // nsurv is final; s_nq is there
         const uint32_t ns = nsurv;
@@ -885,39 +1102,46 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
             for (uint32_t g = wave * 8; g < ns; g += 32) {
                 const uint32_t si = g + slot;
                 const bool live = si < ns;
-                const uint32_t j = live ? surv[si] : 0;
+                const uint64_t e = live ? surv[si] : 0;
                 if (live) {
-                    const uint64_t e = cand[j];
                     const SegDesc& sg = p.seg[(int)(e >> 32)];
                     const uint32_t row = (uint32_t)e;
                     const float4* src = sg.blk + (size_t)(row >> 5) * D4 * 32 + (row & 31);
-                    for (int f4 = part; f4 < D4; f4 += 8) rows[slot * (D4 + 1) + f4] = src[(size_t)f4 * 32];
+                    // eight pieces per lane requested before any is stored (a load-store loop runs at one
+                    // memory round trip per piece)
+                    for (int f0 = part; f0 < D4; f0 += 64) {
+                        float4 t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t[u] = f0 + 8 * u < D4 ? gld4(src + (size_t)(f0 + 8 * u) * 32) : make_float4(0, 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (f0 + 8 * u < D4) rows[slot * (D4 + 1) + f0 + 8 * u] = t[u];
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0);  // the row pieces of this wave are in LDS
-                if (live && part == 0) {
+                // the two feature-order chains of a row run on two lanes: part 0 sums q*x, part 1 sums x*x
+                // (one instruction stream: the multiplicand is selected, not branched on)
+                double chain = 0.0;
+                if (live && part < 2) {
                     const float4* r = rows + slot * (D4 + 1);
-                    double dot = 0.0, nx = 0.0;
-                    for (int f4 = 0; f4 < D4; ++f4) {
+#pragma unroll 8
+                    for (int f4 = 0; f4 < D4; ++f4) {  // unrolled: the LDS reads run ahead of the dependent f64 chain
                         const float4 v = r[f4];
-                        const float4 qv = sq[f4];
-                        dot += (double)qv.x * (double)v.x;
-                        nx += (double)v.x * (double)v.x;
-                        dot += (double)qv.y * (double)v.y;
-                        nx += (double)v.y * (double)v.y;
-                        dot += (double)qv.z * (double)v.z;
-                        nx += (double)v.z * (double)v.z;
-                        dot += (double)qv.w * (double)v.w;
-                        nx += (double)v.w * (double)v.w;
+                        const float4 m = part == 0 ? sq[f4] : v;
+                        chain += (double)m.x * (double)v.x;
+                        chain += (double)m.y * (double)v.y;
+                        chain += (double)m.z * (double)v.z;
+                        chain += (double)m.w * (double)v.w;
                     }
-                    keep(j, finish_score(dot, nx, nq));
                 }
+                const double nx = __shfl(chain, (lane & ~7) | 1);
+                if (live && part == 0) keep(e, finish_score(chain, nx, nq));
                 __builtin_amdgcn_wave_barrier();
             }
         } else {
             for (uint32_t si = tid; si < ns; si += 256) {
-                const uint32_t j = surv[si];
-                const uint64_t e = cand[j];
+                const uint64_t e = surv[si];
                 const SegDesc& sg = p.seg[(int)(e >> 32)];
                 const uint32_t row = (uint32_t)e;
                 const float4* src = sg.blk + (size_t)(row >> 5) * D4 * 32 + (row & 31);
@@ -935,7 +1159,7 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
                     dot += (double)qv.w * (double)v.w;
                     nx += (double)v.w * (double)v.w;
                 }
-                keep(j, finish_score(dot, nx, nq));
+                keep(e, finish_score(dot, nx, nq));
             }
         }
         __syncthreads();
@@ -949,80 +1173,24 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
         out[j] = hit;
         if (outh) outh[j] = hit;
     };
-    auto make_hit = [&](uint32_t gi, double s, int64_t pos) {
-        const uint64_t e = cand[gi];
-        const SegDesc& sg = p.seg[(int)(e >> 32)];
-        const uint32_t row = (uint32_t)e;
-        pcv_hit_dev hit;
-        hit.score = s;
-        hit.pos = pos;
-        hit.id = sg.ids ? sg.ids[row] : sg.id0 + (int64_t)row;
-        return hit;
-    };
+    for (uint32_t i = tid; i < nv; i += 256) {
+        const int r = rank_of(i, nv);
+        if (r < p.k) {
+            const uint64_t e = c_e[i];
+            const SegDesc& sg = p.seg[(int)(e >> 32)];
+            const uint32_t row = (uint32_t)e;
+            pcv_hit_dev hit;
+            hit.score = c_s[i];
+            hit.pos = c_p[i];
+            hit.id = sg.ids ? sg.ids[row] : sg.id0 + (int64_t)row;
+            put(r, hit);
+        }
+    }
     pcv_hit_dev none;
     none.score = __builtin_nan("");
     none.pos = -1;
     none.id = -1;
-    if (nv <= (uint32_t)kSelCap) {
-        // rank by counting: positions are unique, so the ranks are a permutation
-        for (uint32_t i = tid; i < nv; i += 256) {
-            const double s = c_s[i];
-            const int64_t pos = c_p[i];
-            int rank = 0;
-            for (uint32_t j = 0; j < nv; ++j) rank += better(c_s[j], c_p[j], s, pos) ? 1 : 0;
-            if (rank < p.k) put(rank, make_hit(c_i[i], s, pos));
-        }
-        for (int j = (int)nv + tid; j < p.k; j += 256) put(j, none);
-    } else {
-        for (int j = 0; j < p.k; ++j) {
-            double bs = -__builtin_inf();
-            int64_t bp = INT64_MAX;
-            uint32_t bi = 0xffffffffu;
-            for (uint32_t i = tid; i < cnt; i += 256) {
-                const double s = sc[i];
-                if (!(s == s)) continue;
-                const uint64_t e = cand[i];
-                const int64_t pos = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
-                if (bi == 0xffffffffu || better(s, pos, bs, bp)) {
-                    bs = s;
-                    bp = pos;
-                    bi = i;
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double os = __shfl_xor(bs, off);
-                const int64_t op = __shfl_xor(bp, off);
-                const uint32_t oi = __shfl_xor(bi, off);
-                if (oi != 0xffffffffu && (bi == 0xffffffffu || better(os, op, bs, bp))) {
-                    bs = os;
-                    bp = op;
-                    bi = oi;
-                }
-            }
-            if (lane == 0) {
-                r_s[wave] = bs;
-                r_p[wave] = bp;
-                r_i[wave] = bi;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                for (int w = 1; w < 4; ++w)
-                    if (r_i[w] != 0xffffffffu && (bi == 0xffffffffu || better(r_s[w], r_p[w], bs, bp))) {
-                        bs = r_s[w];
-                        bp = r_p[w];
-                        bi = r_i[w];
-                    }
-                if (bi != 0xffffffffu) {
-                    put(j, make_hit(bi, bs, bp));
-                    sc[bi] = __builtin_nan("");
-                } else {
-                    put(j, none);
-                }
-            }
-            __syncthreads();
-        }
-    }
+    for (int j = (int)nv + tid; j < p.k; j += 256) put(j, none);
     // survivor count (uncapped: the host sizes a rerun from it), overflow record, clean state
     if (tid == 0) {
         if (p.cnt_host) p.cnt_host[q] = raw_cnt;
@@ -1171,19 +1339,38 @@ void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const i
     PCV_LAUNCHED();
 }
 
-void launch_reset_scan_state(hipStream_t st, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt, uint32_t* ticket) {
-    reset_scan_state_kernel<<<kMfmaQueries * kMaxK / 256, 256, 0, st>>>(tau, slots, cand_cnt, ticket);
+void launch_reset_scan_state(hipStream_t st, uint32_t* tau, uint32_t* slots, uint32_t* cand_cnt) {
+    reset_scan_state_kernel<<<kMfmaQueries * kMaxK / 256, 256, 0, st>>>(tau, slots, cand_cnt);
     PCV_LAUNCHED();
 }
 
-void launch_prep_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
+void launch_upload(hipStream_t st, const void* src_pinned, void* dst, size_t bytes) {
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    if (n16 == 0) return;
+    upload_kernel<<<(n16 + 255) / 256, 256, 0, st>>>((const uint4*)src_pinned, (uint4*)dst, n16);
+    PCV_LAUNCHED();
+}
+
+void launch_prep_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp, const SegDesc& seg0) {
     const int nparts = std::max(1, (int)((p.seed_blocks * 32u + kSeedPartRows - 1) / kSeedPartRows));
+    const uint32_t nseed = std::min<uint32_t>(seg0.nrows, p.seed_blocks * 32u);
     const size_t Dp = (size_t)p.D4 * 4;
     const size_t lds1 = Dp * sizeof(float) + kMaxK * sizeof(uint32_t);
-    if (p.B <= 2 || 8 * lds1 > 64 * 1024) {  // few queries, or very wide rows: one query per workgroup
-        prep_seed_kernel<1><<<dim3(nparts, p.B), 256, lds1, st>>>(dp);
-    } else {  // 8 queries share every seed row load
-        prep_seed_kernel<8><<<dim3(nparts, (p.B + 7) / 8), 256, 8 * lds1, st>>>(dp);
+    const size_t lds_mfma = 32 * (Dp + 4) * sizeof(float) + 32 * (size_t)p.k * sizeof(uint32_t);
+    if (lds_mfma <= 156 * 1024 && !(p.flags & 4)) {  // flag bit 2: the VALU form (tuning / comparison)
+        static size_t lds_allowed = 64 * 1024;
+        if (lds_mfma > lds_allowed) {
+            PCV_HIP(hipFuncSetAttribute((const void*)prep_seed_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
+            lds_allowed = lds_mfma;
+        }
+        const unsigned parts = (p.seed_blocks + 3) / 4;
+        prep_seed_mfma_kernel<<<dim3(parts ? parts : 1, (p.B + 31) / 32), 256, lds_mfma, st>>>(dp, seg0.blk, seg0.scale, nseed);
+    } else if (p.B <= 2 || 8 * lds1 > 64 * 1024) {  // few queries, or very wide rows: one query per workgroup
+        prep_seed_kernel<1><<<dim3(nparts, p.B), 256, lds1, st>>>(dp, seg0.blk, seg0.scale, nseed);
+    } else if (p.B <= 32 || 16 * lds1 > 64 * 1024 || !(p.flags & 2)) {  // 8 queries share every seed row load
+        prep_seed_kernel<8><<<dim3(nparts, (p.B + 7) / 8), 256, 8 * lds1, st>>>(dp, seg0.blk, seg0.scale, nseed);
+    } else {  // tuning (flag bit 1): 16 do
+        prep_seed_kernel<16><<<dim3(nparts, (p.B + 15) / 16), 256, 16 * lds1, st>>>(dp, seg0.blk, seg0.scale, nseed);
     }
     PCV_LAUNCHED();
 }
@@ -1237,13 +1424,11 @@ uint32_t mfma_tile_rows(int B) { return B <= 32 ? 32u : (B <= 64 ? 64u : 128u); 
 
 template <int NT, bool NTL, int WPB, int NBUF>
 static void launch_mfma_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
-    if (lds > 64 * 1024) {
-        static bool attr_set = false;  // one flag per instantiation
-        if (!attr_set) {
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma_kernel<NT, NTL, WPB, NBUF>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+    static size_t lds_allowed = 64 * 1024;  // one per instantiation; the static LDS of the kernel comes on top
+    if (lds > lds_allowed) {
+        PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma_kernel<NT, NTL, WPB, NBUF>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_allowed = lds;
     }
     scan_mfma_kernel<NT, NTL, WPB, NBUF><<<grid, WPB * 64, lds, st>>>(dp);
 }

@@ -90,9 +90,8 @@ struct pcv_searcher {
     // per-search workspace (sized for one pass of <= 128 queries)
     DevBuf<float> d_qf32, d_qraw, d_margin, d_margin32;
     DevBuf<uint16_t> d_qbf16;
-    DevBuf<double> d_cand_score;
     DevBuf<float> d_cand_s;
-    DevBuf<uint32_t> d_tau, d_slots, d_cnt, d_ticket;
+    DevBuf<uint32_t> d_tau, d_slots, d_cnt;
     DevBuf<uint64_t> d_cand;
     DevBuf<pcv_hit_dev> d_hits;
     // what one pass takes up: ScanParams | SegDesc[nseg] | queries[B][D], built in pinned memory and
@@ -309,9 +308,7 @@ void ensure_workspace(pcv_searcher* s) {
     s->d_tau.ensure(Q * kHot);
     s->d_slots.ensure(Q * kMaxK);
     s->d_cnt.ensure(Q * kHot);
-    s->d_ticket.ensure(64);
     s->d_cand.ensure(Q * s->cand_cap);
-    s->d_cand_score.ensure(Q * s->cand_cap);
     s->d_cand_s.ensure(Q * s->cand_cap);
     s->d_hits.ensure(Q * kMaxK);
     if (!s->pin) PCV_HIP(hipHostMalloc((void**)&s->pin, sizeof(pcv_searcher::Pinned), hipHostMallocDefault));
@@ -355,7 +352,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     hipStream_t st = s->ctx->stream;
     ensure_workspace(s);
     ensure_pass_block(s, (size_t)nseg);
-    if (!s->state_clean) launch_reset_scan_state(st, s->d_tau.p, s->d_slots.p, s->d_cnt.p, s->d_ticket.p);
+    if (!s->state_clean) launch_reset_scan_state(st, s->d_tau.p, s->d_slots.p, s->d_cnt.p);
     s->state_clean = false;  // until finish_pass has seen the pass through
     const PassLayout L = pass_layout(s, (size_t)nseg);
     ScanParams& p = *reinterpret_cast<ScanParams*>(s->pin_pass);
@@ -390,8 +387,6 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.cand_cnt = s->d_cnt.p;
     p.cand = s->d_cand.p;
     p.cand_s = s->d_cand_s.p;
-    p.cand_score = s->d_cand_score.p;
-    p.ticket = s->d_ticket.p;
     p.out = d_out ? d_out : s->d_hits.p;
     p.out_host = download ? s->pin->hits : nullptr;
     p.cnt_host = s->pin->cnt;
@@ -413,8 +408,8 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     }
     const ScanParams* dp = reinterpret_cast<const ScanParams*>(s->d_pass);
     PCV_HIP(hipEventRecord(s->ev[0], st));
-    PCV_HIP(hipMemcpyAsync(s->d_pass, s->pin_pass, bytes, hipMemcpyHostToDevice, st));
-    launch_prep_seed(st, p, dp);
+    launch_upload(st, s->pin_pass, s->d_pass, bytes);
+    launch_prep_seed(st, p, dp, tab[0]);
     PCV_HIP(hipEventRecord(s->ev[1], st));
     if (kernel == PCV_KERNEL_MFMA)
         launch_scan_mfma(st, p, dp, s->ctx->num_cus);
@@ -470,7 +465,6 @@ bool finish_pass(pcv_searcher* s) {
     want = std::min<uint64_t>(want, (uint64_t)rows + 1024);
     s->cand_cap = (uint32_t)std::max<uint64_t>(want, s->cand_cap * 2ull);
     s->d_cand.ensure((size_t)kMfmaQueries * s->cand_cap);
-    s->d_cand_score.ensure((size_t)kMfmaQueries * s->cand_cap);
     s->d_cand_s.ensure((size_t)kMfmaQueries * s->cand_cap);
     return true;
 }
@@ -629,12 +623,10 @@ pcv_status pcv_searcher_destroy(pcv_searcher* s) {
         s->d_margin.release();
         s->d_margin32.release();
         s->d_qbf16.release();
-        s->d_cand_score.release();
         s->d_cand_s.release();
         s->d_tau.release();
         s->d_slots.release();
         s->d_cnt.release();
-        s->d_ticket.release();
         s->d_cand.release();
         s->d_hits.release();
         if (s->pin) (void)hipHostFree(s->pin);
@@ -865,7 +857,6 @@ pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candi
         s->cand_cap = n_candidates;  // the lists are (re)sized to it by the next pass; a pass that needs more grows them
         s->d_cand.release();
         s->d_cand_s.release();
-        s->d_cand_score.release();
     });
 }
 

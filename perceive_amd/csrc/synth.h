@@ -47,19 +47,25 @@ __device__ static inline float4 synth_piece(uint64_t seed, int64_t row, uint32_t
 }
 
 // Clustered variant (bench.py --clustered, DESIGN.md §synthetic data): row = centroid(cluster(row)) / sqrt(D)
-// + noise * synth_row(seed, row), cluster(row) = hash(row) mod n_clusters, centroid(j) = synth row j of
-// the stream `seed ^ kClusterSeedXor`.  Members of one cluster are then within a few `noise` of each
-// other in cosine — the shape of real sentence embeddings that a fixed-width screen has to survive.
+// + noise * u(row) * synth_row(seed, row), cluster(row) = hash(row) mod n_clusters, centroid(j) = synth
+// row j of the stream `seed ^ kClusterSeedXor`, u(row) uniform in [0.5, 1.5) from a second hash.  In high
+// dimension i.i.d. noise of one amplitude puts every member at the same angle from every other (cosines
+// equal to 1e-4); the per-row amplitude spreads the cosines of a cluster over ~noise^2 * D, a continuum
+// like the neighbourhood of a real sentence embedding, which a fixed-width screen has to survive.
 constexpr uint64_t kClusterSeedXor = 0xC1057E25EED5ull;
 __host__ __device__ static inline uint32_t synth_cluster_of(int64_t row, uint32_t n_clusters) {
     return (uint32_t)(((uint64_t)row * 0x9E3779B97F4A7C15ull) >> 33) % n_clusters;
+}
+__host__ __device__ static inline float synth_amplitude_of(int64_t row) {  // uniform in [0.5, 1.5), 24 bits
+    return 0.5f + (float)(uint32_t)((((uint64_t)row * 0xD6E8FEB86659FD93ull) >> 40) & 0xffffffu) * (1.0f / 16777216.0f);
 }
 __device__ static inline float4 synth_piece_clustered(uint64_t seed, int64_t row, uint32_t f4, uint32_t n_clusters,
                                                       float noise, float inv_sqrt_d) {
     const float4 c = synth_piece(seed ^ kClusterSeedXor, (int64_t)synth_cluster_of(row, n_clusters), f4);
     const float4 n = synth_piece(seed, row, f4);
-    return make_float4(fmaf(noise, n.x, c.x * inv_sqrt_d), fmaf(noise, n.y, c.y * inv_sqrt_d),
-                       fmaf(noise, n.z, c.z * inv_sqrt_d), fmaf(noise, n.w, c.w * inv_sqrt_d));
+    const float a = noise * synth_amplitude_of(row);
+    return make_float4(fmaf(a, n.x, c.x * inv_sqrt_d), fmaf(a, n.y, c.y * inv_sqrt_d),
+                       fmaf(a, n.z, c.z * inv_sqrt_d), fmaf(a, n.w, c.w * inv_sqrt_d));
 }
 
 }  // namespace pcv

@@ -398,7 +398,7 @@ def test_clustered_rows_stay_exact_and_selective(ctx, oracle):
     # clustered corpus (centroid + small noise): thousands of rows sit inside the bf16 margin of the k-th
     # best.  The exact-f32 second screen keeps the lists short, nothing overflows, results are exact.
     N, D, B, k = 300_000, 384, 64, 10
-    ncl, noise = 30, 0.0015  # ~10^4 rows per cluster, members within ~0.01 cosine of each other
+    ncl, noise = 30, 0.004  # ~10^4 rows per cluster, cosines inside a cluster spread over ~0.006
     ref = oracle.synth_rows_clustered(0xABCD, 0, N, D, ncl, noise)
     s = pa.Searcher(ctx, D, "cosine")
     s.add_synthetic(1, N, 0xABCD, n_clusters=ncl, noise=noise)

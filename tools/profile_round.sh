@@ -15,6 +15,8 @@ run() {  # run <dir under gpurun_out> <rocprof args...> -- <program...>
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-extra"
 run prof_default     --kernel-trace --stats --output-format csv -d $G/prof_default     -o p -- $BENCH --steps 10
 run prof_10m_b1      --kernel-trace --stats --output-format csv -d $G/prof_10m_b1      -o p -- $BENCH --steps 20 --rows 10000000 --batch 1
+run prof_clustered   --kernel-trace --stats --output-format csv -d $G/prof_clustered   -o p -- $BENCH --steps 10 --clustered
+run prof_12p5m       --kernel-trace --stats --output-format csv -d $G/prof_12p5m       -o p -- $BENCH --steps 20 --rows 12500000
 run pmc_fetch        --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/pmc_fetch        -o p -- $BENCH --steps 3 --warmup 1
 run pmc_write        --pmc WRITE_SIZE --kernel-trace --output-format csv -d $G/pmc_write        -o p -- $BENCH --steps 3 --warmup 1
 run pmc_fetch_10m_b1 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/pmc_fetch_10m_b1 -o p -- $BENCH --steps 3 --warmup 1 --rows 10000000 --batch 1
