@@ -44,6 +44,7 @@ enum { PCV_METRIC_COSINE = 0, PCV_METRIC_DOT = 1 };
 typedef struct pcv_ctx pcv_ctx;
 typedef struct pcv_searcher pcv_searcher;
 typedef struct pcv_model pcv_model;
+typedef struct pcv_tokenizer pcv_tokenizer;
 
 /* ---- library / device context ------------------------------------------------------------- */
 
@@ -318,12 +319,62 @@ typedef struct pcv_encode_stats {
 } pcv_encode_stats;
 pcv_status pcv_model_last_stats(pcv_model* m, pcv_encode_stats* out);
 
+/* ---- Model, text side (model.rs:68-179, model/highlight.rs) -------------------------------------------
+ * The host logic that sits between text and the device forward — model directories, tokenisation of a
+ * batch, chunk planning and offset mapping of highlight — in the library, so that a Rust / C++ host gets
+ * the whole of Model::{new_pretrained, encode, highlight} from this ABI. */
+
+/* Directory name of a SentenceEmbeddingsModelType variant under model_data/ (configs.rs:30-69,121-141):
+ * 0 AllMiniLmL6V2 .. 7 MsMarcoBertBaseDotV5, the enum order, which is also model_id() (configs.rs:72-83).
+ * NULL for an unknown value. */
+const char* pcv_model_type_dir_name(int model_type);
+
+/* Model::new_pretrained (model.rs:68-174) from a sentence-transformers model directory: modules.json,
+ * config.json, sentence_bert_config.json, tokenizer_config.json, vocab.txt (or vocab.json + merges.txt),
+ * <n>_Pooling/config.json, optional <n>_Dense/{config.json, model.safetensors}.  BERT, DistilBERT and RoBERTa
+ * transformers (the ALBERT variant is refused with PCV_ERR_UNSUPPORTED).  The model owns its tokenizer.
+ *   compute       PCV_COMPUTE_*
+ *   load_weights  != 0: read model.safetensors (F32 / F16 / BF16; nothing in the file is executed);
+ *                 0: leave the weights to the caller — hand every checkpoint tensor to pcv_model_load_hf_tensor
+ *                 (e.g. from rust_model.ot or pytorch_model.bin read by the host's own safe loader), then
+ *                 pcv_model_check_loaded. */
+pcv_status pcv_model_create_from_dir(pcv_ctx* ctx, const char* model_dir, int compute, int load_weights, pcv_model** out);
+/* What pcv_model_create_from_dir would build, from the directory's JSON files alone (needs no GPU): the model
+ * description, the transformer family (0 BERT, 1 DistilBERT, 2 RoBERTa) and the tokenizer options
+ * (strip_accents: -1 = follow lower_case).  Any output pointer may be NULL. */
+pcv_status pcv_model_dir_describe(const char* model_dir, pcv_model_desc* out_desc, int* out_arch, int* out_lower_case,
+                                  int* out_strip_accents);
+/* One checkpoint tensor under its Hugging Face / rust-bert name ("bert.encoder.layer.0...", DistilBERT and
+ * RoBERTa names included: they are mapped onto the encoder graph, the RoBERTa position table is shifted);
+ * names the graph does not use are ignored.  `data`: numel f32, row-major. */
+pcv_status pcv_model_load_hf_tensor(pcv_model* m, const char* hf_name, const float* data, int64_t numel);
+/* PCV_ERR_IO naming a missing tensor unless every tensor of the graph has been provided. */
+pcv_status pcv_model_check_loaded(pcv_model* m);
+/* Give a model built by pcv_model_create its tokenizer (Model::tokenizer, model.rs:61).  take_ownership != 0:
+ * the model destroys it. */
+pcv_status pcv_model_set_tokenizer(pcv_model* m, pcv_tokenizer* t, int take_ownership);
+/* The model's tokenizer (NULL if none); still owned as before. */
+pcv_status pcv_model_tokenizer(pcv_model* m, pcv_tokenizer** out_tok);
+/* The description the model was built from and the pad id its token tensors use (tokenize.rs:19). */
+pcv_status pcv_model_get_desc(pcv_model* m, pcv_model_desc* out_desc, int64_t* out_pad_id);
+
+/* Model::encode(&[S]) (model.rs:176-179): tokenize (encode_list, max_seq_length, LongestFirst; host threads),
+ * pad to the batch maximum, forward.  texts[i] = n_bytes[i] bytes of UTF-8.  out: [n_texts][output_dim] f32. */
+pcv_status pcv_model_encode_text(pcv_model* m, const char* const* texts, const size_t* n_bytes, int n_texts, float* out);
+
+/* Model::highlight (model/highlight.rs:23-165): for every document the text of the chunk whose embedding has
+ * the largest dot product with the query's.  Documents are tokenized without truncation, cut into chunks of
+ * `chunk_size` tokens overlapping by `chunk_overlap` (<= 0 / < 0: the CHUNK_SIZE / CHUNK_OVERLAP environment
+ * variables, defaults 20 / 4, highlight.rs:7-18), all chunks are encoded in batches and scored on the device.
+ *   out_begin/out_end [n_docs]  byte range of the highlight inside docs[i];
+ *                               -1/-1 = None (no chunk: the document is too short), begin == end = Some(""). */
+pcv_status pcv_model_highlight(pcv_model* m, const char* query, size_t query_bytes, const char* const* docs, const size_t* doc_bytes,
+                               int n_docs, int chunk_size, int chunk_overlap, int64_t* out_begin, int64_t* out_end);
+
 /* ---- Tokenizer (model/tokenize.rs:60-77; rust_tokenizers BertTokenizer) -------------------------
  * Host code, like the reference's tokenizer: BERT BasicTokenizer (clean text, CJK spacing, lower-casing,
  * accent stripping, punctuation split) + greedy WordPiece over `vocab.txt` (one token per line, id =
  * line number).  Needs no GPU. */
-typedef struct pcv_tokenizer pcv_tokenizer;
-
 /* TokenizerOption::from_file (model.rs:96-113).  strip_accents < 0: follow lower_case (the default of
  * rust_tokenizers / HF when tokenizer_config.strip_accents is absent). */
 pcv_status pcv_tokenizer_create(const char* vocab_path, int lower_case, int strip_accents, pcv_tokenizer** out);

@@ -132,6 +132,17 @@ SYMBOLS = {
     "pcv_model_encode_tokens_device": (C.c_int, [_P, _I64P, _I64P, C.c_int, C.c_int, _P, C.c_int]),
     "pcv_model_debug_hidden": (C.c_int, [_P, C.c_int, _F32P, C.c_int64]),
     "pcv_model_last_stats": (C.c_int, [_P, C.POINTER(EncodeStats)]),
+    "pcv_model_type_dir_name": (C.c_char_p, [C.c_int]),
+    "pcv_model_create_from_dir": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "pcv_model_dir_describe": (C.c_int, [C.c_char_p, C.POINTER(ModelDesc), _INTP, _INTP, _INTP]),
+    "pcv_model_load_hf_tensor": (C.c_int, [_P, C.c_char_p, _F32P, C.c_int64]),
+    "pcv_model_check_loaded": (C.c_int, [_P]),
+    "pcv_model_set_tokenizer": (C.c_int, [_P, _P, C.c_int]),
+    "pcv_model_tokenizer": (C.c_int, [_P, C.POINTER(_P)]),
+    "pcv_model_get_desc": (C.c_int, [_P, C.POINTER(ModelDesc), _I64P]),
+    "pcv_model_encode_text": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, _F32P]),
+    "pcv_model_highlight": (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
+                                      C.c_int, _I64P, _I64P]),
     "pcv_tokenizer_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "pcv_tokenizer_create_bpe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_P)]),
     "pcv_tokenizer_destroy": (C.c_int, [_P]),

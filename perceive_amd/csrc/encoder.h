@@ -52,6 +52,12 @@ void launch_pool(hipStream_t st, const float* hidden, const float* mask01, int B
 void launch_dense(hipStream_t st, const float* x, const float* W, const float* b, int B, int in, int out, int act,
                   int normalize, float* y);
 
+// highlight.rs:109-127 on the device: score of chunk c = dot(query, chunks[c]) in f32 (lib.rs:63-65); per
+// document d the LAST best-scoring chunk of [bounds[d], bounds[d+1]) goes to best[d] (-1: no chunk;
+// itertools' position_max_by keeps the last maximum), nan_flag[d] != 0 if one of its scores is NaN.
+void launch_chunk_argmax(hipStream_t st, const float* query, const float* chunks, int D, const int32_t* bounds, int n_docs,
+                         int32_t* best, int32_t* nan_flag);
+
 void launch_synth_weights(hipStream_t st, float* dst, int64_t n, uint64_t seed, uint32_t tensor_index, float scale,
                           float offset);
 

@@ -1595,4 +1595,61 @@ void launch_synth_weights(hipStream_t st, float* dst, int64_t n, uint64_t seed, 
     synth_weights_kernel<<<(unsigned)((n / 4 + 256) / 256), 256, 0, st>>>(dst, n, seed, tensor_index, scale, offset);
 }
 
+
+namespace {
+// One workgroup per document; each wave takes every fourth chunk, the 64 lanes share a chunk's dot product.
+__global__ __launch_bounds__(256) void chunk_argmax_kernel(const float* __restrict__ query, const float* __restrict__ chunks, int D,
+                                                           const int32_t* __restrict__ bounds, int32_t* __restrict__ best,
+                                                           int32_t* __restrict__ nan_flag) {
+    extern __shared__ float sqv[];  // [D]
+    __shared__ float w_s[4];
+    __shared__ int32_t w_c[4];
+    __shared__ int32_t w_nan[4];
+    const int doc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < D; i += 256) sqv[i] = query[i];
+    __syncthreads();
+    const int c0 = bounds[doc], c1 = bounds[doc + 1];
+    float bs = -__builtin_inff();
+    int bc = -1, nan = 0;
+    for (int c = c0 + wave; c < c1; c += 4) {
+        const float* x = chunks + (size_t)c * D;
+        float part = 0.0f;
+        for (int i = lane; i < D; i += 64) part = fmaf(sqv[i], x[i], part);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (!(part == part)) nan = 1;
+        if (bc < 0 || part >= bs) {  // chunks come in ascending order: >= keeps the last of equal maxima
+            bs = part;
+            bc = c;
+        }
+    }
+    if (lane == 0) {
+        w_s[wave] = bs;
+        w_c[wave] = bc;
+        w_nan[wave] = nan;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.0f;
+        int c = -1, f = 0;
+        for (int w = 0; w < 4; ++w) {
+            f |= w_nan[w];
+            if (w_c[w] < 0) continue;
+            if (c < 0 || w_s[w] > s || (w_s[w] == s && w_c[w] > c)) {
+                s = w_s[w];
+                c = w_c[w];
+            }
+        }
+        best[doc] = c;
+        nan_flag[doc] = f;
+    }
+}
+}  // namespace
+
+void launch_chunk_argmax(hipStream_t st, const float* query, const float* chunks, int D, const int32_t* bounds, int n_docs,
+                         int32_t* best, int32_t* nan_flag) {
+    if (n_docs <= 0) return;
+    chunk_argmax_kernel<<<n_docs, 256, (size_t)D * sizeof(float), st>>>(query, chunks, D, bounds, best, nan_flag);
+}
+
 }  // namespace pcv

@@ -12,57 +12,9 @@
 
 #include "common.h"
 #include "encoder.h"
+#include "model_internal.h"
 
 using namespace pcv;
-
-namespace {
-
-struct Tensor {
-    float* p = nullptr;
-    int64_t n = 0;
-};
-
-struct Planes {  // hi / mid / lo bf16 terms (PCV_COMPUTE_BF16X3) or hi / lo f16 terms of 2^8 * W (PCV_COMPUTE_F16X2)
-    uint16_t* p[3] = {nullptr, nullptr, nullptr};
-};
-
-struct Layer {
-    Tensor qkv_w, qkv_b;  // fused [3H][H], [3H]: rows 0..H = query, H..2H = key, 2H..3H = value
-    Tensor ao_w, ao_b, ln1_w, ln1_b;
-    Tensor i_w, i_b, f_w, f_b, ln2_w, ln2_b;
-    Planes qkv_p, ao_p, i_p, f_p;
-};
-
-}  // namespace
-
-struct pcv_model {
-    pcv_ctx* ctx = nullptr;
-    pcv_model_desc d{};
-    Tensor word, pos, type, eln_w, eln_b, dense_w, dense_b;
-    std::vector<Layer> layers;
-    // name -> (device pointer, element count): HF / rust-bert tensor names
-    std::map<std::string, Tensor> table;
-    std::vector<float*> owned;
-    std::vector<void*> owned_planes;
-    bool planes_dirty = true;  // weights changed since the bf16 planes were derived
-    std::mutex mu;
-    pcv_encode_stats stats{};
-
-    // workspace, grown on demand: capacities in tokens (B*L), padded tokens (B*roundup32(L)) and batch rows
-    int64_t cap_tokens = 0, cap_padded = 0, cap_batch = 0;
-    int64_t* d_ids = nullptr;
-    int64_t* d_mask = nullptr;
-    float *hidden = nullptr, *qkv = nullptr, *ctxbuf = nullptr, *tmp = nullptr, *ff = nullptr;
-    float *mask_add = nullptr, *mask01 = nullptr, *pooled = nullptr, *out = nullptr;
-    float* dbg = nullptr;  // [(layers+1)][T][H] of the last encode when it is small
-    int64_t dbg_tokens = 0;
-    int last_B = 0, last_L = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // hipGraph replay of small forwards, keyed by (B, L)
-    std::map<std::pair<int, int>, hipGraphExec_t> graphs;
-    std::map<std::pair<int, int>, int> shape_seen;
-    bool use_graphs = true;
-};
 
 namespace {
 
@@ -413,6 +365,21 @@ void finish_stats(pcv_model* m) {
 
 }  // namespace
 
+namespace pcv {
+void model_check_tokens(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L) { check_tokens(m, ids, mask, B, L); }
+void model_forward(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L) { forward(m, ids, mask, B, L); }
+void model_finish_stats(pcv_model* m) { finish_stats(m); }
+void model_check_f16_output(pcv_model* m, const float* out, size_t n) {
+    if (m->d.compute != PCV_COMPUTE_F16X2) return;
+    // the one way this mode can fail silently: an activation beyond f16's (rescaled) range turns into inf
+    // and the embedding into NaN.  The f32 path would have produced numbers, so say so instead.
+    for (size_t e = 0; e < n; ++e)
+        if (!std::isfinite(out[e]))
+            PCV_FAIL(PCV_ERR_UNSUPPORTED, "PCV_COMPUTE_F16X2: non-finite embedding (activation outside the f16 range?); "
+                                          "use PCV_COMPUTE_F32 or PCV_COMPUTE_BF16X3 for this model");
+}
+}  // namespace pcv
+
 extern "C" {
 
 void pcv_model_desc_minilm_l6(pcv_model_desc* d) {
@@ -484,8 +451,11 @@ pcv_status pcv_model_destroy(pcv_model* m) {
         free_workspace(m);
         for (float* p : m->owned) hipFree(p);
         for (void* p : m->owned_planes) hipFree(p);
-        if (m->ev0) hipEventDestroy(m->ev0);
-        if (m->ev1) hipEventDestroy(m->ev1);
+        if (m->ev0) (void)hipEventDestroy(m->ev0);
+        if (m->ev1) (void)hipEventDestroy(m->ev1);
+        for (void* p : {(void*)m->hl_emb, (void*)m->hl_query, (void*)m->hl_bounds, (void*)m->hl_best})
+            if (p) (void)hipFree(p);
+        if (m->tok && m->own_tok) pcv_tokenizer_destroy(m->tok);
         delete m;
     });
 }
@@ -540,14 +510,7 @@ pcv_status pcv_model_encode_tokens(pcv_model* m, const int64_t* ids, const int64
         PCV_HIP(hipStreamSynchronize(m->ctx->stream));
         PCV_HIP(hipGetLastError());
         finish_stats(m);
-        if (m->d.compute == PCV_COMPUTE_F16X2) {
-            // the one way this mode can fail silently: an activation beyond f16's (rescaled) range turns into inf
-            // and the embedding into NaN.  The f32 path would have produced numbers, so say so instead.
-            for (size_t e = 0; e < (size_t)B * OD; ++e)
-                if (!std::isfinite(out[e]))
-                    PCV_FAIL(PCV_ERR_UNSUPPORTED, "PCV_COMPUTE_F16X2: non-finite embedding (activation outside the f16 range?); "
-                                                  "use PCV_COMPUTE_F32 or PCV_COMPUTE_BF16X3 for this model");
-        }
+        model_check_f16_output(m, out, (size_t)B * OD);
     });
 }
 

@@ -383,9 +383,6 @@ __global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __rest
     __builtin_amdgcn_sched_barrier(0);
 
     for (int i = tid; i < QG * kMaxK; i += 256) gmax[i] = kKeyNegInf;
-#ifdef PCV_DIAG
-    if (!(p.flags & 0x40))
-#endif
     {
         // all QG queries at once: LPQ lanes per query, each with every LPQ-th element, loads issued eight at a
         // time (one query per wave after the other cost ~10 us each in dependent round trips)
@@ -455,9 +452,6 @@ __global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __rest
     float acc[QG];
 #pragma unroll
     for (int g = 0; g < QG; ++g) acc[g] = 0.0f;
-#ifdef PCV_DIAG
-    if (!(p.flags & 0x20))
-#endif
     for (int f0 = 0; f0 < p.D4; f0 += 16) {  // D4 is a multiple of 16
         if (f0 > 0) {
 #pragma unroll
@@ -484,9 +478,6 @@ __global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __rest
         }
     }
     __syncthreads();
-#ifdef PCV_DIAG
-    if (!(p.flags & 0x10))
-#endif
     for (int i = tid; i < QG * p.k; i += 256) {
         const int g = i / p.k, j = i - g * p.k, q = q0 + g;
         const uint32_t key = gmax[g * kMaxK + j];
@@ -1025,9 +1016,6 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
     }
     __syncthreads();
     const float thr_final = key_f32(max(s_tau0, ld_relaxed(&p.tau[q * kHot]))) - p.margin32[q];
-#ifdef PCV_DIAG
-    if (!(p.flags & 0x100))
-#endif
     if (tid == 255) {  // canonical |q|^2: f64, feature order (the other waves go on to the filter meanwhile)
         double nq = 0.0;
         const float* f = (const float*)sq;
@@ -1061,9 +1049,6 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
         for (uint32_t j = 0; j < nv; ++j) rank += better(c_s[j], c_p[j], s, pos) ? 1 : 0;
         return rank;
     };
-#ifdef PCV_DIAG
-    if (!(p.flags & 0x80))
-#endif
     for (uint32_t base = 0; base < cnt; base += 1024) {
         if (n_valid + 1024u > (uint32_t)kSelCap) {  // same value in every thread: read after a barrier
             const uint32_t nv = n_valid;

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tokenizer.h"
 #include "unicode_tables.h"
 
 using namespace pcv;
@@ -154,11 +155,7 @@ struct Cp {
     uint32_t cp;
     int32_t pos;  // index of the originating char in the input text
 };
-struct Piece {
-    int64_t id;
-    int32_t begin, end;
-    uint8_t special;
-};
+using Piece = pcv::TokPiece;
 
 }  // namespace
 
@@ -676,3 +673,8 @@ pcv_status pcv_tokenizer_encode_batch(pcv_tokenizer* t, const char* const* texts
 }
 
 }  // extern "C"
+
+namespace pcv {
+std::vector<TokPiece> tokenizer_pieces(const pcv_tokenizer* t, const char* text, size_t n_bytes) { return t->tokenize(text, n_bytes); }
+TokSpecials tokenizer_specials(const pcv_tokenizer* t) { return TokSpecials{t->pad, t->unk, t->cls, t->sep}; }
+}  // namespace pcv

@@ -1,10 +1,9 @@
 """Host-side mirror of perceive-core's model module (crates/perceive-core/model.rs,
-model/{configs,tokenize,worker}.rs) over the C ABI.
+model/{configs,tokenize,worker,highlight}.rs) over the C ABI.
 
-`Model.encode_tokens` is the hot path (worker.rs:78-106) and runs on the GPU.  The WordPiece
-tokenizer (rust_tokenizers) and the pretrained checkpoints are not available offline, so a Model is
-built from a description + a flat weight file or seeded synthetic weights; `generate_token_tensors`
-restates the padding/mask layout of tokenize.rs:9-57 for callers that bring their own token ids.
+Everything with logic in it lives in the library: `encode_tokens` (worker.rs:78-106, the device forward),
+`encode` (tokenize + forward, pcv_model_encode_text), `highlight` (pcv_model_highlight) and
+`Model.from_dir` (Model::new_pretrained, pcv_model_create_from_dir).  This module converts arguments.
 """
 import ctypes as C
 import enum
@@ -86,13 +85,6 @@ def save_weights(path, tensors):
             f.write(a.tobytes())
 
 
-def _env_usize(name, default):
-    try:
-        return int(os.environ.get(name, ""))  # highlight.rs:9-17: unparsable / unset -> default
-    except ValueError:
-        return default
-
-
 class Model:
     """model.rs:56-65.  `model_type` is kept as the pub field it is in the reference."""
 
@@ -109,6 +101,48 @@ class Model:
         wp = weights_path.encode() if weights_path else None
         _ffi.check(_ffi.lib().pcv_model_create(ctx.handle, C.byref(self.desc), wp, int(synthetic_seed), C.byref(self._h)))
         ctx._register(self)
+        if tokenizer is not None:  # Model::tokenizer (model.rs:61): the library tokenizes for encode / highlight
+            _ffi.check(_ffi.lib().pcv_model_set_tokenizer(self._h, tokenizer._h, 0))
+
+    @classmethod
+    def from_dir(cls, ctx, directory, compute="f32", model_type=None, load_weights=True):
+        """Model::new_pretrained (model.rs:68-174) from a sentence-transformers model directory
+        (pcv_model_create_from_dir).  load_weights=False: the caller hands the checkpoint tensors to
+        `load_hf_tensor` and then calls `check_loaded` (formats other than model.safetensors)."""
+        from .tokenizer import BertTokenizer
+
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.model_type = model_type if model_type is not None else SentenceEmbeddingsModelType.AllMiniLmL6V2
+        self._h = C.c_void_p()
+        try:
+            _ffi.check(_ffi.lib().pcv_model_create_from_dir(ctx.handle, str(directory).encode(), _COMPUTE[compute],
+                                                            1 if load_weights else 0, C.byref(self._h)))
+        except _ffi.PcvError as e:
+            raise ModelError(str(e)) from e
+        ctx._register(self)
+        self.desc = _ffi.ModelDesc()
+        pad = C.c_int64()
+        _ffi.check(_ffi.lib().pcv_model_get_desc(self._h, C.byref(self.desc), C.byref(pad)))
+        self.pad_token_id = pad.value
+        th = C.c_void_p()
+        _ffi.check(_ffi.lib().pcv_model_tokenizer(self._h, C.byref(th)))
+        self.tokenizer = BertTokenizer._borrowed(th.value)  # owned by the model handle
+        return self
+
+    def load_hf_tensor(self, name, array):
+        """One checkpoint tensor under its Hugging Face / rust-bert name (pcv_model_load_hf_tensor)."""
+        a = np.ascontiguousarray(array, dtype=np.float32).reshape(-1)
+        try:
+            _ffi.check(_ffi.lib().pcv_model_load_hf_tensor(self._handle, name.encode(), _ffi.f32p(a), a.size))
+        except _ffi.PcvError as e:
+            raise ModelError(str(e)) from e
+
+    def check_loaded(self):
+        try:
+            _ffi.check(_ffi.lib().pcv_model_check_loaded(self._handle))
+        except _ffi.PcvError as e:
+            raise ModelError(str(e)) from e
 
     @property
     def output_dim(self):
@@ -160,86 +194,41 @@ class Model:
         enc = self.tokenizer.encode_list(inputs, self.desc.max_seq_length)
         return self.generate_token_tensors([e.token_ids for e in enc])
 
+    @staticmethod
+    def _c_strings(texts):
+        raw = [t.encode("utf-8") for t in texts]
+        n = len(raw)
+        return raw, (C.c_char_p * max(n, 1))(*raw), (C.c_size_t * max(n, 1))(*[len(b) for b in raw])
+
     def encode(self, inputs):
-        """Model::encode (model.rs:176-179)."""
-        ids, mask = self.tokenize(inputs)
-        return self.encode_tokens(ids, mask)
+        """Model::encode (model.rs:176-179): tokenize + forward in the library (pcv_model_encode_text)."""
+        inputs = list(inputs)
+        out = np.empty((len(inputs), self.output_dim), dtype=np.float32)
+        if not inputs:
+            return out
+        raw, arr, nb = self._c_strings(inputs)
+        try:
+            _ffi.check(_ffi.lib().pcv_model_encode_text(self._handle, arr, nb, len(raw), _ffi.f32p(out)))
+        except _ffi.PcvError as e:
+            raise ModelError(str(e)) from e
+        return out
 
-    def highlight(self, query, documents):
-        """Model::highlight (highlight.rs:23-165): for each document the text chunk whose embedding has
-        the largest dot product with the query's.  Chunks of CHUNK_SIZE tokens overlapping by
-        CHUNK_OVERLAP (env, defaults 20 / 4, highlight.rs:7-18).  Restated line by line, including
-        the reference's boundary quirks (a chunk's longest non-special run starts AT the special
-        token that precedes it; the returned slice runs one char past the last token, and is empty
-        when that char does not exist)."""
-        from .search import dot_product
-
-        if self.tokenizer is None:
-            raise ModelError("highlight needs a tokenizer")
+    def highlight(self, query, documents, chunk_size=0, chunk_overlap=-1):
+        """Model::highlight (highlight.rs:23-165), computed by pcv_model_highlight: for each document the text
+        of the chunk that matches the query best, None when the document is too short for a chunk.
+        chunk_size / chunk_overlap default to the CHUNK_SIZE / CHUNK_OVERLAP environment (20 / 4)."""
         documents = list(documents)
-        query_encoding = self.encode([query])                                          # highlight.rs:29
-        tokenized_docs = self.tokenizer.encode_list(documents, 1_000_000)              # highlight.rs:32-38
-        chunk_size = _env_usize("CHUNK_SIZE", 20)
-        chunk_overlap = _env_usize("CHUNK_OVERLAP", 4)
-        chunk_index_inc = chunk_size - chunk_overlap                                   # highlight.rs:43
-        token_chunks, token_chunk_boundaries, document_chunk_boundaries = [], [], []
-        for tokens in tokenized_docs:                                                  # highlight.rs:53-100
-            n = len(tokens.token_ids)
-            i = 0
-            while i + chunk_overlap < n:
-                start_index = i
-                end_index = min(i + chunk_size, n)
-                longest_start = longest_length = current_start = current_length = 0
-                for index, is_special in enumerate(tokens.special_tokens_mask[start_index:end_index]):
-                    if is_special == 0:
-                        current_length += 1
-                    else:
-                        if current_length > longest_length:
-                            longest_start, longest_length = current_start, current_length
-                        current_start, current_length = index, 0
-                if current_length > longest_length:
-                    longest_start, longest_length = current_start, current_length
-                start_index = start_index + longest_start
-                end_index = min(start_index + longest_length, end_index)
-                if end_index - start_index >= chunk_size // 2:
-                    token_chunk_boundaries.append((start_index, end_index))
-                    token_chunks.append(tokens.token_ids[start_index:end_index])
-                i += chunk_index_inc
-            document_chunk_boundaries.append(len(token_chunks))
-        if token_chunks:                                                               # highlight.rs:102-111
-            ids, mask = self.generate_token_tensors(token_chunks)
-            docs_encoding = self.encode_tokens(ids, mask)
-            scores = dot_product(self.ctx, query_encoding, docs_encoding)[0]
-        else:
-            scores = np.zeros(0, np.float32)
-        highlights = []
-        for index, overall_chunk_end in enumerate(document_chunk_boundaries):          # highlight.rs:114-162
-            overall_chunk_start = 0 if index == 0 else document_chunk_boundaries[index - 1]
-            doc_scores = scores[overall_chunk_start:overall_chunk_end]
-            if doc_scores.size == 0:
-                highlights.append(None)
-                continue
-            if np.isnan(doc_scores).any():
-                raise ModelError("NaN chunk score (the reference unwraps partial_cmp and panics)")
-            mx = doc_scores.max()
-            best = int(np.nonzero(doc_scores == mx)[0][-1])  # itertools position_max_by: last of equal maxima
-            lo, hi = token_chunk_boundaries[overall_chunk_start + best]
-            text_start = text_end = 0
-            for off in tokenized_docs[index].token_offsets[lo:hi]:
-                if off is None:
-                    continue
-                if text_start == 0 and text_end == 0:
-                    text_start, text_end = off
-                else:
-                    text_start, text_end = min(text_start, off[0]), max(text_end, off[1])
-            doc = documents[index]
-            # char_indices().nth(text_start), then .nth(text_end - text_start) on the same iterator
-            # -> chars text_start and text_end + 1 must both exist (highlight.rs:150-158)
-            if text_start < len(doc) and text_end + 1 < len(doc):
-                highlights.append(doc[text_start:text_end + 1])
-            else:
-                highlights.append("")
-        return highlights
+        raw, arr, nb = self._c_strings(documents)
+        n = len(documents)
+        begin = np.full(max(n, 1), -1, dtype=np.int64)
+        end = np.full(max(n, 1), -1, dtype=np.int64)
+        q = query.encode("utf-8")
+        try:
+            _ffi.check(_ffi.lib().pcv_model_highlight(self._handle, q, len(q), arr, nb, n, int(chunk_size), int(chunk_overlap),
+                                                      _ffi.i64p(begin), _ffi.i64p(end)))
+        except _ffi.PcvError as e:
+            raise ModelError(str(e)) from e
+        return [None if begin[i] < 0 else raw[i][begin[i]:end[i]].decode("utf-8") for i in range(n)]
 
     # ---- weights / diagnostics ----------------------------------------------------------------
     def get_tensor(self, name):

@@ -29,6 +29,17 @@ class BertTokenizer:
         _ffi.check(_ffi.lib().pcv_tokenizer_special_ids(self._h, *[C.byref(x) for x in ids]))
         self.pad_id, self.unk_id, self.cls_id, self.sep_id = [x.value for x in ids]
 
+    @classmethod
+    def _borrowed(cls, handle):
+        """A view of a tokenizer some other handle owns (a Model built from a directory): never destroyed here."""
+        t = cls.__new__(cls)
+        t._h = C.c_void_p(handle)
+        t._borrowed_handle = True
+        ids = [C.c_int64() for _ in range(4)]
+        _ffi.check(_ffi.lib().pcv_tokenizer_special_ids(t._h, *[C.byref(x) for x in ids]))
+        t.pad_id, t.unk_id, t.cls_id, t.sep_id = [x.value for x in ids]
+        return t
+
     def get_pad_id(self):
         """tokenize.rs:19: `self.tokenizer.get_pad_id().unwrap_or(0)` at the call site."""
         return self.pad_id if self.pad_id >= 0 else None
@@ -81,7 +92,8 @@ class BertTokenizer:
 
     def close(self):
         if self._h:
-            _ffi.lib().pcv_tokenizer_destroy(self._h)
+            if not getattr(self, "_borrowed_handle", False):
+                _ffi.lib().pcv_tokenizer_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -66,3 +66,38 @@ def test_highlight_matches_oracle(setup, oracle):
         assert got8 == exp8 and got8[4] is None
     finally:
         del os.environ["CHUNK_SIZE"], os.environ["CHUNK_OVERLAP"]
+    # the same through explicit arguments, and a Unicode document: offsets are chars, the returned range is bytes
+    assert m.highlight("tokyo cafe", DOCS, chunk_size=8, chunk_overlap=2) == exp8
+    uni = ["Ünïcödé çafé in Tōkyō — how good is the search model — " + "people work each day and years go on. " * 6 + "naïve café",
+           "Ünïcödé çafé in Tōkyō — " + "people work each day and the search model is good " * 3 + "naïve café"]
+    got_u = m.highlight("how good is the search model", uni)
+    exp_u, _ = oracle_highlight.highlight(oracle, desc, m.state_dict(), vocab, 64, "how good is the search model", uni)
+    assert got_u == exp_u and all(g in d for g, d in zip(got_u, uni))
+    assert any("ï" in g or "ō" in g or "—" in g for g in got_u), got_u  # a range that crosses multi-byte chars
+    with pytest.raises(pa.ModelError):
+        m.highlight("q", DOCS, chunk_size=4, chunk_overlap=4)
+
+
+def test_highlight_many_documents_batches(setup, oracle):
+    # more chunks than one forward takes (2048): several batches, same answer per document as alone
+    m, desc, vocab = setup
+    docs = [DOCS[1] + " " + DOCS[2] * (1 + i % 3) for i in range(120)] + [DOCS[0]] * 80
+    got = m.highlight("where did the work come from", docs)
+    assert len(got) == 200 and all(g for g in got)
+    for i in (0, 1, 2, 119, 120, 199):
+        assert got[i] == m.highlight("where did the work come from", [docs[i]])[0]
+
+
+def test_encode_text_large_batch_and_errors(setup, oracle):
+    m, desc, vocab = setup
+    texts = [f"document number {i} about the search of embeddings" for i in range(1500)]  # two forwards of <= 1024
+    out = m.encode(texts)
+    assert out.shape == (1500, 128)
+    np.testing.assert_allclose(out[1234], m.encode([texts[1234]])[0], atol=2e-6)
+    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+    assert m.encode([]).shape == (0, 128)
+    bare = pa.Model(m.ctx, pa.make_desc(desc["vocab"], 128, 1, 4, 256, 64), synthetic_seed=1)
+    with pytest.raises(pa.ModelError) as e:
+        bare.encode(["no tokenizer"])
+    assert "tokenizer" in str(e.value)
+    bare.close()
