@@ -124,6 +124,17 @@ pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id);
 /* Pack pending rows into the HBM layout, compute row norms (set_searching_mode, search.rs:150). */
 pcv_status pcv_searcher_finalize(pcv_searcher* s);
 
+/* Searcher::build (search.rs:38-56) / rebuild_source (search.rs:58-79) straight from the reference's SQLite
+ * file: runs `SELECT id FROM sources` and the items / item_embeddings join of search.rs:87-93 for
+ * (model_id, model_version) — rows with `skipped` or `hidden_at` set never enter the index — streams the
+ * embedding blobs into the device (one segment per source, sized from a COUNT), and finalizes.
+ *   only_source   NULL: every source of the database; else that source is cleared and reloaded
+ *   out_rows      rows loaded (may be NULL)
+ * SQLite is bound at run time (libsqlite3.so.0); PCV_ERR_UNSUPPORTED if it is not installed. */
+pcv_status pcv_searcher_load_sqlite(pcv_searcher* s, const char* db_path, uint32_t model_id, uint32_t model_version,
+                                    const int64_t* only_source, int64_t* out_rows);
+
+pcv_status pcv_searcher_dim(pcv_searcher* s, int* out_dim);
 pcv_status pcv_searcher_num_rows(pcv_searcher* s, int64_t* out_rows);
 /* Device segments the rows currently occupy (diagnostics: adds append in place while a segment has room). */
 pcv_status pcv_searcher_num_segments(pcv_searcher* s, int* out_n);

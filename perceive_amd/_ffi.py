@@ -100,6 +100,8 @@ SYMBOLS = {
     "pcv_searcher_add_synthetic_clustered": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_float]),
     "pcv_searcher_clear_source": (C.c_int, [_P, C.c_int64]),
     "pcv_searcher_finalize": (C.c_int, [_P]),
+    "pcv_searcher_load_sqlite": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint32, _I64P, _I64P]),
+    "pcv_searcher_dim": (C.c_int, [_P, _INTP]),
     "pcv_searcher_num_rows": (C.c_int, [_P, _I64P]),
     "pcv_searcher_num_sources": (C.c_int, [_P, _INTP]),
     "pcv_searcher_source_ids": (C.c_int, [_P, _I64P, C.c_int]),

@@ -748,6 +748,13 @@ pcv_status pcv_searcher_finalize(pcv_searcher* s) {
     });
 }
 
+pcv_status pcv_searcher_dim(pcv_searcher* s, int* out_dim) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && out_dim != nullptr, "searcher_dim: NULL argument");
+        *out_dim = s->D;
+    });
+}
+
 pcv_status pcv_searcher_num_rows(pcv_searcher* s, int64_t* out_rows) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr && out_rows != nullptr, "num_rows: NULL argument");

@@ -41,12 +41,14 @@ class Database:
     """db.rs:43-59 reduced to a read connection."""
 
     def __init__(self, path):
+        self.path = None if path == ":memory:" else str(path)
         self.conn = sqlite3.connect(f"file:{path}?mode=ro", uri=True) if path != ":memory:" else sqlite3.connect(path)
 
     @classmethod
     def from_connection(cls, conn):
         d = cls.__new__(cls)
         d.conn = conn
+        d.path = None  # no file the library could open itself: rows are streamed from this connection
         return d
 
 
@@ -87,6 +89,19 @@ def _load(searcher, conn, model_id, model_version, sources):
         flush(source_id)
 
 
+def _load_sqlite(searcher, path, model_id, model_version, only_source):
+    """build_sources (search.rs:81-155) inside the library: SQL, blob streaming, finalize."""
+    import ctypes as C
+
+    from . import _ffi
+
+    src = None if only_source is None else np.array([only_source], dtype=np.int64)
+    n = C.c_int64()
+    _ffi.check(_ffi.lib().pcv_searcher_load_sqlite(searcher._handle, str(path).encode(), int(model_id), int(model_version),
+                                                   None if src is None else _ffi.i64p(src), C.byref(n)))
+    return n.value
+
+
 def build_searcher(ctx, database, model_id, model_version, metric="dot", dim=None):
     """Searcher::build(database, model_id, model_version) — search.rs:38-56."""
     conn = database.conn
@@ -95,6 +110,9 @@ def build_searcher(ctx, database, model_id, model_version, metric="dot", dim=Non
     if dim is None:
         raise ValueError("no embeddings stored for this model version; pass dim= to build an empty index")
     s = Searcher(ctx, dim, metric)
+    if database.path is not None:  # the library reads the file itself (pcv_searcher_load_sqlite)
+        _load_sqlite(s, database.path, model_id, model_version, None)
+        return s
     _load(s, conn, model_id, model_version, sources)
     s.finalize()
     return s
@@ -104,6 +122,9 @@ def rebuild_source(searcher, database, source_id, model_id, model_version):
     """Searcher::rebuild_source — search.rs:58-79."""
     from . import _ffi
 
+    if database.path is not None:
+        _load_sqlite(searcher, database.path, model_id, model_version, int(source_id))
+        return
     _ffi.check(_ffi.lib().pcv_searcher_clear_source(searcher._handle, int(source_id)))
     _load(searcher, database.conn, model_id, model_version, [source_id])
     searcher.finalize()
