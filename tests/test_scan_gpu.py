@@ -372,7 +372,7 @@ def test_streaming_ingest_keeps_host_memory_bounded(ctx):
     import sys
 
     code = (
-        "import sys, resource, numpy as np; sys.path.insert(0, %r); import perceive_amd as pa\n"
+        "import sys, re, numpy as np; sys.path.insert(0, %r); import perceive_amd as pa\n"
         "ctx = pa.Context(0); s = pa.Searcher(ctx, 384, 'cosine')\n"
         "rng = np.random.default_rng(1); chunk = rng.standard_normal((131072, 384)).astype(np.float32)\n"
         "blob = chunk.tobytes(); N = 20_000_000; done = 0\n"
@@ -383,7 +383,9 @@ def test_streaming_ingest_keeps_host_memory_bounded(ctx):
         "s.finalize()\n"
         "q = chunk[77:78] + 0.0\n"
         "ids, sc, cnt = s.search_vectors(None, 3, q)\n"
-        "print('RESULT', s.num_rows, s.num_segments, int(ids[0, 0]) %% 131072, float(sc[0, 0]), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)\n"
+        # peak RSS of THIS process image: VmHWM (ru_maxrss also carries the parent's peak across fork + exec)
+        "hwm = int(re.search(r'VmHWM:\\s+(\\d+) kB', open('/proc/self/status').read()).group(1))\n"
+        "print('RESULT', s.num_rows, s.num_segments, int(ids[0, 0]) %% 131072, float(sc[0, 0]), hwm)\n"
     ) % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-1500:]
