@@ -47,6 +47,28 @@ __device__ __forceinline__ void tile_of_block(int ncols, int& tile_m, int& tile_
     tile_n = (int)(logical % (unsigned)ncols);
 }
 
+// erf for the GELU epilogues: Abramowitz & Stegun 7.1.28, erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16 for
+// x >= 0, |error| <= 3e-7 — an error of <= 1e-6 in a GELU output, two orders below the f32 noise of the
+// 1536-term contraction that consumes it.  Branch-free, 14 VALU operations; erff() is ~30 with two divergent
+// paths, and VALU work in an epilogue is paid in matrix-pipe time (tools/ubench/coexec.hip): it was 15 % of the
+// FFN-up GEMM.
+__device__ __forceinline__ float erf_as(float x) {
+    const float t = fabsf(x);
+    float p = fmaf(t, 0.0000430638f, 0.0002765672f);
+    p = fmaf(t, p, 0.0001520143f);
+    p = fmaf(t, p, 0.0092705272f);
+    p = fmaf(t, p, 0.0422820123f);
+    p = fmaf(t, p, 0.0705230784f);
+    p = fmaf(t, p, 1.0f);
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;  // (..)^16; +inf for large |x|, whose reciprocal is 0
+    const float e = 1.0f - __builtin_amdgcn_rcpf(p);
+    return copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); }
+
 // Epilogue of the 128x128 GEMMs: one wave's 64x64 quarter (2x2 MFMA tiles) -> +bias (+GELU | +residual) ->
 // C.  Full quarters take a branch-free path.  With a per-element `if (row < M)` every element became its
 // own basic block, the waitcnt pass lost track of the bias load across them and put `s_waitcnt vmcnt(0)` in
@@ -75,7 +97,7 @@ __device__ __forceinline__ void store_quarter(const f32x16 (&acc)[2][2], const f
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[a][b][r] + bv[b];
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
                     if (EPI == EPI_BIAS_RESIDUAL) v += rv[a][b][r];
                     C[base0 + (size_t)(a * 32 + acc_row(r, 0)) * N + b * 32] = v;
                 }
@@ -91,12 +113,49 @@ __device__ __forceinline__ void store_quarter(const f32x16 (&acc)[2][2], const f
                 const int row = row0 + a * 32 + acc_row(r, h);
                 if (row < M) {
                     float v = acc[a][b][r] + bv[b];
-                    if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
                     if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
                     C[(size_t)row * N + col] = v;
                 }
             }
         }
+}
+
+// Epilogue of gemm_f32_kernel for a full 64x64 quarter: the accumulators (column on the lane, rows in the
+// registers) go through a per-wave LDS tile, half a quarter at a time, and come back row-major, so that bias,
+// residual and the output move as 16-byte accesses: 16 stores (and 16 residual loads) per lane instead of 64.
+constexpr int LDE = 68;  // floats per row of the [32][64] transpose tile: 16-lane ds_read_b128 groups cover a bank row
+template <int EPI>
+__device__ __forceinline__ void store_quarter_wide(const f32x16 (&acc)[2][2], const float* __restrict__ bias,
+                                                   const float* __restrict__ resid, float* __restrict__ C, int N, int row0,
+                                                   int col0, float* __restrict__ tile, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+    const int c4 = lane & 15, rq = lane >> 4;  // read side: float4 column, row = rq + 4*u
+    const f32x4 b4 = bias ? *(const f32x4*)(bias + col0 + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        f32x4 rv[8];
+        if (EPI == EPI_BIAS_RESIDUAL) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                rv[u] = *(const f32x4*)(resid + (size_t)(row0 + a * 32 + rq + 4 * u) * N + col0 + 4 * c4);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[acc_row(r, h) * LDE + b * 32 + i] = acc[a][b][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's tile is written (no other wave touches it)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            f32x4 v = *(const f32x4*)(tile + (rq + 4 * u) * LDE + 4 * c4) + b4;
+            if (EPI == EPI_BIAS_GELU) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+            if (EPI == EPI_BIAS_RESIDUAL) v += rv[u];
+            *(f32x4*)(C + (size_t)(row0 + a * 32 + rq + 4 * u) * N + col0 + 4 * c4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();  // the reads are issued before the next half overwrites the tile
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
 }
 
 // the bias values of a wave's two column tiles
@@ -110,8 +169,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ C, int M,
                                                        int N, int K) {
-    __shared__ float As[BM * LDT];
-    __shared__ float Ws[BN * LDT];
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];  // K-step tiles; the epilogue's transpose tiles after the loop
+    float* As = smem;
+    float* Ws = smem + BM * LDT;
+    static_assert(4 * 32 * LDE <= (BM + BN) * LDT, "epilogue tiles fit the staging buffers");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kk = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
@@ -185,6 +246,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
     }
 
+    if (m0 + BM <= M) {  // full tile (workgroup-uniform): wide epilogue through LDS
+        __syncthreads();  // every wave is done with the last K-step's fragments
+        store_quarter_wide<EPI>(acc, bias, resid, C, N, m0 + wr * 64, n0 + wc * 64, smem + wave * 32 * LDE, lane);
+        return;
+    }
     float bv[2];
     load_bias2(bias, n0 + wc * 64, i, bv);
     store_quarter<EPI>(acc, bv, resid, C, M, N, m0 + wr * 64, n0 + wc * 64, i, kk);
@@ -244,7 +310,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(const float* _
         const int row = 32 * t + acc_row(r, l >> 5), col = n0 + (l & 31);
         if (row < M) {
             v += bias ? bias[col] : 0.0f;
-            if (EPI == EPI_BIAS_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
             if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
             C[(size_t)row * N + col] = v;
         }
