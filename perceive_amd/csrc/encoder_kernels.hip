@@ -135,7 +135,7 @@ __device__ __forceinline__ void store_quarter_wide(const f32x16 (&acc)[2][2], co
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         f32x4 rv[8];
-        if (EPI == EPI_BIAS_RESIDUAL) {
+        if (EPI == EPI_BIAS_RESIDUAL) {  // in flight while the half tile goes through LDS
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 rv[u] = *(const f32x4*)(resid + (size_t)(row0 + a * 32 + rq + 4 * u) * N + col0 + 4 * c4);
@@ -165,7 +165,7 @@ __device__ __forceinline__ void load_bias2(const float* __restrict__ bias, int c
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ C, int M,
                                                        int N, int K) {

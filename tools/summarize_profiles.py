@@ -20,9 +20,10 @@ GO = os.path.join(ROOT, "gpurun_out")
 
 
 def newest(pattern):
-    """gpurun merges every call's files into gpurun_out/: keep only the latest run of a directory."""
-    files = sorted(glob.glob(pattern) + glob.glob(pattern.replace(os.sep + "*" + os.sep, os.sep + "*" + os.sep + "*" + os.sep)),
-                   key=os.path.getmtime)
+    """gpurun merges every call's files into gpurun_out/: keep only the latest run of a directory.  `pattern` is
+    <dir>/*/<file>; the file may also sit directly in <dir>."""
+    flat = pattern.replace(os.sep + "*" + os.sep, os.sep)
+    files = sorted(set(glob.glob(pattern)) | set(glob.glob(flat)), key=os.path.getmtime)
     return files[-1:]
 
 
@@ -51,6 +52,8 @@ def main():
         # (label, stats dir, fetch dir, write dir, kernel, rows, dim)
         ("100m_b64_mfma", "prof_default", "pmc_fetch", "pmc_write", "scan_mfma_kernel", 100_000_000, 384),
         ("10m_b1_wave", "prof_10m_b1", "pmc_fetch_10m_b1", "pmc_write_10m_b1", "scan_wave_kernel", 10_000_000, 384),
+        ("12p5m_b64_mfma", "prof_12p5m", None, None, "scan_mfma_kernel", 12_500_000, 384),
+        ("100m_b64_mfma_clustered", "prof_clustered", None, None, "scan_mfma_kernel", 100_000_000, 384),
     ]
     for c in ("f32", "bf16x3", "f16x2"):  # encoder forward per kernel
         for f in newest(os.path.join(GO, f"prof_enc_{c}", "*", "*_kernel_stats.csv")):
@@ -62,8 +65,14 @@ def main():
         fetch_kib, nf = pmc_mean(fdir, "FETCH_SIZE", kern) if fdir else (None, 0)
         write_kib, nw = pmc_mean(wdir, "WRITE_SIZE", kern) if wdir else (None, 0)
         alg = rows * dim * 4
+        fixed = {}
+        for f in newest(os.path.join(GO, sdir, "*", "*_kernel_stats.csv")):
+            for row in csv.DictReader(open(f)):
+                for k in ("upload_kernel", "prep_seed", "rescore_select"):
+                    if k in row["Name"]:
+                        fixed[k + "_avg_us"] = float(row["AverageNs"]) / 1e3
         entry = {
-            "kernel": kern, "rows": rows, "dim": dim, "algorithmic_bytes_per_launch": alg,
+            "kernel": kern, "rows": rows, "dim": dim, "algorithmic_bytes_per_launch": alg, "other_kernels_of_a_pass": fixed,
             "rocprof_avg_kernel_ms": ms, "rocprof_calls": calls,
             "achieved_GBps_from_rocprof": alg / (ms * 1e-3) / 1e9 if ms else None,
             "FETCH_SIZE_KiB_raw": fetch_kib, "FETCH_launches": nf,
@@ -85,6 +94,21 @@ def main():
         json.dump({e["kernel"]: {"bytes_per_row": e.get("traffic_bytes_per_row"), "dim": e["dim"],
                                  "source": f"profiles/{tag}_summary.json:{k}"}
                    for k, e in summary.items() if e.get("traffic_bytes_per_row")}, f, indent=1)
+    # encoder forward: per-kernel time per forward and TFLOP/s of the GEMM shapes (MiniLM-L6 shape, 256 x 256 tokens)
+    enc = {}
+    for c in ("f32", "bf16x3", "f16x2"):
+        for f in newest(os.path.join(GO, f"prof_enc_{c}", "*", "*_kernel_stats.csv")):
+            rows_ = list(csv.DictReader(open(f)))
+            fwd = 9  # bench_encode.py --steps 7 --warmup 2
+            tot = sum(float(r["TotalDurationNs"]) for r in rows_ if "synth_weights" not in r["Name"] and "split_planes" not in r["Name"])
+            enc[c] = {"ms_per_forward": tot / 1e6 / fwd, "effective_TFLOPps": 1.546188e12 / (tot / 1e9 / fwd) / 1e12,
+                      "kernels_us_per_forward": {r["Name"].split("(anonymous namespace)::")[-1].split("(")[0]:
+                                                 round(float(r["TotalDurationNs"]) / 1e3 / fwd, 1) for r in rows_
+                                                 if float(r["TotalDurationNs"]) / 1e3 / fwd > 5}}
+    if enc:
+        summary["encoder_256x256"] = enc
+        with open(os.path.join(OUT, f"{tag}_summary.json"), "w") as f:
+            json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))
 
 
