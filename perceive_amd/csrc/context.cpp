@@ -58,14 +58,14 @@ pcv_status pcv_init(int device_index, pcv_ctx** out_ctx) {
 pcv_status pcv_shutdown(pcv_ctx* ctx) {
     return guarded([&] {
         if (!ctx) return;
-        hipSetDevice(ctx->device);
-        if (ctx->stream) hipStreamSynchronize(ctx->stream);
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         if (ctx->own_stream) {
-            hipStreamSynchronize(ctx->own_stream);
-            hipStreamDestroy(ctx->own_stream);
+            (void)hipStreamSynchronize(ctx->own_stream);
+            (void)hipStreamDestroy(ctx->own_stream);
         }
-        if (ctx->merge_dev) hipFree(ctx->merge_dev);
-        if (ctx->merge_pin) hipHostFree(ctx->merge_pin);
+        if (ctx->merge_dev) (void)hipFree(ctx->merge_dev);
+        if (ctx->merge_pin) (void)hipHostFree(ctx->merge_pin);
         delete ctx;
     });
 }

@@ -6,6 +6,7 @@
 // order), so the result differs from a CPU f32 evaluation only by summation order.
 #include <cstdlib>
 
+#include "common.h"
 #include "encoder.h"
 #include "synth.h"
 
@@ -1485,11 +1486,11 @@ static void launch_gemm_bf16x3_ws(hipStream_t st, const float* A, const uint16_t
     static bool configured = false;  // > 64 KB of dynamic LDS has to be allowed once per kernel
     static int num_cus = 0;
     if (!configured) {
-        hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kGemmWsLdsBytes);
+        PCV_HIP(hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kGemmWsLdsBytes));
         int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev);
+        PCV_HIP(hipGetDevice(&dev));
+        PCV_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (num_cus <= 0) num_cus = 256;
         configured = true;
     }
@@ -1579,10 +1580,10 @@ void launch_layer_norm(hipStream_t st, float* x, int T, int H, const float* w, c
 template <int HD, int NW, int TPC>
 static void launch_attention_f16_v(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int Lp, int H,
                                    int heads, size_t lds) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)attention_f16_kernel<HD, NW, TPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
+    static size_t allowed = 64 * 1024;  // per instantiation: dynamic LDS beyond 64 KB has to be allowed (static LDS comes on top)
+    if (lds > allowed) {
+        PCV_HIP(hipFuncSetAttribute((const void*)attention_f16_kernel<HD, NW, TPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed = lds;
     }
     dim3 grid((Lp / 32 + NW - 1) / NW, heads, B);
     attention_f16_kernel<HD, NW, TPC><<<grid, NW * 64, lds, st>>>(qkv, mask_add, ctx, B, L, Lp, H);
@@ -1612,10 +1613,10 @@ bool launch_attention_f16(hipStream_t st, const float* qkv, const float* mask_ad
 template <int HD, int NW, int TPC>
 static void launch_attention_staged(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int Lp,
                                     int H, int heads, size_t lds) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)attention_kernel<HD, true, NW, TPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
+    static size_t allowed = 64 * 1024;
+    if (lds > allowed) {
+        PCV_HIP(hipFuncSetAttribute((const void*)attention_kernel<HD, true, NW, TPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed = lds;
     }
     dim3 grid((Lp / 32 + NW - 1) / NW, heads, B);
     attention_kernel<HD, true, NW, TPC><<<grid, NW * 64, lds, st>>>(qkv, mask_add, ctx, B, L, Lp, H);

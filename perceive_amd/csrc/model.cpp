@@ -22,7 +22,7 @@ constexpr int64_t kDebugTokenLimit = 16384;
 constexpr int kGraphTokens = 128;  // forwards up to this many tokens are replayed as hipGraphs
 
 void drop_graphs(pcv_model* m) {
-    for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+    for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     m->graphs.clear();
     m->shape_seen.clear();
 }
@@ -62,10 +62,10 @@ void refresh_planes(pcv_model* m) {
             PCV_HIP(hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, st));
             PCV_HIP(hipStreamSynchronize(st));
         } catch (...) {
-            hipFree(d_over);
+            (void)hipFree(d_over);
             throw;
         }
-        hipFree(d_over);
+        (void)hipFree(d_over);
         if (over) PCV_FAIL(PCV_ERR_UNSUPPORTED, "PCV_COMPUTE_F16X2: a linear-layer weight is outside (-255, 255) or not finite; use PCV_COMPUTE_F32 or PCV_COMPUTE_BF16X3");
         m->planes_dirty = false;
         return;
@@ -215,7 +215,7 @@ void load_weight_file(pcv_model* m, const char* path) {
 void free_workspace(pcv_model* m) {
     for (void* p : {(void*)m->d_ids, (void*)m->d_mask, (void*)m->hidden, (void*)m->qkv, (void*)m->ctxbuf, (void*)m->tmp,
                     (void*)m->ff, (void*)m->mask_add, (void*)m->mask01, (void*)m->pooled, (void*)m->out, (void*)m->dbg})
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     m->d_ids = m->d_mask = nullptr;
     m->hidden = m->qkv = m->ctxbuf = m->tmp = m->ff = m->mask_add = m->mask01 = m->pooled = m->out = m->dbg = nullptr;
     m->cap_tokens = m->cap_padded = m->cap_batch = 0;
@@ -328,7 +328,7 @@ void forward(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, int L
             m->use_graphs = false;
             launch_forward(m, B, L);
         }
-        if (graph) hipGraphDestroy(graph);
+        if (graph) (void)hipGraphDestroy(graph);
     } else {
         launch_forward(m, B, L);
     }
@@ -355,7 +355,7 @@ void check_tokens(pcv_model* m, const int64_t* ids, const int64_t* mask, int B, 
 
 void finish_stats(pcv_model* m) {
     float ms = 0.0f;
-    hipEventElapsedTime(&ms, m->ev0, m->ev1);
+    (void)hipEventElapsedTime(&ms, m->ev0, m->ev1);
     const double H = m->d.hidden, F = m->d.intermediate, L = m->last_L, T = (double)m->last_B * m->last_L;
     m->stats.total_ms = ms;
     m->stats.flops = T * m->d.layers * (8.0 * H * H + 4.0 * H * F + 4.0 * L * H);
@@ -445,12 +445,12 @@ pcv_status pcv_model_create(pcv_ctx* ctx, const pcv_model_desc* desc, const char
 pcv_status pcv_model_destroy(pcv_model* m) {
     return guarded([&] {
         if (!m) return;
-        hipSetDevice(m->ctx->device);
-        hipStreamSynchronize(m->ctx->stream);
+        (void)hipSetDevice(m->ctx->device);
+        (void)hipStreamSynchronize(m->ctx->stream);
         drop_graphs(m);
         free_workspace(m);
-        for (float* p : m->owned) hipFree(p);
-        for (void* p : m->owned_planes) hipFree(p);
+        for (float* p : m->owned) (void)hipFree(p);
+        for (void* p : m->owned_planes) (void)hipFree(p);
         if (m->ev0) (void)hipEventDestroy(m->ev0);
         if (m->ev1) (void)hipEventDestroy(m->ev1);
         for (void* p : {(void*)m->hl_emb, (void*)m->hl_query, (void*)m->hl_bounds, (void*)m->hl_best})

@@ -890,10 +890,14 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
                         const int i = __builtin_ctz(m);
                         m &= m - 1;
                         const int rib = (i & 3) + 8 * (i >> 2) + 4 * hh;  // row of the block this accumulator holds
+                        // row scale, threshold and the row itself are requested together: one memory round trip
+                        // per survivor (tested one after the other they were three, ~6 us under a saturated stream)
                         const float sc = gld(&scp[rib]);
+                        const uint32_t tkey = ld_relaxed(&p.tau[q * kHot]);
+                        const float dot = wave_dot_f32(p.qf32 + (size_t)q * Dp, bbase + rib, D4, lane);
                         if (sc == 0.0f) continue;  // padding / unsearchable row
-                        const float s32 = wave_dot_f32(p.qf32 + (size_t)q * Dp, bbase + rib, D4, lane) * sc;
-                        const float taun = key_f32(max(ltau0[q], ld_relaxed(&p.tau[q * kHot])));
+                        const float s32 = dot * sc;
+                        const float taun = key_f32(max(ltau0[q], tkey));
                         if (s32 < taun - m32) continue;
                         if (lane == 0) {
                             const uint32_t at = g_atomic_add(&p.cand_cnt[q * kHot], 1u);

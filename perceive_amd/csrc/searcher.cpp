@@ -1106,13 +1106,13 @@ pcv_status pcv_comm_create(pcv_ctx* ctx, int world_size, int rank, const uint8_t
 pcv_status pcv_comm_destroy(pcv_comm* c) {
     return guarded([&] {
         if (!c) return;
-        hipSetDevice(c->ctx->device);
-        hipStreamSynchronize(c->ctx->stream);
+        (void)hipSetDevice(c->ctx->device);
+        (void)hipStreamSynchronize(c->ctx->stream);
         if (c->comm) rccl().CommDestroy(c->comm);
         c->d_local.release();
         c->d_gathered.release();
         c->d_merged.release();
-        if (c->pin_hits) hipHostFree(c->pin_hits);
+        if (c->pin_hits) (void)hipHostFree(c->pin_hits);
         delete c;
     });
 }
