@@ -1,7 +1,7 @@
 // perceive.hpp — C++ host-side mirror of perceive-core's public surface over the C ABI
 // (include/perceive_hip.h).  Header-only.  The reference is a compiled (Rust) library; no Rust
-// toolchain exists in the build image, so this is the compiled-language form of the shim shown in
-// same names, argument meaning and error behaviour as
+// toolchain exists in the build image, so this is the compiled-language form of the shim in
+// shim/perceive-core: same names, argument meaning and error behaviour as
 //   crates/perceive-core/search.rs   (Searcher, SearchItem, serialize/deserialize_embedding)
 //   crates/perceive-core/model.rs    (Model, ModelError, SentenceEmbeddingsModelType)
 //   crates/perceive-core/lib.rs:63-77 (dot_product, cosine_similarity_*)
@@ -11,8 +11,10 @@
 #include <cstdint>
 #include <array>
 #include <memory>
+#include <optional>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <unordered_set>
 #include <utility>
 #include <vector>
@@ -160,6 +162,17 @@ public:
         check(pcv_searcher_num_rows(h_, &n));
         return n;
     }
+    // Searcher::build / rebuild_source against the reference's SQLite file itself (search.rs:38-155): the SQL
+    // runs inside the library.  `only_source` empty = every source of the database.
+    int64_t load_sqlite(const std::string& db_path, uint32_t model_id, uint32_t model_version,
+                        std::optional<int64_t> only_source = std::nullopt) {
+        int64_t rows = 0;
+        const int64_t src = only_source.value_or(0);
+        check(pcv_searcher_load_sqlite(h_, db_path.c_str(), model_id, model_version, only_source ? &src : nullptr, &rows));
+        return rows;
+    }
+    // capacity hint: the rows about to be added to `source_id` land in one device segment
+    void reserve(int64_t source_id, int64_t n_rows) { check(pcv_searcher_reserve(h_, source_id, n_rows)); }
     pcv_searcher* handle() const { return h_; }
 
 private:
@@ -202,7 +215,7 @@ inline TokenTensors generate_token_tensors(const std::vector<std::vector<int64_t
     return t;
 }
 
-// model.rs:56-191 (transformer part; the tokenizer stays on the host)
+// model.rs:56-191
 class Model {
 public:
     SentenceEmbeddingsModelType model_type;  // pub field, model.rs:57
@@ -214,9 +227,51 @@ public:
         if (s != PCV_OK) throw ModelError(s, pcv_last_error());
         check(pcv_model_output_dim(h_, &dim_));
     }
+    // Model::new_pretrained (model.rs:68-174) from a sentence-transformers directory: configs, tokenizer and
+    // model.safetensors are read by the library; the model owns its tokenizer
+    Model(Context& ctx, const std::string& model_dir, SentenceEmbeddingsModelType type = SentenceEmbeddingsModelType::AllMiniLmL6V2,
+          int compute = PCV_COMPUTE_F32, bool load_weights = true)
+        : model_type(type) {
+        pcv_status s = pcv_model_create_from_dir(ctx.handle(), model_dir.c_str(), compute, load_weights ? 1 : 0, &h_);
+        if (s != PCV_OK) throw ModelError(s, pcv_last_error());
+        check(pcv_model_output_dim(h_, &dim_));
+    }
     ~Model() { pcv_model_destroy(h_); }
     Model(const Model&) = delete;
     Model& operator=(const Model&) = delete;
+
+    // Model::encode(&[S]) (model.rs:176-179): tokenize + forward in one call
+    std::vector<std::vector<float>> encode(const std::vector<std::string>& inputs) const {
+        std::vector<const char*> ptrs;
+        std::vector<size_t> lens;
+        for (const auto& t : inputs) {
+            ptrs.push_back(t.data());
+            lens.push_back(t.size());
+        }
+        std::vector<float> flat(inputs.size() * (size_t)dim_);
+        pcv_status s = pcv_model_encode_text(h_, ptrs.data(), lens.data(), (int)inputs.size(), flat.data());
+        if (s != PCV_OK) throw ModelError(s, pcv_last_error());
+        std::vector<std::vector<float>> out(inputs.size());
+        for (size_t b = 0; b < inputs.size(); ++b) out[b].assign(flat.begin() + b * dim_, flat.begin() + (b + 1) * dim_);
+        return out;
+    }
+    // Model::highlight (highlight.rs:23-165): views into `documents` (nullopt: the document gave no chunk)
+    std::vector<std::optional<std::string_view>> highlight(const std::string& query, const std::vector<std::string>& documents) const {
+        std::vector<const char*> ptrs;
+        std::vector<size_t> lens;
+        for (const auto& d : documents) {
+            ptrs.push_back(d.data());
+            lens.push_back(d.size());
+        }
+        std::vector<int64_t> b(documents.size(), -1), e(documents.size(), -1);
+        pcv_status s = pcv_model_highlight(h_, query.data(), query.size(), ptrs.data(), lens.data(), (int)documents.size(), 0, -1,
+                                           b.data(), e.data());
+        if (s != PCV_OK) throw ModelError(s, pcv_last_error());
+        std::vector<std::optional<std::string_view>> out(documents.size());
+        for (size_t i = 0; i < documents.size(); ++i)
+            if (b[i] >= 0) out[i] = std::string_view(documents[i]).substr((size_t)b[i], (size_t)(e[i] - b[i]));
+        return out;
+    }
 
     // Model::encode_tokens (model.rs:181-190 -> worker.rs:78-106); result rows = Vec<Vec<f32>>::from(Tensor)
     std::vector<std::vector<float>> encode_tokens(const TokenTensors& t) const {

@@ -15,6 +15,11 @@ enum GemmEpilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
 void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float* bias, const float* resid, float* C,
                      int M, int N, int K, int epilogue);
 
+// out = LayerNorm(A W^T + bias + resid) * ln_w + ln_b in one kernel (N = hidden in {128, 256, 384}, M > 128, exact
+// f32); false when the shape is not covered: the caller then runs launch_gemm_f32 + launch_layer_norm.
+bool launch_gemm_f32_ln(hipStream_t st, const float* A, const float* W, const float* bias, const float* resid, const float* ln_w,
+                        const float* ln_b, float eps, float* C, int M, int N, int K);
+
 // Same contraction with every f32 operand split into three bf16 terms (x = hi + mid + lo): six
 // v_mfma_f32_32x32x16_bf16 per product, f32 accumulate.  Wp = the three pre-split weight planes,
 // each [N][K] bf16; A is split on the fly while it is staged into LDS.

@@ -258,6 +258,143 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// out = LayerNorm(A W^T + bias + resid) for N = hidden <= 384 (all-MiniLM widths): the attention-output
+// and FFN-down projections with their residual + LayerNorm in the epilogue.  A workgroup owns 64 whole rows
+// (64 x N output tile, the four waves side by side, CT = N/128 column tiles of 32 each per wave), so a row's
+// mean and variance never leave the workgroup; the standalone LayerNorm pass — at the HBM roofline already,
+// 100 MB in + 100 MB out per call at 256 x 256 tokens — disappears.  After the K loop the tile goes through
+// LDS (the staging buffers, half the rows at a time) and comes back row-major, eight lanes per row: bias,
+// residual and the normalised output move as 16-byte accesses and the two row reductions are three
+// shuffles each.  Same arithmetic as layer_norm_fixed_kernel (mean, then sum of squared deviations).
+// ------------------------------------------------------------------------------------------------
+constexpr int LBM = 64;
+template <int CT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_ln_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, const float* __restrict__ resid,
+                                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                             float eps, float* __restrict__ C, int M, int K) {
+    constexpr int N = CT * 128;
+    constexpr int LDR = N + 4;  // floats per row of the row-major half tile
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    float* As = lsm;              // [64][LDT]
+    float* Ws = lsm + LBM * LDT;  // [N][LDT]
+    static_assert(32 * LDR <= (LBM + N) * LDT, "the epilogue's half tile fits the staging buffers");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int m0 = blockIdx.x * LBM;
+
+    // staging: thread t moves float4 (row = (t>>3) + 32*u, 16-byte column c4 = t&7)
+    const int srow = tid >> 3, c4 = tid & 7;
+    const float* ag[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) ag[u] = A + (size_t)min(m0 + srow + 32 * u, M - 1) * K + c4 * 4;
+    const float* wg = W + (size_t)srow * K + c4 * 4;  // rows srow + 32*u, u = 0 .. 4*CT-1
+    f32x4 ra[2], rw[4 * CT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) ra[u] = *(const f32x4*)(ag[u]);
+#pragma unroll
+    for (int u = 0; u < 4 * CT; ++u) rw[u] = *(const f32x4*)(wg + (size_t)32 * u * K);
+
+    f32x16 acc[2][CT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *(f32x4*)&As[(srow + 32 * u) * LDT + c4 * 4] = ra[u];
+#pragma unroll
+        for (int u = 0; u < 4 * CT; ++u) *(f32x4*)&Ws[(srow + 32 * u) * LDT + c4 * 4] = rw[u];
+        __syncthreads();
+        {  // next step's global loads fly under this step's MFMAs (the last step re-reads its own tile)
+            const size_t koff = (size_t)min(kt + 1, nk - 1) * BK;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) ra[u] = *(const f32x4*)(ag[u] + koff);
+#pragma unroll
+            for (int u = 0; u < 4 * CT; ++u) rw[u] = *(const f32x4*)(wg + (size_t)32 * u * K + koff);
+        }
+        // fragments in two halves of eight k each: 40 registers of operands instead of 80
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float af[2][8], bf[CT][8];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float* ap = &As[(a * 32 + i) * LDT + 16 * kk + 8 * hh];
+                const f32x4 x0 = *(const f32x4*)ap, x1 = *(const f32x4*)(ap + 4);
+                af[a][0] = x0.x; af[a][1] = x0.y; af[a][2] = x0.z; af[a][3] = x0.w;
+                af[a][4] = x1.x; af[a][5] = x1.y; af[a][6] = x1.z; af[a][7] = x1.w;
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float* bp = &Ws[((wave * CT + c) * 32 + i) * LDT + 16 * kk + 8 * hh];
+                const f32x4 y0 = *(const f32x4*)bp, y1 = *(const f32x4*)(bp + 4);
+                bf[c][0] = y0.x; bf[c][1] = y0.y; bf[c][2] = y0.z; bf[c][3] = y0.w;
+                bf[c][4] = y1.x; bf[c][5] = y1.y; bf[c][6] = y1.z; bf[c][7] = y1.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[c][s], acc[a][c], 0, 0, 0);
+        }
+    }
+
+    // epilogue: rows 0..31 then 32..63 of the tile, row-major through LDS; 8 lanes per row, lane j of a row
+    // holds its float4 columns j, j+8, ... (N/32 of them)
+    constexpr int Q = N / 32;
+    const int erow = tid >> 3, ej = tid & 7;
+    float* tile = lsm;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        __syncthreads();  // fragment reads (a = 0) / the previous half's row reads (a = 1) are done
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[acc_row(r, kk) * LDR + (wave * CT + c) * 32 + i] = acc[a][c][r];
+        __syncthreads();
+        const int row = m0 + a * 32 + erow;
+        const bool live = row < M;
+        const float* rrow = resid + (size_t)(live ? row : 0) * N;
+        f32x4 v[Q];
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < Q; ++t) {
+            const int col = 4 * (ej + 8 * t);
+            v[t] = *(const f32x4*)(tile + erow * LDR + col) + *(const f32x4*)(bias + col) + *(const f32x4*)(rrow + col);
+            sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+        const float mean = sum / (float)N;
+        float sq = 0.0f;
+#pragma unroll
+        for (int t = 0; t < Q; ++t) {
+            const f32x4 d = v[t] - mean;
+            sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+        sq += __shfl_xor(sq, 1);
+        sq += __shfl_xor(sq, 2);
+        sq += __shfl_xor(sq, 4);
+        const float rstd = 1.0f / sqrtf(sq / (float)N + eps);
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < Q; ++t) {
+                const int col = 4 * (ej + 8 * t);
+                *(f32x4*)(C + (size_t)row * N + col) = (v[t] - mean) * rstd * *(const f32x4*)(ln_w + col) + *(const f32x4*)(ln_b + col);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny GEMM for M <= 128 (a single query, a few highlight chunks): the 128x128 tiling would run
 // N/128 workgroups through K/32 barrier-separated steps each (30-115 us per layer GEMM, launch- and
 // latency-bound).  Here a workgroup owns a 32-column strip of the output for ALL rows, its 8 waves
@@ -1353,15 +1490,31 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hid
         float acc[kMaxPerLane];
 #pragma unroll
         for (int j = 0; j < kMaxPerLane; ++j) acc[j] = mode == PCV_POOL_MAX ? -__builtin_inff() : 0.0f;
-        for (int l = wave; l < L; l += 4) {
-            const float m = mb[l];
-            const float* row = hb + (size_t)l * H;
+        // four tokens' loads are requested together (one token per iteration ran at one memory round trip per
+        // token: 124 us for 256 documents of 256 tokens); accumulation order unchanged
+        constexpr int TG = 4;
+        for (int l0 = wave; l0 < L; l0 += 4 * TG) {
+            float m[TG], x[TG][kMaxPerLane];
 #pragma unroll
-            for (int j = 0; j < kMaxPerLane; ++j) {
-                const int c = lane + 64 * j;
-                if (j < npl && c < H) {
-                    const float x = row[c];
-                    acc[j] = mode == PCV_POOL_MAX ? fmaxf(acc[j], m != 0.0f ? x : -1e9f) : acc[j] + x * m;
+            for (int g = 0; g < TG; ++g) {
+                const int l = l0 + 4 * g;
+                const bool live = l < L;
+                m[g] = live ? mb[l] : 0.0f;
+                const float* row = hb + (size_t)(live ? l : 0) * H;
+#pragma unroll
+                for (int j = 0; j < kMaxPerLane; ++j) {
+                    const int c = lane + 64 * j;
+                    x[g][j] = (live && j < npl && c < H) ? row[c] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < TG; ++g) {
+                if (l0 + 4 * g >= L) break;
+#pragma unroll
+                for (int j = 0; j < kMaxPerLane; ++j) {
+                    const int c = lane + 64 * j;
+                    if (j < npl && c < H)
+                        acc[j] = mode == PCV_POOL_MAX ? fmaxf(acc[j], m[g] != 0.0f ? x[g][j] : -1e9f) : acc[j] + x[g][j] * m[g];
                 }
             }
         }
@@ -1456,6 +1609,26 @@ static void launch_skinny(hipStream_t st, const float* A, const float* W, const 
             break;
         default: gemm_skinny_f32_kernel<EPI_BIAS, MT, NW><<<grid, NW * 64, 0, st>>>(A, W, bias, resid, C, M, N, K); break;
     }
+}
+
+bool launch_gemm_f32_ln(hipStream_t st, const float* A, const float* W, const float* bias, const float* resid, const float* ln_w,
+                        const float* ln_b, float eps, float* C, int M, int N, int K) {
+    if (M <= 128 || (N != 128 && N != 256 && N != 384) || K % BK != 0 || bias == nullptr || resid == nullptr) return false;
+    const size_t lds = (size_t)(LBM + N) * LDT * sizeof(float);
+    const dim3 grid((M + LBM - 1) / LBM);
+    switch (N / 128) {
+        case 1: gemm_f32_ln_kernel<1><<<grid, 256, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K); break;
+        case 2: gemm_f32_ln_kernel<2><<<grid, 256, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K); break;
+        default: {
+            static bool allowed = false;  // 64.5 KB of dynamic LDS
+            if (!allowed) {
+                PCV_HIP(hipFuncSetAttribute((const void*)gemm_f32_ln_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                allowed = true;
+            }
+            gemm_f32_ln_kernel<3><<<grid, 256, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
+        }
+    }
+    return true;
 }
 
 void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float* bias, const float* resid, float* C,

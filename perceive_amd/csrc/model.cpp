@@ -273,11 +273,19 @@ void launch_forward(pcv_model* m, int B, int L) {
         gemm(m, m->hidden, W.qkv_w, W.qkv_p, W.qkv_b.p, nullptr, m->qkv, T, 3 * H, H, EPI_BIAS);
         if (!(d.compute == PCV_COMPUTE_F16X2 && launch_attention_f16(st, m->qkv, m->mask_add, m->ctxbuf, B, L, H, d.heads)))
             launch_attention(st, m->qkv, m->mask_add, m->ctxbuf, B, L, H, d.heads);
-        gemm(m, m->ctxbuf, W.ao_w, W.ao_p, W.ao_b.p, m->hidden, m->tmp, T, H, H, EPI_BIAS_RESIDUAL);
-        launch_layer_norm(st, m->tmp, T, H, W.ln1_w.p, W.ln1_b.p, d.layer_norm_eps);
+        // projection + residual + LayerNorm: one kernel where the width allows whole rows per workgroup
+        const bool fuse = d.compute == PCV_COMPUTE_F32 && m->fuse_ln;
+        if (!(fuse && launch_gemm_f32_ln(st, m->ctxbuf, W.ao_w.p, W.ao_b.p, m->hidden, W.ln1_w.p, W.ln1_b.p, d.layer_norm_eps,
+                                         m->tmp, T, H, H))) {
+            gemm(m, m->ctxbuf, W.ao_w, W.ao_p, W.ao_b.p, m->hidden, m->tmp, T, H, H, EPI_BIAS_RESIDUAL);
+            launch_layer_norm(st, m->tmp, T, H, W.ln1_w.p, W.ln1_b.p, d.layer_norm_eps);
+        }
         gemm(m, m->tmp, W.i_w, W.i_p, W.i_b.p, nullptr, m->ff, T, F, H, EPI_BIAS_GELU);
-        gemm(m, m->ff, W.f_w, W.f_p, W.f_b.p, m->tmp, m->hidden, T, H, F, EPI_BIAS_RESIDUAL);
-        launch_layer_norm(st, m->hidden, T, H, W.ln2_w.p, W.ln2_b.p, d.layer_norm_eps);
+        if (!(fuse && launch_gemm_f32_ln(st, m->ff, W.f_w.p, W.f_b.p, m->tmp, W.ln2_w.p, W.ln2_b.p, d.layer_norm_eps, m->hidden,
+                                         T, H, F))) {
+            gemm(m, m->ff, W.f_w, W.f_p, W.f_b.p, m->tmp, m->hidden, T, H, F, EPI_BIAS_RESIDUAL);
+            launch_layer_norm(st, m->hidden, T, H, W.ln2_w.p, W.ln2_b.p, d.layer_norm_eps);
+        }
         snap(ly + 1);
     }
     if (d.dense_out > 0) {
@@ -426,6 +434,7 @@ pcv_status pcv_model_create(pcv_ctx* ctx, const pcv_model_desc* desc, const char
         m->ctx = ctx;
         m->d = d;
         if (getenv("PCV_NO_GRAPHS")) m->use_graphs = false;  // diagnostics: always launch eagerly
+        if (getenv("PCV_NO_FUSED_LN")) m->fuse_ln = false;   // diagnostics / A-B: projection and LayerNorm as two kernels
         try {
             build_tensors(m);
             PCV_HIP(hipEventCreate(&m->ev0));

@@ -59,6 +59,7 @@ struct pcv_model {
     std::map<std::pair<int, int>, hipGraphExec_t> graphs;
     std::map<std::pair<int, int>, int> shape_seen;
     bool use_graphs = true;
+    bool fuse_ln = true;  // residual + LayerNorm inside the projection GEMMs where the width allows (PCV_NO_FUSED_LN=1: off)
     // text side (text_model.cpp): Model::tokenizer / sentence_bert_config of model.rs:61-63
     pcv_tokenizer* tok = nullptr;
     bool own_tok = false;

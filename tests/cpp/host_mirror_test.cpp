@@ -5,7 +5,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <fstream>
 #include <random>
+#include <sstream>
 
 #include "perceive.hpp"
 
@@ -20,7 +22,7 @@ static int failures = 0;
         }                                                                 \
     } while (0)
 
-int main() {
+int main(int argc, char** argv) {
     Context ctx(0);
     const int D = 384, N = 3000;
     std::mt19937 rng(7);
@@ -97,6 +99,28 @@ int main() {
     }
     auto sim = cosine_similarity_single_query(ctx, e1[0], e1[0], 1, m.output_dim());
     EXPECT(std::fabs(sim[0] - 1.0f) < 1e-5f);
+
+    // Model::new_pretrained / encode / highlight from a model directory (argv[1], written by the Python test:
+    // JSON configs + vocab.txt; weights stay the seeded synthetic ones, load_weights = false)
+    if (argc > 1) {
+        Model tm(ctx, argv[1], SentenceEmbeddingsModelType::AllMiniLmL6V2, PCV_COMPUTE_F32, /*load_weights=*/false);
+        std::vector<std::string> texts = {"Hello world", "the search of embeddings, really?", "Hello world"};
+        auto emb = tm.encode(texts);
+        EXPECT(emb.size() == 3 && (int)emb[0].size() == tm.output_dim());
+        EXPECT(emb[0] == emb[2] && emb[0] != emb[1]);
+        std::string filler;
+        for (int i = 0; i < 12; ++i) filler += "people work each day and the years go on. ";
+        std::vector<std::string> docs = {filler + "how good is the search model in the world today " + filler, "short one", ""};
+        auto hl = tm.highlight("how good is the search model", docs);
+        EXPECT(hl.size() == 3 && hl[0].has_value() && !hl[1].has_value() && !hl[2].has_value());
+        if (hl[0]) EXPECT(hl[0]->data() >= docs[0].data() && hl[0]->data() + hl[0]->size() <= docs[0].data() + docs[0].size());
+        try {
+            Model missing(ctx, std::string(argv[1]) + "/nope");
+            EXPECT(false);
+        } catch (const ModelError& e) {
+            EXPECT(e.status == PCV_ERR_IO);
+        }
+    }
 
     std::printf(failures ? "host_mirror_test: %d failure(s)\n" : "host_mirror_test: ok\n", failures);
     return failures ? 1 : 0;
