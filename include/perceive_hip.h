@@ -342,19 +342,30 @@ const char* pcv_model_type_dir_name(int model_type);
 
 /* Model::new_pretrained (model.rs:68-174) from a sentence-transformers model directory: modules.json,
  * config.json, sentence_bert_config.json, tokenizer_config.json, vocab.txt (or vocab.json + merges.txt),
- * <n>_Pooling/config.json, optional <n>_Dense/{config.json, model.safetensors}.  BERT, DistilBERT and RoBERTa
+ * <n>_Pooling/config.json, optional <n>_Dense/{config.json, weights}.  BERT, DistilBERT and RoBERTa
  * transformers (the ALBERT variant is refused with PCV_ERR_UNSUPPORTED).  The model owns its tokenizer.
  *   compute       PCV_COMPUTE_*
- *   load_weights  != 0: read model.safetensors (F32 / F16 / BF16; nothing in the file is executed);
- *                 0: leave the weights to the caller — hand every checkpoint tensor to pcv_model_load_hf_tensor
- *                 (e.g. from rust_model.ot or pytorch_model.bin read by the host's own safe loader), then
- *                 pcv_model_check_loaded. */
+ *   load_weights  != 0: read the weights file of the directory — rust_model.ot (what the reference loads,
+ *                 configs.rs:109,112), else model.safetensors, else pytorch_model.bin; see pcv_checkpoint_visit;
+ *                 0: leave the weights to the caller — hand every checkpoint tensor to pcv_model_load_hf_tensor,
+ *                 then pcv_model_check_loaded. */
 pcv_status pcv_model_create_from_dir(pcv_ctx* ctx, const char* model_dir, int compute, int load_weights, pcv_model** out);
 /* What pcv_model_create_from_dir would build, from the directory's JSON files alone (needs no GPU): the model
  * description, the transformer family (0 BERT, 1 DistilBERT, 2 RoBERTa) and the tokenizer options
  * (strip_accents: -1 = follow lower_case).  Any output pointer may be NULL. */
 pcv_status pcv_model_dir_describe(const char* model_dir, pcv_model_desc* out_desc, int* out_arch, int* out_lower_case,
                                   int* out_strip_accents);
+/* Walk a checkpoint file: model.safetensors, or a libtorch zip archive — rust_model.ot as tch's
+ * Tensor::save_multi writes it (VarStore::load, model.rs:117-124) or a torch.save state dict (pytorch_model.bin).
+ * The archive's pickle is interpreted by a closed machine that knows only the tensor / dict / module records those
+ * writers emit; nothing from the file is executed, an unknown record is PCV_ERR_UNSUPPORTED.
+ * `visit` is called once per tensor in file order: shape[rank], dtype PCV_TENSOR_*, values = numel row-major f32
+ * converted from the stored dtype (NULL for PCV_TENSOR_OTHER: integer tensors such as position_ids).  A non-zero
+ * return from `visit` stops the walk with PCV_ERR_INVALID.  Needs no GPU. */
+enum { PCV_TENSOR_F32 = 0, PCV_TENSOR_F16 = 1, PCV_TENSOR_BF16 = 2, PCV_TENSOR_F64 = 3, PCV_TENSOR_OTHER = 4 };
+typedef int (*pcv_tensor_visitor)(void* user, const char* name, const int64_t* shape, int rank, int dtype, const float* values,
+                                  int64_t numel);
+pcv_status pcv_checkpoint_visit(const char* path, pcv_tensor_visitor visit, void* user);
 /* One checkpoint tensor under its Hugging Face / rust-bert name ("bert.encoder.layer.0...", DistilBERT and
  * RoBERTa names included: they are mapped onto the encoder graph, the RoBERTa position table is shifted);
  * names the graph does not use are ignored.  `data`: numel f32, row-major. */

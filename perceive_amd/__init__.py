@@ -37,4 +37,4 @@ from .database import (  # noqa: F401,E402
     search_and_retrieve,
     search_vector_and_retrieve,
 )
-from .pretrained import new_pretrained, parse_model_dir  # noqa: F401,E402
+from .pretrained import checkpoint_tensors, new_pretrained, parse_model_dir  # noqa: F401,E402

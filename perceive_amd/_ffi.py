@@ -75,6 +75,8 @@ _I64P = C.c_void_p  # int64_t*
 _F32P = C.c_void_p  # float*
 _U8P = C.c_void_p  # uint8_t*
 _INTP = C.c_void_p  # int* / int32_t*
+# int visit(void* user, const char* name, const int64_t* shape, int rank, int dtype, const float* values, int64_t numel)
+TENSOR_VISITOR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int64)
 SYMBOLS = {
     "pcv_last_error": (C.c_char_p, []),
     "pcv_version": (C.c_char_p, []),
@@ -137,6 +139,7 @@ SYMBOLS = {
     "pcv_model_type_dir_name": (C.c_char_p, [C.c_int]),
     "pcv_model_create_from_dir": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "pcv_model_dir_describe": (C.c_int, [C.c_char_p, C.POINTER(ModelDesc), _INTP, _INTP, _INTP]),
+    "pcv_checkpoint_visit": (C.c_int, [C.c_char_p, TENSOR_VISITOR, _P]),
     "pcv_model_load_hf_tensor": (C.c_int, [_P, C.c_char_p, _F32P, C.c_int64]),
     "pcv_model_check_loaded": (C.c_int, [_P]),
     "pcv_model_set_tokenizer": (C.c_int, [_P, _P, C.c_int]),

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <exception>
 #include <fstream>
+#include <functional>
 #include <memory>
 #include <sstream>
 #include <thread>
@@ -23,6 +24,7 @@
 #include "encoder.h"
 #include "model_internal.h"
 #include "tokenizer.h"
+#include "torch_archive.h"
 
 using namespace pcv;
 
@@ -315,9 +317,12 @@ float half_to_float(uint16_t h) {
     return f;
 }
 
+using WantFn = std::function<bool(const std::string&)>;
+using TensorFn = std::function<void(const ArchiveTensor&)>;
+
 // safetensors: u64 LE header length, JSON header {name: {dtype, shape, data_offsets}}, raw little-endian data.
-// Nothing in the file is executed; F32 / F16 / BF16 tensors are accepted.
-void load_safetensors(pcv_model* m, const std::string& path, const char* rename_prefix) {
+// Nothing in the file is executed; F32 / F16 / BF16 / F64 tensors are converted, others reported as AR_OTHER.
+void read_safetensors(const std::string& path, const WantFn& want, const TensorFn& fn) {
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) PCV_FAIL(PCV_ERR_IO, "cannot open %s", path.c_str());
     struct Closer {
@@ -334,50 +339,94 @@ void load_safetensors(pcv_model* m, const std::string& path, const char* rename_
     std::fseek(f, 0, SEEK_END);
     const uint64_t fsize = (uint64_t)std::ftell(f), base = 8 + hlen;
     const JVal doc = parse_json(header, path);
-    if (doc.t != JVal::Obj) PCV_FAIL(PCV_ERR_IO, "%s: header is not an object", path.c_str());
+    if (doc.t != JVal::Obj) PCV_FAIL(PCV_ERR_IO, "%s: header is not a JSON object", path.c_str());
     std::vector<uint8_t> raw;
-    std::vector<float> conv;
+    ArchiveTensor out;
     for (const auto& kv : doc.o) {
         if (kv.first == "__metadata__") continue;
-        const JVal& e = kv.second;
-        const std::string dtype = e.str("dtype", "");
-        const JVal* shape = e.get("shape");
-        const JVal* offs = e.get("data_offsets");
-        if (!shape || shape->t != JVal::Arr || !offs || offs->t != JVal::Arr || offs->a.size() != 2)
+        const JVal& t = kv.second;
+        const std::string dtype = t.str("dtype", "");
+        const JVal* offs = t.get("data_offsets");
+        const JVal* shape = t.get("shape");
+        if (!offs || offs->t != JVal::Arr || offs->a.size() != 2 || !shape || shape->t != JVal::Arr)
             PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has no shape / data_offsets", path.c_str(), kv.first.c_str());
-        int64_t numel = 1;
-        for (const JVal& d : shape->a) numel *= (int64_t)d.n;
-        const int esize = dtype == "F32" ? 4 : (dtype == "F16" || dtype == "BF16") ? 2 : 0;
-        const uint64_t a = (uint64_t)offs->a[0].n, b = (uint64_t)offs->a[1].n;
-        if (esize == 0) {
-            if (m->table.count(graph_name(m->arch, std::string(rename_prefix) + kv.first)))
-                PCV_FAIL(PCV_ERR_UNSUPPORTED, "%s: tensor %s has dtype %s (F32, F16 and BF16 are read)", path.c_str(), kv.first.c_str(),
-                         dtype.c_str());
-            continue;  // e.g. the I64 position_ids buffer
+        if (!want(kv.first)) continue;
+        out.name = kv.first;
+        out.dtype_name = dtype;
+        out.shape.clear();
+        out.numel = 1;
+        for (const JVal& d : shape->a) {
+            out.shape.push_back((int64_t)d.n);
+            out.numel *= (int64_t)d.n;
         }
-        if (b < a || b - a != (uint64_t)numel * esize || base + b > fsize)
-            PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has inconsistent offsets", path.c_str(), kv.first.c_str());
-        const std::string hf = std::string(rename_prefix) + kv.first;
-        if (!m->table.count(graph_name(m->arch, hf))) continue;
-        raw.resize((size_t)(b - a));
-        std::fseek(f, (long)(base + a), SEEK_SET);
-        if (std::fread(raw.data(), 1, raw.size(), f) != raw.size()) PCV_FAIL(PCV_ERR_IO, "%s: truncated data of %s", path.c_str(), kv.first.c_str());
-        conv.resize((size_t)numel);
-        if (esize == 4) {
-            std::memcpy(conv.data(), raw.data(), raw.size());  // little-endian host
-        } else {
-            for (int64_t i = 0; i < numel; ++i) {
-                const uint16_t h = (uint16_t)raw[2 * i] | ((uint16_t)raw[2 * i + 1] << 8);
-                if (dtype == "BF16") {
-                    const uint32_t u = (uint32_t)h << 16;
-                    std::memcpy(&conv[i], &u, 4);
-                } else {
-                    conv[i] = half_to_float(h);
+        const uint64_t a = (uint64_t)offs->a[0].n, b = (uint64_t)offs->a[1].n;
+        const uint64_t esize = dtype == "F32" ? 4 : (dtype == "F16" || dtype == "BF16") ? 2 : dtype == "F64" ? 8 : 0;
+        out.dtype = dtype == "F32" ? AR_F32 : dtype == "F16" ? AR_F16 : dtype == "BF16" ? AR_BF16 : dtype == "F64" ? AR_F64 : AR_OTHER;
+        out.values.clear();
+        if (esize != 0) {
+            if (b < a || b - a != (uint64_t)out.numel * esize || base + b > fsize)
+                PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has inconsistent offsets", path.c_str(), kv.first.c_str());
+            raw.resize((size_t)(b - a));
+            std::fseek(f, (long)(base + a), SEEK_SET);
+            if (std::fread(raw.data(), 1, raw.size(), f) != raw.size()) PCV_FAIL(PCV_ERR_IO, "%s: truncated data of %s", path.c_str(), kv.first.c_str());
+            out.values.resize((size_t)out.numel);
+            if (esize == 4) {
+                std::memcpy(out.values.data(), raw.data(), raw.size());  // little-endian host
+            } else if (esize == 8) {
+                for (int64_t i = 0; i < out.numel; ++i) {
+                    double d;
+                    std::memcpy(&d, raw.data() + 8 * i, 8);
+                    out.values[(size_t)i] = (float)d;
+                }
+            } else {
+                for (int64_t i = 0; i < out.numel; ++i) {
+                    const uint16_t h = (uint16_t)raw[2 * i] | ((uint16_t)raw[2 * i + 1] << 8);
+                    if (out.dtype == AR_BF16) {
+                        const uint32_t u = (uint32_t)h << 16;
+                        std::memcpy(&out.values[(size_t)i], &u, 4);
+                    } else {
+                        out.values[(size_t)i] = half_to_float(h);
+                    }
                 }
             }
         }
-        load_hf_tensor(m, hf, conv.data(), numel);
+        fn(out);
     }
+}
+
+// A checkpoint in any of the three formats a model directory may hold: `model.safetensors`, the reference's
+// `rust_model.ot` (configs.rs:109,112) or `pytorch_model.bin`; told apart by the zip signature.
+void read_checkpoint(const std::string& path, const WantFn& want, const TensorFn& fn) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) PCV_FAIL(PCV_ERR_IO, "cannot open %s", path.c_str());
+    uint8_t magic[4] = {0, 0, 0, 0};
+    const size_t got = std::fread(magic, 1, 4, f);
+    std::fclose(f);
+    if (got == 4 && magic[0] == 'P' && magic[1] == 'K' && (magic[2] == 3 || magic[2] == 5) && (magic[3] == 4 || magic[3] == 6))
+        read_torch_archive(path, want, fn);
+    else
+        read_safetensors(path, want, fn);
+}
+
+// Every tensor of `path` the graph has a place for, under `rename_prefix` + its checkpoint name.
+void load_checkpoint(pcv_model* m, const std::string& path, const char* rename_prefix) {
+    const std::string prefix(rename_prefix);
+    read_checkpoint(
+        path, [&](const std::string& name) { return m->table.count(graph_name(m->arch, prefix + name)) != 0; },
+        [&](const ArchiveTensor& t) {
+            if (t.dtype == AR_OTHER)
+                PCV_FAIL(PCV_ERR_UNSUPPORTED, "%s: tensor %s has dtype %s (32/16-bit floats and doubles are read)", path.c_str(), t.name.c_str(),
+                         t.dtype_name.c_str());
+            PCV_REQUIRE(t.numel > 0, "%s: tensor %s is empty", path.c_str(), t.name.c_str());
+            load_hf_tensor(m, prefix + t.name, t.values.data(), t.numel);
+        });
+}
+
+// The weights file of a module directory, in the order: what the reference reads, then what Hugging Face ships.
+std::string find_weights(const std::string& dir) {
+    for (const char* name : {"rust_model.ot", "model.safetensors", "pytorch_model.bin"})
+        if (file_exists(dir + name)) return dir + name;
+    return std::string();
 }
 
 void require_all_loaded(pcv_model* m, const std::string& where) {
@@ -674,13 +723,16 @@ pcv_status pcv_model_create_from_dir(pcv_ctx* ctx, const char* model_dir, int co
                 m->loaded["dense.linear.bias"] = true;
             }
             if (load_weights) {
-                const std::string wpath = dir + "model.safetensors";
-                if (!file_exists(wpath))
-                    PCV_FAIL(PCV_ERR_IO, "%s: no model.safetensors (other formats: build with load_weights = 0 and hand the tensors to "
-                                         "pcv_model_load_hf_tensor)", model_dir);
+                const std::string wpath = find_weights(dir);
+                if (wpath.empty())
+                    PCV_FAIL(PCV_ERR_IO, "%s: no rust_model.ot, model.safetensors or pytorch_model.bin", model_dir);
                 std::lock_guard<std::mutex> lk(m->mu);
-                load_safetensors(m, wpath, "");
-                if (!pd.dense_path.empty()) load_safetensors(m, dir + pd.dense_path + "/model.safetensors", "dense.");
+                load_checkpoint(m, wpath, "");
+                if (!pd.dense_path.empty()) {
+                    const std::string dpath = find_weights(dir + pd.dense_path + "/");
+                    if (dpath.empty()) PCV_FAIL(PCV_ERR_IO, "%s: the Dense module %s holds no weights file", model_dir, pd.dense_path.c_str());
+                    load_checkpoint(m, dpath, "dense.");
+                }
                 require_all_loaded(m, model_dir);
             }
         } catch (...) {
@@ -688,6 +740,19 @@ pcv_status pcv_model_create_from_dir(pcv_ctx* ctx, const char* model_dir, int co
             throw;
         }
         *out = m;
+    });
+}
+
+pcv_status pcv_checkpoint_visit(const char* path, pcv_tensor_visitor visit, void* user) {
+    return guarded([&] {
+        PCV_REQUIRE(path != nullptr && visit != nullptr, "checkpoint_visit: NULL argument");
+        read_checkpoint(
+            path, [](const std::string&) { return true; },
+            [&](const ArchiveTensor& t) {
+                const float* values = t.dtype == AR_OTHER || t.values.empty() ? nullptr : t.values.data();
+                if (visit(user, t.name.c_str(), t.shape.data(), (int)t.shape.size(), t.dtype, values, t.numel) != 0)
+                    PCV_FAIL(PCV_ERR_INVALID, "checkpoint_visit: stopped by the visitor at %s", t.name.c_str());
+            });
     });
 }
 

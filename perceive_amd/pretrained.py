@@ -5,9 +5,8 @@ model/configs.rs:97-119).  The reference reads, per model, the sentence-transfor
                        vocab.txt, 1_Pooling/config.json, [2_Dense/config.json], weights
 
 with weights converted to rust-bert's `rust_model.ot`.  The directory is read by the library itself
-(pcv_model_create_from_dir: JSON configs, tokenizer files and `model.safetensors`, in C++).  What is left
-here is the one format a C++ host has no safe reader for: `pytorch_model.bin`, loaded with
-`torch.load(weights_only=True)` and handed over tensor by tensor (pcv_model_load_hf_tensor).
+(pcv_model_create_from_dir: JSON configs, tokenizer files, and the weights as `rust_model.ot`,
+`model.safetensors` or `pytorch_model.bin`, all in C++); this file converts arguments.
 """
 import ctypes as C
 import os
@@ -48,11 +47,24 @@ def parse_model_dir(directory):
     return desc, tok, dense
 
 
-def _torch_bin(path):
-    import torch
+def checkpoint_tensors(path):
+    """{name: (f32 array, or None for an integer tensor)} of a checkpoint file — model.safetensors, rust_model.ot or
+    pytorch_model.bin — as the library's own readers see it (pcv_checkpoint_visit; nothing in the file is executed)."""
+    import numpy as np
 
-    sd = torch.load(path, map_location="cpu", weights_only=True)  # never unpickle arbitrary objects
-    return {k: v.float().numpy() for k, v in sd.items()}
+    out = {}
+
+    @_ffi.TENSOR_VISITOR
+    def visit(_user, name, shape, rank, dtype, values, numel):
+        dims = tuple(shape[i] for i in range(rank))
+        out[name.decode()] = None if not values else np.ctypeslib.as_array(values, shape=(numel,)).reshape(dims).copy()
+        return 0
+
+    try:
+        _ffi.check(_ffi.lib().pcv_checkpoint_visit(str(path).encode(), visit, None))
+    except _ffi.PcvError as e:
+        raise ModelError(str(e)) from e
+    return out
 
 
 def new_pretrained(ctx, model, model_data_dir=None, compute="f32"):
@@ -64,26 +76,4 @@ def new_pretrained(ctx, model, model_data_dir=None, compute="f32"):
         model_type = model
     else:
         directory, model_type = str(model), SentenceEmbeddingsModelType.AllMiniLmL6V2
-    if os.path.exists(os.path.join(directory, "model.safetensors")):
-        return Model.from_dir(ctx, directory, compute=compute, model_type=model_type)
-    pt = os.path.join(directory, "pytorch_model.bin")
-    if not os.path.exists(pt) and os.path.isdir(directory):
-        raise ModelError(f"no model.safetensors / pytorch_model.bin under {directory}")
-    m = Model.from_dir(ctx, directory, compute=compute, model_type=model_type, load_weights=False)  # raises on a bad directory
-    try:
-        for k, v in _torch_bin(pt).items():
-            m.load_hf_tensor(k, v)
-        dense = next((p for p in sorted(os.listdir(directory)) if p.endswith("_Dense")), None)
-        if dense and os.path.exists(os.path.join(directory, dense, "pytorch_model.bin")):
-            for k, v in _torch_bin(os.path.join(directory, dense, "pytorch_model.bin")).items():
-                m.load_hf_tensor("dense." + k, v)
-        elif dense and os.path.exists(os.path.join(directory, dense, "model.safetensors")):
-            from safetensors.numpy import load_file
-
-            for k, v in load_file(os.path.join(directory, dense, "model.safetensors")).items():
-                m.load_hf_tensor("dense." + k, v)
-        m.check_loaded()
-    except Exception:
-        m.close()
-        raise
-    return m
+    return Model.from_dir(ctx, directory, compute=compute, model_type=model_type)

@@ -104,6 +104,13 @@ pub const PCV_ACT_TANH: c_int = 1;
 pub const PCV_COMPUTE_F32: c_int = 0;
 pub const PCV_COMPUTE_BF16X3: c_int = 1;
 pub const PCV_COMPUTE_F16X2: c_int = 2;
+pub const PCV_TENSOR_F32: c_int = 0;
+pub const PCV_TENSOR_F16: c_int = 1;
+pub const PCV_TENSOR_BF16: c_int = 2;
+pub const PCV_TENSOR_F64: c_int = 3;
+pub const PCV_TENSOR_OTHER: c_int = 4;
+
+pub type pcv_tensor_visitor = Option<unsafe extern "C" fn(user: *mut c_void, name: *const c_char, shape: *const i64, rank: c_int, dtype: c_int, values: *const f32, numel: i64) -> c_int>;
 
 #[link(name = "perceive_hip")]
 extern "C" {
@@ -168,6 +175,7 @@ extern "C" {
     pub fn pcv_model_type_dir_name(model_type: c_int) -> *const c_char;
     pub fn pcv_model_create_from_dir(ctx: *mut pcv_ctx, model_dir: *const c_char, compute: c_int, load_weights: c_int, out: *mut *mut pcv_model) -> c_int;
     pub fn pcv_model_dir_describe(model_dir: *const c_char, out_desc: *mut pcv_model_desc, out_arch: *mut c_int, out_lower_case: *mut c_int, out_strip_accents: *mut c_int) -> c_int;
+    pub fn pcv_checkpoint_visit(path: *const c_char, visit: pcv_tensor_visitor, user: *mut c_void) -> c_int;
     pub fn pcv_model_load_hf_tensor(m: *mut pcv_model, hf_name: *const c_char, data: *const f32, numel: i64) -> c_int;
     pub fn pcv_model_check_loaded(m: *mut pcv_model) -> c_int;
     pub fn pcv_model_set_tokenizer(m: *mut pcv_model, t: *mut pcv_tokenizer, take_ownership: c_int) -> c_int;

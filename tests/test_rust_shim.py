@@ -120,6 +120,25 @@ def test_ffi_structs_and_constants():
     assert consts == rconsts and len(consts) >= 20
 
 
+def test_ffi_callback_types_match_the_header():
+    htext = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    rtext = open(os.path.join(SHIM, "src", "ffi.rs")).read()
+    found = 0
+    for m in re.finditer(r"typedef\s+([\w \*]+?)\(\s*\*\s*(pcv_\w+)\s*\)\s*\(([^;]*?)\)\s*;", htext, flags=re.S):
+        ret, name, params = m.group(1), m.group(2), " ".join(m.group(3).split())
+        cargs = []
+        for p in params.split(","):
+            pm = re.match(r"(.*?)(\w+)\s*$", p.strip())
+            cargs.append(c_canon(pm.group(1)))
+        rm = re.search(r'pub type %s = Option<unsafe extern "C" fn\((.*?)\)(?:\s*->\s*([^>;]+))?>;' % name, rtext)
+        assert rm, name
+        rargs = [r_canon(p.split(":", 1)[1]) for p in rm.group(1).split(",") if p.strip()]
+        assert cargs == rargs, (name, cargs, rargs)
+        assert c_canon(ret) == (r_canon(rm.group(2)) if rm.group(2) else ("void", []))
+        found += 1
+    assert found >= 1
+
+
 def test_ffi_is_what_the_generator_writes():
     import importlib.util
     import shutil

@@ -80,6 +80,14 @@ def structs(text):
         yield m.group(1), fields
 
 
+def callbacks(text):
+    """`typedef int (*pcv_x)(void* user, ...);` -> (ret, name, [(ctype, pname)])"""
+    text = strip_comments(text)
+    for m in re.finditer(r"typedef\s+([\w \*]+?)\(\s*\*\s*(pcv_\w+)\s*\)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        params = " ".join(m.group(3).split())
+        yield m.group(1).strip(), m.group(2), [split_param(p) for p in params.split(",")]
+
+
 def enums(text):
     text_nc = strip_comments(text)
     for m in re.finditer(r"enum\s*\{(.*?)\};", text_nc, flags=re.S):
@@ -115,6 +123,12 @@ def main():
         lines += ["}", ""]
     for name, value in enums(text):
         lines.append(f"pub const {name}: c_int = {value};")
+    lines.append("")
+    for ret, name, params in callbacks(text):
+        SCALARS[name] = name
+        args = ", ".join(f"{n}: {rust_type(t)}" for t, n in params)
+        r = "" if ret == "void" else f" -> {rust_type(ret)}"
+        lines.append(f"pub type {name} = Option<unsafe extern \"C\" fn({args}){r}>;")
     lines += ["", "#[link(name = \"perceive_hip\")]", "extern \"C\" {"]
     for ret, name, params in functions(text):
         args = ", ".join(f"{(n + '_') if n in KEYWORDS else n}: {rust_type(t)}" for t, n in params)
