@@ -406,6 +406,15 @@ pcv_status pcv_tokenizer_create(const char* vocab_path, int lower_case, int stri
  * pcv_tokenizer_encode / _encode_batch / _special_ids (pad = <pad>, cls = <s>, sep = </s>). */
 pcv_status pcv_tokenizer_create_bpe(const char* vocab_json_path, const char* merges_path, int add_prefix_space,
                                     pcv_tokenizer** out);
+/* AlbertTokenizer::from_file(spiece.model, lower_case, strip_accents) of rust_tokenizers (what rust-bert builds for
+ * ModelType::Albert, the ParaphraseAlbertSmallV2 variant of configs.rs:35): a SentencePiece unigram model file.
+ * Text is cleaned, NFKC-normalised, lower-cased / stripped of accents as asked, whitespace becomes U+2581 and the
+ * best-scoring segmentation is found by Viterbi; ALBERT's "<digit>," pieces are split again.  Framing is
+ * [CLS] ... [SEP], padding <pad>.  strip_accents < 0 = follow lower_case. */
+pcv_status pcv_tokenizer_create_sentencepiece(const char* model_path, int lower_case, int strip_accents, pcv_tokenizer** out);
+/* Unicode NFKC (Unicode 13 tables) of UTF-8 `text`: what the SentencePiece path normalises with.  *out_n = bytes
+ * of the result; out may be NULL to ask for the size. */
+pcv_status pcv_unicode_nfkc(const char* text, size_t n_bytes, char* out, size_t cap, size_t* out_n);
 pcv_status pcv_tokenizer_destroy(pcv_tokenizer* t);
 pcv_status pcv_tokenizer_vocab_size(pcv_tokenizer* t, int* out_n);
 /* ids of [PAD] (get_pad_id, tokenize.rs:19), [UNK], [CLS], [SEP]; -1 when the vocab lacks one */

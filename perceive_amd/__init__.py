@@ -23,7 +23,7 @@ from .model import (  # noqa: F401,E402
     minilm_l6_desc,
     save_weights,
 )
-from .tokenizer import BertTokenizer, RobertaTokenizer, TokenizedInput  # noqa: F401,E402
+from .tokenizer import AlbertTokenizer, BertTokenizer, RobertaTokenizer, TokenizedInput, nfkc  # noqa: F401,E402
 from .database import (  # noqa: F401,E402
     Database,
     Item,

@@ -150,6 +150,8 @@ SYMBOLS = {
                                       C.c_int, _I64P, _I64P]),
     "pcv_tokenizer_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "pcv_tokenizer_create_bpe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_P)]),
+    "pcv_tokenizer_create_sentencepiece": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "pcv_unicode_nfkc": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "pcv_tokenizer_destroy": (C.c_int, [_P]),
     "pcv_tokenizer_vocab_size": (C.c_int, [_P, _INTP]),
     "pcv_tokenizer_special_ids": (C.c_int, [_P, _I64P, _I64P, _I64P, _I64P]),

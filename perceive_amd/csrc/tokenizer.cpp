@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "tokenizer.h"
+#include "unicode_nfkc_tables.h"
 #include "unicode_tables.h"
 
 using namespace pcv;
@@ -86,6 +87,121 @@ void decompose(uint32_t cp, std::vector<uint32_t>& out) {
         }
     }
     out.push_back(cp);
+}
+
+// ---- NFKC (UAX #15): compatibility decomposition, canonical ordering, canonical composition ----------------
+uint32_t combining_class(uint32_t cp) {
+    if (cp < 0x300) return 0;
+    size_t lo = 0, hi = sizeof(uni::kCcc) / sizeof(uni::kCcc[0]);
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (cp < uni::kCcc[mid].lo)
+            hi = mid;
+        else if (cp > uni::kCcc[mid].hi)
+            lo = mid + 1;
+        else
+            return uni::kCcc[mid].ccc;
+    }
+    return 0;
+}
+
+uint32_t compose_pair(uint32_t a, uint32_t b) {  // 0 = no primary composite
+    if (a >= 0x1100 && a < 0x1113 && b >= 0x1161 && b < 0x1176) return 0xAC00 + ((a - 0x1100) * 21 + (b - 0x1161)) * 28;  // L + V
+    if (a >= 0xAC00 && a <= 0xD7A3 && (a - 0xAC00) % 28 == 0 && b > 0x11A7 && b < 0x11C3) return a + (b - 0x11A7);        // LV + T
+    size_t lo = 0, hi = sizeof(uni::kCompose) / sizeof(uni::kCompose[0]);
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        const uni::Compose& c = uni::kCompose[mid];
+        if (a < c.a || (a == c.a && b < c.b))
+            hi = mid;
+        else if (a > c.a || (a == c.a && b > c.b))
+            lo = mid + 1;
+        else
+            return c.c;
+    }
+    return 0;
+}
+
+struct Cp {
+    uint32_t cp;
+    int32_t pos;  // index of the originating char in the input text
+};
+
+void decompose_compat(const Cp& c, std::vector<Cp>& out) {
+    const uint32_t cp = c.cp;
+    if (cp >= 0xAC00 && cp <= 0xD7A3) {
+        const uint32_t s = cp - 0xAC00;
+        out.push_back({0x1100 + s / 588, c.pos});
+        out.push_back({0x1161 + (s % 588) / 28, c.pos});
+        if (s % 28) out.push_back({0x11A7 + s % 28, c.pos});
+        return;
+    }
+    if (cp >= 0xA0) {
+        size_t lo = 0, hi = sizeof(uni::kCompatIdx) / sizeof(uni::kCompatIdx[0]);
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (cp < uni::kCompatIdx[mid].cp)
+                hi = mid;
+            else if (cp > uni::kCompatIdx[mid].cp)
+                lo = mid + 1;
+            else {
+                for (uint32_t i = 0; i < uni::kCompatIdx[mid].n; ++i) out.push_back({uni::kCompatPool[uni::kCompatIdx[mid].off + i], c.pos});
+                return;
+            }
+        }
+    }
+    out.push_back(c);
+}
+
+// NFKC of a code-point sequence; every output code point keeps the input position it came from (a composite:
+// the position of its starter)
+std::vector<Cp> nfkc(const std::vector<Cp>& in) {
+    bool plain = true;
+    for (const Cp& c : in)
+        if (c.cp >= 0xA0) {
+            plain = false;
+            break;
+        }
+    if (plain) return in;
+    std::vector<Cp> d;
+    d.reserve(in.size() + 8);
+    for (const Cp& c : in) decompose_compat(c, d);
+    // canonical ordering: stable sort of every run of non-starters by combining class
+    for (size_t i = 0; i < d.size();) {
+        if (combining_class(d[i].cp) == 0) {
+            ++i;
+            continue;
+        }
+        size_t j = i;
+        while (j < d.size() && combining_class(d[j].cp) != 0) ++j;
+        std::stable_sort(d.begin() + (long)i, d.begin() + (long)j,
+                         [](const Cp& x, const Cp& y) { return combining_class(x.cp) < combining_class(y.cp); });
+        i = j;
+    }
+    if (d.empty()) return d;
+    // canonical composition (the reference algorithm of UAX #15)
+    size_t starter = 0, comp = 1;
+    uint32_t starter_cp = d[0].cp;
+    int last_class = (int)combining_class(starter_cp);
+    if (last_class != 0) last_class = 256;  // a leading non-starter never composes
+    for (size_t i = 1; i < d.size(); ++i) {
+        const Cp ch = d[i];
+        const int cls = (int)combining_class(ch.cp);
+        const uint32_t composite = compose_pair(starter_cp, ch.cp);
+        if (composite != 0 && (last_class < cls || last_class == 0)) {
+            d[starter].cp = composite;
+            starter_cp = composite;
+        } else {
+            if (cls == 0) {
+                starter = comp;
+                starter_cp = ch.cp;
+            }
+            last_class = cls;
+            d[comp++] = ch;
+        }
+    }
+    d.resize(comp);
+    return d;
 }
 
 bool is_whitespace(uint32_t cp) {
@@ -151,10 +267,6 @@ std::vector<uint32_t> decode_utf8(const char* s, size_t n) {
     return out;
 }
 
-struct Cp {
-    uint32_t cp;
-    int32_t pos;  // index of the originating char in the input text
-};
 using Piece = pcv::TokPiece;
 
 }  // namespace
@@ -175,6 +287,14 @@ struct pcv_tokenizer {
     mutable std::mutex bpe_mu;
     int64_t pad = -1, unk = -1, cls = -1, sep = -1, mask = -1;
     std::vector<std::pair<std::vector<uint32_t>, int64_t>> specials;  // kept whole when found in text
+    // SentencePiece unigram model (ALBERT): a trie over the code points of the NORMAL / USER_DEFINED pieces
+    bool spm = false;
+    struct TrieNode {
+        std::vector<std::pair<uint32_t, int32_t>> next;  // sorted by code point
+        int64_t id = -1;
+        float score = 0.f;
+    };
+    std::vector<TrieNode> trie;
 
     int64_t lookup(const std::string& s) const {
         auto it = vocab.find(s);
@@ -385,7 +505,157 @@ struct pcv_tokenizer {
         return out;
     }
 
+    // ---- SentencePiece unigram (AlbertTokenizer of rust_tokenizers, what rust-bert builds for ModelType::Albert) ----
+    void trie_insert(const std::vector<uint32_t>& cps, int64_t id, float score) {
+        int32_t node = 0;
+        for (uint32_t c : cps) {
+            auto& nx = trie[(size_t)node].next;
+            auto it = std::lower_bound(nx.begin(), nx.end(), std::make_pair(c, (int32_t)INT32_MIN));
+            if (it != nx.end() && it->first == c) {
+                node = it->second;
+            } else {
+                const int32_t fresh = (int32_t)trie.size();
+                nx.insert(it, {c, fresh});
+                trie.emplace_back();
+                node = fresh;
+            }
+        }
+        if (trie[(size_t)node].id < 0) {  // first occurrence wins
+            trie[(size_t)node].id = id;
+            trie[(size_t)node].score = score;
+        }
+    }
+
+    // id of the piece spelled w[a..b), or <unk>
+    int64_t trie_lookup(const std::vector<Cp>& w, size_t a, size_t b) const {
+        int32_t node = 0;
+        for (size_t j = a; j < b; ++j) {
+            const auto& nx = trie[(size_t)node].next;
+            auto it = std::lower_bound(nx.begin(), nx.end(), std::make_pair(w[j].cp, (int32_t)INT32_MIN));
+            if (it == nx.end() || it->first != w[j].cp) return unk;
+            node = it->second;
+        }
+        return trie[(size_t)node].id >= 0 ? trie[(size_t)node].id : unk;
+    }
+
+    // character span of w[a..b) in the caller's text; the inserted leading "▁" (pos -1) covers nothing
+    static Piece piece_over(const std::vector<Cp>& w, size_t a, size_t b, int64_t id) {
+        int32_t lo = INT32_MAX, hi = -1;
+        for (size_t k = a; k < b; ++k)
+            if (w[k].pos >= 0) {
+                lo = std::min(lo, w[k].pos);
+                hi = std::max(hi, w[k].pos + 1);
+            }
+        if (hi < 0) lo = hi = (b < w.size() && w[b].pos >= 0) ? w[b].pos : 0;
+        return Piece{id, lo, hi, 0};
+    }
+
+    struct Span {
+        size_t a, b;
+        int64_t id;
+    };
+
+    // Viterbi over the code points of w: the best-scoring segmentation into pieces (f32 sums, a later candidate
+    // replaces an earlier one only when strictly better); a char no piece covers becomes <unk> on its own and the
+    // running score restarts behind it (rust_tokenizers' SentencePieceModel::decode_forward)
+    std::vector<Span> unigram(const std::vector<Cp>& w) const {
+        const size_t n = w.size();
+        struct Best {
+            float score;
+            int32_t from;
+            int64_t id;
+        };
+        std::vector<Best> best(n + 1, Best{-INFINITY, -1, -1});
+        best[0].score = 0.f;
+        for (size_t i = 0; i < n; ++i) {
+            int32_t node = 0;
+            for (size_t j = i; j < n; ++j) {
+                const auto& nx = trie[(size_t)node].next;
+                auto it = std::lower_bound(nx.begin(), nx.end(), std::make_pair(w[j].cp, (int32_t)INT32_MIN));
+                if (it == nx.end() || it->first != w[j].cp) break;
+                node = it->second;
+                const TrieNode& tn = trie[(size_t)node];
+                if (tn.id >= 0) {
+                    const float sc = best[i].score + tn.score;
+                    if (sc > best[j + 1].score) best[j + 1] = Best{sc, (int32_t)i, tn.id};
+                }
+            }
+            if (best[i + 1].from < 0) best[i + 1] = Best{0.f, (int32_t)i, unk};
+        }
+        std::vector<Span> out;
+        for (size_t e = n; e > 0; e = (size_t)best[e].from) out.push_back(Span{(size_t)best[e].from, e, best[e].id});
+        std::reverse(out.begin(), out.end());
+        return out;
+    }
+
+    std::vector<Piece> tokenize_spm(const char* text, size_t n) const {
+        const std::vector<uint32_t> raw = decode_utf8(text, n);
+        std::vector<Cp> w;
+        w.reserve(raw.size() + 1);
+        for (size_t i = 0; i < raw.size(); ++i) {  // clean_text: control characters go, whitespace becomes ' '
+            const uint32_t cp = raw[i];
+            if (cp == 0 || cp == 0xFFFD || is_control(cp)) continue;
+            w.push_back({is_whitespace(cp) ? (uint32_t)' ' : cp, (int32_t)i});
+        }
+        w = nfkc(w);
+        if (lower_case || strip_accents) {
+            std::vector<Cp> v;
+            v.reserve(w.size());
+            std::vector<uint32_t> tmp;
+            for (const Cp& c : w) {
+                uint32_t cp = c.cp;
+                if (lower_case) {
+                    if (cp == 0x130) {  // the full lowercase mapping of U+0130 is two code points
+                        v.push_back({'i', c.pos});
+                        if (!strip_accents) v.push_back({0x307, c.pos});
+                        continue;
+                    }
+                    cp = to_lower(cp);
+                }
+                if (strip_accents) {
+                    tmp.clear();
+                    decompose(cp, tmp);
+                    for (uint32_t d : tmp)
+                        if (!in_ranges(uni::kMn, d)) v.push_back({d, c.pos});
+                } else {
+                    v.push_back({cp, c.pos});
+                }
+            }
+            w.swap(v);
+        }
+        for (Cp& c : w)
+            if (is_whitespace(c.cp)) c.cp = 0x2581;
+        if (w.empty() || w[0].cp != 0x2581) w.insert(w.begin(), Cp{0x2581, -1});
+        std::vector<Piece> out;
+        for (const Span& sp : unigram(w)) {
+            const size_t len = sp.b - sp.a;
+            // ALBERT's digit rule: a piece "<...digit>," is segmented again without the comma ("▁2000," -> "▁2000" ",")
+            if (len > 1 && w[sp.b - 1].cp == ',' && w[sp.b - 2].cp >= '0' && w[sp.b - 2].cp <= '9') {
+                const bool had_prefix = w[sp.a].cp == 0x2581;
+                std::vector<Cp> sub;
+                sub.push_back(Cp{0x2581, had_prefix ? w[sp.a].pos : -1});  // the dummy prefix of a fresh encode
+                for (size_t k = sp.a; k + 1 < sp.b; ++k)
+                    if (w[k].cp != 0x2581) sub.push_back(w[k]);
+                std::vector<Span> again = unigram(sub);
+                for (size_t q = 0; q < again.size(); ++q) {
+                    Span s2 = again[q];
+                    if (q == 0 && !had_prefix && sub[s2.a].cp == 0x2581) {  // the prefix was only there for the re-run
+                        if (s2.b - s2.a == 1) continue;
+                        s2.a += 1;
+                        s2.id = trie_lookup(sub, s2.a, s2.b);
+                    }
+                    out.push_back(piece_over(sub, s2.a, s2.b, s2.id));
+                }
+                out.push_back(piece_over(w, sp.b - 1, sp.b, trie_lookup(w, sp.b - 1, sp.b)));
+            } else {
+                out.push_back(piece_over(w, sp.a, sp.b, sp.id));
+            }
+        }
+        return out;
+    }
+
     std::vector<Piece> tokenize(const char* text, size_t n) const {
+        if (spm) return tokenize_spm(text, n);
         if (bpe) return tokenize_bpe(text, n);
         const std::vector<uint32_t> raw = decode_utf8(text, n);
         std::vector<Piece> out;
@@ -576,6 +846,118 @@ pcv_status pcv_tokenizer_create_bpe(const char* vocab_json_path, const char* mer
         if (t->unk < 0 || t->cls < 0 || t->sep < 0)
             PCV_FAIL(PCV_ERR_IO, "tokenizer_create_bpe: vocab %s lacks <unk>/<s>/</s>", vocab_json_path);
         *out = t.release();
+    });
+}
+
+namespace {
+// protobuf wire format, as much as sentencepiece_model.proto needs:
+//   ModelProto { repeated SentencePiece pieces = 1; ... }   SentencePiece { string piece = 1; float score = 2; Type type = 3; }
+struct Wire {
+    const uint8_t* p;
+    size_t n, i = 0;
+    const char* what;
+    bool more() const { return i < n; }
+    uint64_t varint() {
+        uint64_t v = 0;
+        for (int shift = 0; shift < 64; shift += 7) {
+            if (i >= n) PCV_FAIL(PCV_ERR_IO, "%s: truncated varint", what);
+            const uint8_t b = p[i++];
+            v |= (uint64_t)(b & 0x7f) << shift;
+            if (!(b & 0x80)) return v;
+        }
+        PCV_FAIL(PCV_ERR_IO, "%s: varint too long", what);
+    }
+    Wire bytes() {
+        const uint64_t len = varint();
+        if (len > n - i) PCV_FAIL(PCV_ERR_IO, "%s: field runs past the end", what);
+        Wire w{p + i, (size_t)len, 0, what};
+        i += (size_t)len;
+        return w;
+    }
+    void skip(int wire_type) {
+        switch (wire_type) {
+            case 0: (void)varint(); break;
+            case 1: if (n - i < 8) PCV_FAIL(PCV_ERR_IO, "%s: truncated", what); i += 8; break;
+            case 2: (void)bytes(); break;
+            case 5: if (n - i < 4) PCV_FAIL(PCV_ERR_IO, "%s: truncated", what); i += 4; break;
+            default: PCV_FAIL(PCV_ERR_IO, "%s: wire type %d is not supported", what, wire_type);
+        }
+    }
+};
+}  // namespace
+
+// AlbertTokenizer::from_file(spiece.model, lower_case, strip_accents) of rust_tokenizers (what rust-bert builds for
+// ModelType::Albert): the unigram pieces and scores of a SentencePiece model file.  The model's own normaliser
+// spec (precompiled character map) is not applied: like rust_tokenizers the text is cleaned, NFKC-normalised,
+// lower-cased, stripped of accents and its whitespace turned into "▁" before the Viterbi segmentation.
+pcv_status pcv_tokenizer_create_sentencepiece(const char* model_path, int lower_case, int strip_accents, pcv_tokenizer** out) {
+    return guarded([&] {
+        PCV_REQUIRE(model_path != nullptr && out != nullptr, "tokenizer_create_sentencepiece: NULL argument");
+        *out = nullptr;
+        std::ifstream f(model_path, std::ios::binary);
+        if (!f) PCV_FAIL(PCV_ERR_IO, "tokenizer_create_sentencepiece: cannot open %s", model_path);
+        const std::string blob((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        auto t = std::make_unique<pcv_tokenizer>();
+        t->spm = true;
+        t->lower_case = lower_case != 0;
+        t->strip_accents = strip_accents < 0 ? t->lower_case : strip_accents != 0;
+        t->trie.emplace_back();
+        Wire top{(const uint8_t*)blob.data(), blob.size(), 0, model_path};
+        int64_t id = 0;
+        while (top.more()) {
+            const uint64_t tag = top.varint();
+            if ((tag >> 3) != 1 || (tag & 7) != 2) {  // trainer / normaliser specs ...
+                top.skip((int)(tag & 7));
+                continue;
+            }
+            Wire pc = top.bytes();
+            std::string piece;
+            float score = 0.f;
+            int type = 1;  // NORMAL
+            while (pc.more()) {
+                const uint64_t ptag = pc.varint();
+                if ((ptag >> 3) == 1 && (ptag & 7) == 2) {
+                    Wire sv = pc.bytes();
+                    piece.assign((const char*)sv.p, sv.n);
+                } else if ((ptag >> 3) == 2 && (ptag & 7) == 5) {
+                    if (pc.n - pc.i < 4) PCV_FAIL(PCV_ERR_IO, "%s: truncated score", model_path);
+                    std::memcpy(&score, pc.p + pc.i, 4);  // little-endian float
+                    pc.i += 4;
+                } else if ((ptag >> 3) == 3 && (ptag & 7) == 0) {
+                    type = (int)pc.varint();
+                } else {
+                    pc.skip((int)(ptag & 7));
+                }
+            }
+            t->vocab.emplace(piece, id);
+            // NORMAL = 1 and USER_DEFINED = 4 pieces can be matched in text; <unk>, control and unused pieces cannot
+            if ((type == 1 || type == 4) && !piece.empty()) t->trie_insert(decode_utf8(piece.data(), piece.size()), id, score);
+            ++id;
+        }
+        PCV_REQUIRE(id > 0, "tokenizer_create_sentencepiece: %s holds no pieces (not a SentencePiece model?)", model_path);
+        t->pad = t->lookup("<pad>");
+        t->unk = t->lookup("<unk>");
+        t->cls = t->lookup("[CLS]");
+        t->sep = t->lookup("[SEP]");
+        t->mask = t->lookup("[MASK]");
+        if (t->unk < 0 || t->cls < 0 || t->sep < 0)
+            PCV_FAIL(PCV_ERR_IO, "tokenizer_create_sentencepiece: %s lacks <unk>/[CLS]/[SEP]", model_path);
+        *out = t.release();
+    });
+}
+
+// Unicode NFKC of a UTF-8 string (the normal form the SentencePiece path applies); out_n = bytes needed.
+pcv_status pcv_unicode_nfkc(const char* text, size_t n_bytes, char* out, size_t cap, size_t* out_n) {
+    return guarded([&] {
+        PCV_REQUIRE((text != nullptr || n_bytes == 0) && out_n != nullptr, "unicode_nfkc: NULL argument");
+        const std::vector<uint32_t> raw = decode_utf8(text, n_bytes);
+        std::vector<Cp> w(raw.size());
+        for (size_t i = 0; i < raw.size(); ++i) w[i] = Cp{raw[i], (int32_t)i};
+        std::string res;
+        for (const Cp& c : nfkc(w)) append_utf8(res, c.cp);
+        *out_n = res.size();
+        if (out != nullptr && cap >= res.size()) std::memcpy(out, res.data(), res.size());
+        else if (out != nullptr) PCV_FAIL(PCV_ERR_INVALID, "unicode_nfkc: %zu bytes needed, room for %zu", res.size(), cap);
     });
 }
 

@@ -115,3 +115,27 @@ class RobertaTokenizer(BertTokenizer):
         ids = [C.c_int64() for _ in range(4)]
         _ffi.check(_ffi.lib().pcv_tokenizer_special_ids(self._h, *[C.byref(x) for x in ids]))
         self.pad_id, self.unk_id, self.cls_id, self.sep_id = [x.value for x in ids]
+
+
+class AlbertTokenizer(BertTokenizer):
+    """TokenizerOption::from_file(Albert, spiece.model, lower_case, strip_accents) — the SentencePiece unigram
+    tokenizer of the ParaphraseAlbertSmallV2 entry of the reference's model list (configs.rs:35).  Same methods as
+    BertTokenizer; cls / sep / pad are [CLS] / [SEP] / <pad>."""
+
+    def __init__(self, model_path, lower_case=True, strip_accents=None):
+        self._h = C.c_void_p()
+        sa = -1 if strip_accents is None else (1 if strip_accents else 0)
+        _ffi.check(_ffi.lib().pcv_tokenizer_create_sentencepiece(str(model_path).encode(), 1 if lower_case else 0, sa, C.byref(self._h)))
+        ids = [C.c_int64() for _ in range(4)]
+        _ffi.check(_ffi.lib().pcv_tokenizer_special_ids(self._h, *[C.byref(x) for x in ids]))
+        self.pad_id, self.unk_id, self.cls_id, self.sep_id = [x.value for x in ids]
+
+
+def nfkc(text):
+    """Unicode NFKC as the library computes it (pcv_unicode_nfkc)."""
+    b = text.encode("utf-8")
+    n = C.c_size_t()
+    _ffi.check(_ffi.lib().pcv_unicode_nfkc(b, len(b), None, 0, C.byref(n)))
+    out = C.create_string_buffer(max(1, n.value))
+    _ffi.check(_ffi.lib().pcv_unicode_nfkc(b, len(b), out, n.value, C.byref(n)))
+    return out.raw[: n.value].decode("utf-8")

@@ -185,6 +185,8 @@ extern "C" {
     pub fn pcv_model_highlight(m: *mut pcv_model, query: *const c_char, query_bytes: usize, docs: *const *const c_char, doc_bytes: *const usize, n_docs: c_int, chunk_size: c_int, chunk_overlap: c_int, out_begin: *mut i64, out_end: *mut i64) -> c_int;
     pub fn pcv_tokenizer_create(vocab_path: *const c_char, lower_case: c_int, strip_accents: c_int, out: *mut *mut pcv_tokenizer) -> c_int;
     pub fn pcv_tokenizer_create_bpe(vocab_json_path: *const c_char, merges_path: *const c_char, add_prefix_space: c_int, out: *mut *mut pcv_tokenizer) -> c_int;
+    pub fn pcv_tokenizer_create_sentencepiece(model_path: *const c_char, lower_case: c_int, strip_accents: c_int, out: *mut *mut pcv_tokenizer) -> c_int;
+    pub fn pcv_unicode_nfkc(text: *const c_char, n_bytes: usize, out: *mut c_char, cap: usize, out_n: *mut usize) -> c_int;
     pub fn pcv_tokenizer_destroy(t: *mut pcv_tokenizer) -> c_int;
     pub fn pcv_tokenizer_vocab_size(t: *mut pcv_tokenizer, out_n: *mut c_int) -> c_int;
     pub fn pcv_tokenizer_special_ids(t: *mut pcv_tokenizer, pad: *mut i64, unk: *mut i64, cls: *mut i64, sep: *mut i64) -> c_int;

@@ -111,3 +111,72 @@ def test_byte_level_bpe_matches_the_tokenizers_library(golden_dir):
     assert len(e.token_ids) == 16 and e.token_ids[0] == 0 and e.token_ids[-1] == 2
     ids, lens = toks[False].encode_batch_ids(["Hello world", "", "x" * 300], 12, pad_id=1, n_threads=2)
     assert list(lens) == [4, 2, 12] and list(ids[1]) == [0, 2] + [1] * 10 and ids[0][3] == 2
+
+
+def test_nfkc_matches_unicodedata():
+    """The NFKC the SentencePiece path applies (rust_tokenizers' decompose_nfkc) against Python's unicodedata, which
+    the tables were generated from: every code point that has a compatibility mapping or a combining class, and
+    strings that exercise canonical reordering and composition."""
+    import random
+    import unicodedata as ud
+
+    singles = [chr(cp) for cp in range(0xA0, 0x30000) if not 0xD800 <= cp <= 0xDFFF
+               and (ud.normalize("NFKC", chr(cp)) != chr(cp) or ud.combining(chr(cp)))]
+    assert len(singles) > 5000
+    joined = "\n".join(singles)  # '\n' is a starter: one call checks them all independently
+    assert pa.nfkc(joined) == ud.normalize("NFKC", joined)
+    rnd = random.Random(1)
+    marks = [chr(c) for c in range(0x300, 0x370)] + [chr(0x5B0 + i) for i in range(20)] + list("़゙゚ཱིུᅡᆨ")
+    bases = list("aeiouAEIOUnNcCsSyYとはか가한ㄱᄀ") + ["ﬁ", "㌀", "①", "ǆ", "ｶ", "ﾞ", "Å", "Ω", "ೆ", "ෙ"]
+    for _ in range(3000):
+        s = "".join(rnd.choice(bases + marks * 2) for _ in range(rnd.randint(1, 8)))
+        assert pa.nfkc(s) == ud.normalize("NFKC", s), [hex(ord(c)) for c in s]
+    assert pa.nfkc("") == "" and pa.nfkc("plain ascii") == "plain ascii"
+
+
+def test_sentencepiece_matches_the_sentencepiece_library(golden_dir):
+    """AlbertTokenizer (SentencePiece unigram) against ids the sentencepiece library's own Viterbi produced for the
+    same prepared text + ALBERT's digit rule (tests/golden/gen_spm_golden.py), in all three normalisation modes."""
+    g = json.load(open(os.path.join(golden_dir, "spm_golden.json"), encoding="utf-8"))
+    model = os.path.join(golden_dir, "spiece.model")
+    toks = {}
+    assert len(g["cases"]) > 100
+    for c in g["cases"]:
+        key = (c["lower"], c["strip"])
+        if key not in toks:
+            toks[key] = pa.AlbertTokenizer(model, lower_case=c["lower"], strip_accents=c["strip"])
+        enc = toks[key].encode(c["text"], c["max_len"])
+        assert enc.token_ids == c["ids"], (c["text"], key, c["max_len"])
+        assert enc.special_tokens_mask == [1] + [0] * (len(c["ids"]) - 2) + [1]
+    t = toks[(True, True)]
+    assert (t.pad_id, t.unk_id, t.cls_id, t.sep_id) == (0, 1, 2, 3) and t.vocab_size == g["vocab_size"]
+    # the batch entry point writes the same ids, padded with <pad>
+    texts = sorted({c["text"] for c in g["cases"]})
+    ids, lens = t.encode_batch_ids(texts, 24, pad_id=t.pad_id, n_threads=3)
+    for row, n, text in zip(ids, lens, texts):
+        assert list(row[:n]) == t.encode(text, 24).token_ids and (row[n:] == 0).all()
+
+
+def test_sentencepiece_offsets_unknowns_and_errors(golden_dir, tmp_path):
+    t = pa.AlbertTokenizer(os.path.join(golden_dir, "spiece.model"))
+    # offsets are character positions in the caller's text; the inserted leading U+2581 covers nothing
+    text = "Hello  wörld, in 1999, ok"
+    enc = t.encode(text, 64)
+    spans = [o for o in enc.token_offsets if o is not None]
+    assert spans[0][0] == 0 and spans[-1][1] == len(text)
+    assert all(a <= b for a, b in spans) and all(spans[i][1] <= spans[i + 1][0] or spans[i][0] <= spans[i + 1][0] for i in range(len(spans) - 1))
+    covered = "".join(text[a:b] for a, b in spans)
+    assert covered.replace(" ", "") == text.replace(" ", "")  # nothing but whitespace falls between pieces
+    # a character outside the model: one <unk> per character, the pieces around it unaffected (rust_tokenizers'
+    # decode_forward restarts the score behind it; the sentencepiece library would merge a run into one <unk>)
+    a = t.encode("hello world", 64).token_ids
+    b = t.encode("hello 東京 world", 64).token_ids
+    assert b.count(t.unk_id) == 2 and [x for x in b if x != t.unk_id][:2] == a[:2] and b[-2:] == a[-2:]
+    with pytest.raises(pa.PcvError):
+        pa.AlbertTokenizer(str(tmp_path / "missing.model"))
+    (tmp_path / "junk.model").write_bytes(b"\xff\xff\xff\xff\xff\xff\xff\xff\xff\xff\xff\xff")
+    with pytest.raises(pa.PcvError):
+        pa.AlbertTokenizer(str(tmp_path / "junk.model"))
+    (tmp_path / "vocab.txt").write_text("[PAD]\n[UNK]\n")
+    with pytest.raises(pa.PcvError):  # a text vocabulary is not a SentencePiece model
+        pa.AlbertTokenizer(str(tmp_path / "vocab.txt"))
