@@ -283,7 +283,13 @@ typedef struct pcv_model_desc {
     int32_t dense_activation;    /* PCV_ACT_* of the Dense module                               */
     int32_t max_seq_length;      /* sentence_bert_config.max_seq_length (tokenize.rs:66)        */
     int32_t compute;             /* PCV_COMPUTE_*                                               */
+    /* ALBERT (ParaphraseAlbertSmallV2, configs.rs:35); all three 0 for the BERT-family models */
+    int32_t embedding_size;      /* width of the embedding tables when they are factorised (0 = hidden): a Linear
+                                    embedding_size -> hidden follows the embedding LayerNorm       */
+    int32_t shared_layers;       /* != 0: every layer runs with the weights of layer 0              */
+    int32_t hidden_act;          /* PCV_GELU_ERF (BERT's "gelu") or PCV_GELU_TANH ("gelu_new")      */
 } pcv_model_desc;
+enum { PCV_GELU_ERF = 0, PCV_GELU_TANH = 1 };
 enum { PCV_POOL_MEAN = 0, PCV_POOL_CLS = 1, PCV_POOL_MAX = 2, PCV_POOL_MEAN_SQRT_LEN = 3 };
 enum { PCV_ACT_IDENTITY = 0, PCV_ACT_TANH = 1 };
 /* F32   : every GEMM on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), the reference's dtype.
@@ -341,9 +347,9 @@ pcv_status pcv_model_last_stats(pcv_model* m, pcv_encode_stats* out);
 const char* pcv_model_type_dir_name(int model_type);
 
 /* Model::new_pretrained (model.rs:68-174) from a sentence-transformers model directory: modules.json,
- * config.json, sentence_bert_config.json, tokenizer_config.json, vocab.txt (or vocab.json + merges.txt),
- * <n>_Pooling/config.json, optional <n>_Dense/{config.json, weights}.  BERT, DistilBERT and RoBERTa
- * transformers (the ALBERT variant is refused with PCV_ERR_UNSUPPORTED).  The model owns its tokenizer.
+ * config.json, sentence_bert_config.json, tokenizer_config.json, vocab.txt (or vocab.json + merges.txt, or spiece.model),
+ * <n>_Pooling/config.json, optional <n>_Dense/{config.json, weights}.  BERT, DistilBERT, RoBERTa and ALBERT
+ * (spiece.model; one layer group) transformers: all eight variants of configs.rs:30-39.  The model owns its tokenizer.
  *   compute       PCV_COMPUTE_*
  *   load_weights  != 0: read the weights file of the directory — rust_model.ot (what the reference loads,
  *                 configs.rs:109,112), else model.safetensors, else pytorch_model.bin; see pcv_checkpoint_visit;
@@ -351,7 +357,7 @@ const char* pcv_model_type_dir_name(int model_type);
  *                 then pcv_model_check_loaded. */
 pcv_status pcv_model_create_from_dir(pcv_ctx* ctx, const char* model_dir, int compute, int load_weights, pcv_model** out);
 /* What pcv_model_create_from_dir would build, from the directory's JSON files alone (needs no GPU): the model
- * description, the transformer family (0 BERT, 1 DistilBERT, 2 RoBERTa) and the tokenizer options
+ * description, the transformer family (0 BERT, 1 DistilBERT, 2 RoBERTa, 3 ALBERT) and the tokenizer options
  * (strip_accents: -1 = follow lower_case).  Any output pointer may be NULL. */
 pcv_status pcv_model_dir_describe(const char* model_dir, pcv_model_desc* out_desc, int* out_arch, int* out_lower_case,
                                   int* out_strip_accents);

@@ -59,6 +59,9 @@ class ModelDesc(C.Structure):
         ("dense_activation", C.c_int32),
         ("max_seq_length", C.c_int32),
         ("compute", C.c_int32),
+        ("embedding_size", C.c_int32),
+        ("shared_layers", C.c_int32),
+        ("hidden_act", C.c_int32),
     ]
 
 

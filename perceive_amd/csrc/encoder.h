@@ -8,7 +8,7 @@
 
 namespace pcv {
 
-enum GemmEpilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2 };
+enum GemmEpilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_BIAS_GELU_TANH = 3 };
 
 // C[M][N] = A[M][K] * W[N][K]^T + bias (+ GELU | + resid).  N % 128 == 0, K % 32 == 0.
 // exact f32 on v_mfma_f32_32x32x2_f32.

@@ -69,6 +69,18 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(e, x);
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); }
+// "gelu_new" of ALBERT (the tanh form): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), written as x * sigmoid(2u)
+// so that one exp serves and large |x| saturate to x / 0 without overflow
+__device__ __forceinline__ float gelu_tanh(float v) {
+    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+    return v / (1.0f + __expf(-2.0f * u));
+}
+template <int EPI>
+__device__ __forceinline__ float epi_act(float v) {
+    if (EPI == EPI_BIAS_GELU) return gelu_erf(v);
+    if (EPI == EPI_BIAS_GELU_TANH) return gelu_tanh(v);
+    return v;
+}
 
 // Epilogue of the 128x128 GEMMs: one wave's 64x64 quarter (2x2 MFMA tiles) -> +bias (+GELU | +residual) ->
 // C.  Full quarters take a branch-free path.  With a per-element `if (row < M)` every element became its
@@ -98,7 +110,7 @@ __device__ __forceinline__ void store_quarter(const f32x16 (&acc)[2][2], const f
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[a][b][r] + bv[b];
-                    if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                    v = epi_act<EPI>(v);
                     if (EPI == EPI_BIAS_RESIDUAL) v += rv[a][b][r];
                     C[base0 + (size_t)(a * 32 + acc_row(r, 0)) * N + b * 32] = v;
                 }
@@ -114,7 +126,7 @@ __device__ __forceinline__ void store_quarter(const f32x16 (&acc)[2][2], const f
                 const int row = row0 + a * 32 + acc_row(r, h);
                 if (row < M) {
                     float v = acc[a][b][r] + bv[b];
-                    if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                    v = epi_act<EPI>(v);
                     if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
                     C[(size_t)row * N + col] = v;
                 }
@@ -150,7 +162,7 @@ __device__ __forceinline__ void store_quarter_wide(const f32x16 (&acc)[2][2], co
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             f32x4 v = *(const f32x4*)(tile + (rq + 4 * u) * LDE + 4 * c4) + b4;
-            if (EPI == EPI_BIAS_GELU) v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+            if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_TANH) v = f32x4{epi_act<EPI>(v.x), epi_act<EPI>(v.y), epi_act<EPI>(v.z), epi_act<EPI>(v.w)};
             if (EPI == EPI_BIAS_RESIDUAL) v += rv[u];
             *(f32x4*)(C + (size_t)(row0 + a * 32 + rq + 4 * u) * N + col0 + 4 * c4) = v;
         }
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(const float* _
         const int row = 32 * t + acc_row(r, l >> 5), col = n0 + (l & 31);
         if (row < M) {
             v += bias ? bias[col] : 0.0f;
-            if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+            v = epi_act<EPI>(v);
             if (EPI == EPI_BIAS_RESIDUAL) v += resid[(size_t)row * N + col];
             C[(size_t)row * N + col] = v;
         }
@@ -1604,6 +1616,9 @@ static void launch_skinny(hipStream_t st, const float* A, const float* W, const 
         case EPI_BIAS_GELU:
             gemm_skinny_f32_kernel<EPI_BIAS_GELU, MT, NW><<<grid, NW * 64, 0, st>>>(A, W, bias, resid, C, M, N, K);
             break;
+        case EPI_BIAS_GELU_TANH:
+            gemm_skinny_f32_kernel<EPI_BIAS_GELU_TANH, MT, NW><<<grid, NW * 64, 0, st>>>(A, W, bias, resid, C, M, N, K);
+            break;
         case EPI_BIAS_RESIDUAL:
             gemm_skinny_f32_kernel<EPI_BIAS_RESIDUAL, MT, NW><<<grid, NW * 64, 0, st>>>(A, W, bias, resid, C, M, N, K);
             break;
@@ -1646,6 +1661,7 @@ void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float
     dim3 grid((N / BN) * ((M + BM - 1) / BM));
     switch (epilogue) {
         case EPI_BIAS_GELU: gemm_f32_kernel<EPI_BIAS_GELU><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K); break;
+        case EPI_BIAS_GELU_TANH: gemm_f32_kernel<EPI_BIAS_GELU_TANH><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K); break;
         case EPI_BIAS_RESIDUAL:
             gemm_f32_kernel<EPI_BIAS_RESIDUAL><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K);
             break;
@@ -1682,6 +1698,7 @@ void launch_gemm_bf16x3(hipStream_t st, const float* A, const uint16_t* Wh, cons
     if (ws) {
         switch (epilogue) {
             case EPI_BIAS_GELU: launch_gemm_bf16x3_ws<EPI_BIAS_GELU>(st, A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;
+            case EPI_BIAS_GELU_TANH: launch_gemm_bf16x3_ws<EPI_BIAS_GELU_TANH>(st, A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;
             case EPI_BIAS_RESIDUAL: launch_gemm_bf16x3_ws<EPI_BIAS_RESIDUAL>(st, A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;
             default: launch_gemm_bf16x3_ws<EPI_BIAS>(st, A, Wh, Wm, Wl, bias, resid, C, M, N, K); break;
         }
@@ -1690,6 +1707,9 @@ void launch_gemm_bf16x3(hipStream_t st, const float* A, const uint16_t* Wh, cons
     switch (epilogue) {
         case EPI_BIAS_GELU:
             gemm_bf16x3_kernel<EPI_BIAS_GELU><<<grid, 256, 0, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K);
+            break;
+        case EPI_BIAS_GELU_TANH:
+            gemm_bf16x3_kernel<EPI_BIAS_GELU_TANH><<<grid, 256, 0, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K);
             break;
         case EPI_BIAS_RESIDUAL:
             gemm_bf16x3_kernel<EPI_BIAS_RESIDUAL><<<grid, 256, 0, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K);
@@ -1703,6 +1723,7 @@ static void launch_gemm_f16x2_n(hipStream_t st, dim3 grid, const float* A, const
                                 const float* bias, const float* resid, float* C, int M, int N, int K, int epilogue) {
     switch (epilogue) {
         case EPI_BIAS_GELU: gemm_f16x2_kernel<EPI_BIAS_GELU, NSET><<<grid, 256, 0, st>>>(A, Wh, Wl, bias, resid, C, M, N, K); break;
+        case EPI_BIAS_GELU_TANH: gemm_f16x2_kernel<EPI_BIAS_GELU_TANH, NSET><<<grid, 256, 0, st>>>(A, Wh, Wl, bias, resid, C, M, N, K); break;
         case EPI_BIAS_RESIDUAL:
             gemm_f16x2_kernel<EPI_BIAS_RESIDUAL, NSET><<<grid, 256, 0, st>>>(A, Wh, Wl, bias, resid, C, M, N, K);
             break;

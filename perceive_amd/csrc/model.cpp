@@ -53,6 +53,7 @@ void refresh_planes(pcv_model* m) {
         int over = 0;
         try {
             PCV_HIP(hipMemsetAsync(d_over, 0, sizeof(int), st));
+            if (m->map_w.p) launch_split_planes_f16(st, m->map_w.p, m->map_w.n, m->map_p.p[0], m->map_p.p[1], d_over);
             for (Layer& L : m->layers) {
                 launch_split_planes_f16(st, L.qkv_w.p, L.qkv_w.n, L.qkv_p.p[0], L.qkv_p.p[1], d_over);
                 launch_split_planes_f16(st, L.ao_w.p, L.ao_w.n, L.ao_p.p[0], L.ao_p.p[1], d_over);
@@ -70,6 +71,7 @@ void refresh_planes(pcv_model* m) {
         m->planes_dirty = false;
         return;
     }
+    if (m->map_w.p) launch_split_planes(st, m->map_w.p, m->map_w.n, m->map_p.p[0], m->map_p.p[1], m->map_p.p[2]);
     for (Layer& L : m->layers) {
         launch_split_planes(st, L.qkv_w.p, L.qkv_w.n, L.qkv_p.p[0], L.qkv_p.p[1], L.qkv_p.p[2]);
         launch_split_planes(st, L.ao_w.p, L.ao_w.n, L.ao_p.p[0], L.ao_p.p[1], L.ao_p.p[2]);
@@ -93,18 +95,27 @@ void gemm(pcv_model* m, const float* A, const Tensor& W, const Planes& P, const 
 void build_tensors(pcv_model* m) {
     const pcv_model_desc& d = m->d;
     const int64_t H = d.hidden, F = d.intermediate;
-    m->word = alloc_tensor(m, (int64_t)d.vocab_size * H);
-    m->pos = alloc_tensor(m, (int64_t)d.max_positions * H);
-    m->type = alloc_tensor(m, (int64_t)d.type_vocab * H);
-    m->eln_w = alloc_tensor(m, H);
-    m->eln_b = alloc_tensor(m, H);
+    const int64_t E = d.embedding_size > 0 ? d.embedding_size : H;  // ALBERT factorises the embedding tables
+    m->word = alloc_tensor(m, (int64_t)d.vocab_size * E);
+    m->pos = alloc_tensor(m, (int64_t)d.max_positions * E);
+    m->type = alloc_tensor(m, (int64_t)d.type_vocab * E);
+    m->eln_w = alloc_tensor(m, E);
+    m->eln_b = alloc_tensor(m, E);
     reg(m, "embeddings.word_embeddings.weight", m->word.p, m->word.n);
     reg(m, "embeddings.position_embeddings.weight", m->pos.p, m->pos.n);
     reg(m, "embeddings.token_type_embeddings.weight", m->type.p, m->type.n);
-    reg(m, "embeddings.LayerNorm.weight", m->eln_w.p, H);
-    reg(m, "embeddings.LayerNorm.bias", m->eln_b.p, H);
-    m->layers.resize(d.layers);
-    for (int i = 0; i < d.layers; ++i) {
+    reg(m, "embeddings.LayerNorm.weight", m->eln_w.p, E);
+    reg(m, "embeddings.LayerNorm.bias", m->eln_b.p, E);
+    if (d.embedding_size > 0) {
+        m->map_w = alloc_tensor(m, H * E);
+        m->map_b = alloc_tensor(m, H);
+        if (d.compute != PCV_COMPUTE_F32) alloc_planes(m, m->map_p, H * E);
+        reg(m, "encoder.embedding_hidden_mapping_in.weight", m->map_w.p, H * E);
+        reg(m, "encoder.embedding_hidden_mapping_in.bias", m->map_b.p, H);
+    }
+    const int n_weight_sets = d.shared_layers ? 1 : d.layers;  // ALBERT: one set of layer weights, run `layers` times
+    m->layers.resize(n_weight_sets);
+    for (int i = 0; i < n_weight_sets; ++i) {
         Layer& L = m->layers[i];
         L.qkv_w = alloc_tensor(m, 3 * H * H);
         L.qkv_b = alloc_tensor(m, 3 * H);
@@ -259,8 +270,15 @@ void launch_forward(pcv_model* m, int B, int L) {
     const int H = d.hidden, F = d.intermediate;
     const int T = B * L;
     hipStream_t st = m->ctx->stream;
-    launch_embed_ln(st, m->d_ids, m->d_mask, B, L, H, d.vocab_size, m->word.p, m->pos.p, m->type.p, m->eln_w.p,
-                    m->eln_b.p, d.layer_norm_eps, m->hidden, m->mask_add, m->mask01);
+    if (d.embedding_size > 0) {  // embeddings + LayerNorm at the narrow width, then the Linear up to hidden
+        launch_embed_ln(st, m->d_ids, m->d_mask, B, L, d.embedding_size, d.vocab_size, m->word.p, m->pos.p, m->type.p, m->eln_w.p,
+                        m->eln_b.p, d.layer_norm_eps, m->tmp, m->mask_add, m->mask01);
+        gemm(m, m->tmp, m->map_w, m->map_p, m->map_b.p, nullptr, m->hidden, T, H, d.embedding_size, EPI_BIAS);
+    } else {
+        launch_embed_ln(st, m->d_ids, m->d_mask, B, L, H, d.vocab_size, m->word.p, m->pos.p, m->type.p, m->eln_w.p,
+                        m->eln_b.p, d.layer_norm_eps, m->hidden, m->mask_add, m->mask01);
+    }
+    const int act_epi = d.hidden_act == PCV_GELU_TANH ? EPI_BIAS_GELU_TANH : EPI_BIAS_GELU;
     const bool dbg = m->dbg != nullptr && T <= kDebugTokenLimit;
     auto snap = [&](int layer) {
         if (dbg)
@@ -269,7 +287,7 @@ void launch_forward(pcv_model* m, int B, int L) {
     };
     snap(0);
     for (int ly = 0; ly < d.layers; ++ly) {
-        const Layer& W = m->layers[ly];
+        const Layer& W = m->layers[d.shared_layers ? 0 : ly];
         gemm(m, m->hidden, W.qkv_w, W.qkv_p, W.qkv_b.p, nullptr, m->qkv, T, 3 * H, H, EPI_BIAS);
         if (!(d.compute == PCV_COMPUTE_F16X2 && launch_attention_f16(st, m->qkv, m->mask_add, m->ctxbuf, B, L, H, d.heads)))
             launch_attention(st, m->qkv, m->mask_add, m->ctxbuf, B, L, H, d.heads);
@@ -280,7 +298,7 @@ void launch_forward(pcv_model* m, int B, int L) {
             gemm(m, m->ctxbuf, W.ao_w, W.ao_p, W.ao_b.p, m->hidden, m->tmp, T, H, H, EPI_BIAS_RESIDUAL);
             launch_layer_norm(st, m->tmp, T, H, W.ln1_w.p, W.ln1_b.p, d.layer_norm_eps);
         }
-        gemm(m, m->tmp, W.i_w, W.i_p, W.i_b.p, nullptr, m->ff, T, F, H, EPI_BIAS_GELU);
+        gemm(m, m->tmp, W.i_w, W.i_p, W.i_b.p, nullptr, m->ff, T, F, H, act_epi);
         if (!(fuse && launch_gemm_f32_ln(st, m->ff, W.f_w.p, W.f_b.p, m->tmp, W.ln2_w.p, W.ln2_b.p, d.layer_norm_eps, m->hidden,
                                          T, H, F))) {
             gemm(m, m->ff, W.f_w, W.f_p, W.f_b.p, m->tmp, m->hidden, T, H, F, EPI_BIAS_RESIDUAL);
@@ -367,6 +385,7 @@ void finish_stats(pcv_model* m) {
     const double H = m->d.hidden, F = m->d.intermediate, L = m->last_L, T = (double)m->last_B * m->last_L;
     m->stats.total_ms = ms;
     m->stats.flops = T * m->d.layers * (8.0 * H * H + 4.0 * H * F + 4.0 * L * H);
+    if (m->d.embedding_size > 0) m->stats.flops += 2.0 * T * H * m->d.embedding_size;
     m->stats.batch = m->last_B;
     m->stats.seq_len = m->last_L;
 }
@@ -406,6 +425,9 @@ void pcv_model_desc_minilm_l6(pcv_model_desc* d) {
     d->dense_activation = PCV_ACT_IDENTITY;
     d->max_seq_length = 256;
     d->compute = PCV_COMPUTE_F32;
+    d->embedding_size = 0;
+    d->shared_layers = 0;
+    d->hidden_act = PCV_GELU_ERF;
 }
 
 pcv_status pcv_model_create(pcv_ctx* ctx, const pcv_model_desc* desc, const char* weights_path,
@@ -423,6 +445,9 @@ pcv_status pcv_model_create(pcv_ctx* ctx, const pcv_model_desc* desc, const char
         if (d.hidden % d.heads != 0 || (d.hidden / d.heads != 32 && d.hidden / d.heads != 64))
             PCV_FAIL(PCV_ERR_UNSUPPORTED, "model_create: head dimension %d not supported (32 or 64)",
                      d.heads ? d.hidden / d.heads : 0);
+        if (d.embedding_size < 0 || d.embedding_size % 128 != 0 || d.embedding_size > d.hidden)
+            PCV_FAIL(PCV_ERR_UNSUPPORTED, "model_create: embedding_size %d must be a multiple of 128 up to hidden (0 = hidden)", d.embedding_size);
+        PCV_REQUIRE(d.hidden_act == PCV_GELU_ERF || d.hidden_act == PCV_GELU_TANH, "model_create: unknown hidden_act %d", d.hidden_act);
         PCV_REQUIRE(d.pooling >= PCV_POOL_MEAN && d.pooling <= PCV_POOL_MEAN_SQRT_LEN, "model_create: unknown pooling %d",
                     d.pooling);
         PCV_REQUIRE(d.dense_out >= 0 && d.dense_out <= 1024, "model_create: dense_out %d outside [0,1024]", d.dense_out);

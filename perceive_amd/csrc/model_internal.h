@@ -36,6 +36,8 @@ struct pcv_model {
     pcv_ctx* ctx = nullptr;
     pcv_model_desc d{};
     pcv::Tensor word, pos, type, eln_w, eln_b, dense_w, dense_b;
+    pcv::Tensor map_w, map_b;  // ALBERT: embedding_hidden_mapping_in [hidden][embedding_size], [hidden]
+    pcv::Planes map_p;
     std::vector<pcv::Layer> layers;
     // name -> (device pointer, element count): HF / rust-bert tensor names
     std::map<std::string, pcv::Tensor> table;
@@ -64,7 +66,7 @@ struct pcv_model {
     pcv_tokenizer* tok = nullptr;
     bool own_tok = false;
     int64_t pad_id = 0;                       // get_pad_id().unwrap_or(0), tokenize.rs:19
-    int arch = 0;                             // 0 bert, 1 distilbert, 2 roberta: how checkpoint tensor names map
+    int arch = 0;                             // 0 bert, 1 distilbert, 2 roberta, 3 albert: how checkpoint tensor names map
     int pos_shift = 0;                        // rows of the position table skipped (RoBERTa: padding_idx + 1)
     std::map<std::string, bool> loaded;       // tensors provided so far by pcv_model_load_hf_tensor
     // highlight scratch (grown on demand)

@@ -246,7 +246,7 @@ std::string last_component(const std::string& dotted) {
 }
 
 // ---- checkpoint tensor names -> the names of the encoder graph (model.cpp) -----------------------------
-enum Arch { ARCH_BERT = 0, ARCH_DISTILBERT = 1, ARCH_ROBERTA = 2 };
+enum Arch { ARCH_BERT = 0, ARCH_DISTILBERT = 1, ARCH_ROBERTA = 2, ARCH_ALBERT = 3 };
 
 void replace_all(std::string& s, const char* a, const char* b) {
     const size_t la = std::strlen(a), lb = std::strlen(b);
@@ -254,7 +254,7 @@ void replace_all(std::string& s, const char* a, const char* b) {
 }
 
 std::string graph_name(int arch, std::string k) {
-    for (const char* pre : {"bert.", "roberta.", "distilbert."})
+    for (const char* pre : {"bert.", "roberta.", "distilbert.", "albert."})
         if (k.compare(0, std::strlen(pre), pre) == 0) k = k.substr(std::strlen(pre));
     if (arch == ARCH_DISTILBERT) {  // the same post-LayerNorm encoder under DistilBertModel's names
         replace_all(k, "transformer.layer.", "encoder.layer.");
@@ -266,6 +266,19 @@ std::string graph_name(int arch, std::string k) {
         replace_all(k, ".ffn.lin1.", ".intermediate.dense.");
         replace_all(k, ".ffn.lin2.", ".output.dense.");
         replace_all(k, ".output_layer_norm.", ".output.LayerNorm.");
+    }
+    if (arch == ARCH_ALBERT) {  // one shared layer (group 0, inner layer 0) under AlbertModel's names
+        replace_all(k, "encoder.albert_layer_groups.0.albert_layers.0.", "encoder.layer.0.");
+        if (k.compare(0, 16, "encoder.layer.0.") == 0) {
+            replace_all(k, ".attention.query.", ".attention.self.query.");
+            replace_all(k, ".attention.key.", ".attention.self.key.");
+            replace_all(k, ".attention.value.", ".attention.self.value.");
+            replace_all(k, ".attention.dense.", ".attention.output.dense.");
+            replace_all(k, ".attention.LayerNorm.", ".attention.output.LayerNorm.");
+            replace_all(k, ".ffn_output.", ".output.dense.");
+            replace_all(k, ".ffn.", ".intermediate.dense.");
+            replace_all(k, ".full_layer_layer_norm.", ".output.LayerNorm.");
+        }
     }
     return k;
 }
@@ -604,9 +617,12 @@ ParsedDir parse_model_dir(const char* model_dir) {
     if (mt == "bert") pd.arch = ARCH_BERT;
     else if (mt == "distilbert") pd.arch = ARCH_DISTILBERT;
     else if (mt == "roberta") pd.arch = ARCH_ROBERTA;
-    else PCV_FAIL(PCV_ERR_UNSUPPORTED, "%s: transformer type '%s' is not supported (BERT, DistilBERT and RoBERTa are)", model_dir, mt.c_str());
-    const std::string act = cfg.str("hidden_act", cfg.str("activation", "gelu"));
-    if (act != "gelu") PCV_FAIL(PCV_ERR_UNSUPPORTED, "%s: activation '%s' is not supported (erf GELU only)", model_dir, act.c_str());
+    else if (mt == "albert") pd.arch = ARCH_ALBERT;
+    else PCV_FAIL(PCV_ERR_UNSUPPORTED, "%s: transformer type '%s' is not supported (BERT, DistilBERT, RoBERTa and ALBERT are)", model_dir, mt.c_str());
+    const std::string act = cfg.str("hidden_act", cfg.str("activation", pd.arch == ARCH_ALBERT ? "gelu_new" : "gelu"));
+    if (act == "gelu") d.hidden_act = PCV_GELU_ERF;
+    else if (act == "gelu_new" || act == "gelu_pytorch_tanh" || act == "gelu_fast") d.hidden_act = PCV_GELU_TANH;  // one formula, three names
+    else PCV_FAIL(PCV_ERR_UNSUPPORTED, "%s: activation '%s' is not supported (gelu and gelu_new are)", model_dir, act.c_str());
     d.vocab_size = (int)cfg.num("vocab_size", 0);
     d.max_positions = (int)cfg.num("max_position_embeddings", 0);
     if (pd.arch == ARCH_DISTILBERT) {
@@ -624,6 +640,14 @@ ParsedDir parse_model_dir(const char* model_dir) {
         d.intermediate = (int)cfg.num("intermediate_size", 0);
         d.type_vocab = (int)cfg.num("type_vocab_size", 2);
         d.layer_norm_eps = (float)cfg.num("layer_norm_eps", 1e-12);
+    }
+    if (pd.arch == ARCH_ALBERT) {
+        // factorised embeddings and one set of layer weights run num_hidden_layers times
+        d.embedding_size = (int)cfg.num("embedding_size", 128);
+        d.shared_layers = 1;
+        const int groups = (int)cfg.num("num_hidden_groups", 1), inner = (int)cfg.num("inner_group_num", 1);
+        if (groups != 1 || inner != 1)
+            PCV_FAIL(PCV_ERR_UNSUPPORTED, "%s: ALBERT with %d layer groups of %d inner layers is not supported (1 x 1 is)", model_dir, groups, inner);
     }
     if (pd.arch == ARCH_ROBERTA) {
         // RoBERTa numbers positions from padding_idx + 1 (pad tokens sit at padding_idx): for right-padded
@@ -698,6 +722,8 @@ pcv_status pcv_model_create_from_dir(pcv_ctx* ctx, const char* model_dir, int co
         pcv_tokenizer* tok = nullptr;
         pcv_status st = pd.arch == ARCH_ROBERTA
                             ? pcv_tokenizer_create_bpe((dir + "vocab.json").c_str(), (dir + "merges.txt").c_str(), pd.add_prefix_space ? 1 : 0, &tok)
+                        : pd.arch == ARCH_ALBERT
+                            ? pcv_tokenizer_create_sentencepiece((dir + "spiece.model").c_str(), pd.lower ? 1 : 0, pd.strip_accents, &tok)
                             : pcv_tokenizer_create((dir + "vocab.txt").c_str(), pd.lower ? 1 : 0, pd.strip_accents, &tok);
         if (st != PCV_OK) throw Error{st};
         pcv_model* m = nullptr;

@@ -16,7 +16,7 @@ from .model import Model, ModelError, SentenceEmbeddingsModelType
 
 _POOL = {_ffi.POOL_MEAN: "mean", _ffi.POOL_CLS: "cls", _ffi.POOL_MAX: "max", _ffi.POOL_MEAN_SQRT_LEN: "mean_sqrt_len"}
 _ACT = {_ffi.ACT_IDENTITY: "identity", _ffi.ACT_TANH: "tanh"}
-_ARCH = {0: "bert", 1: "distilbert", 2: "roberta"}
+_ARCH = {0: "bert", 1: "distilbert", 2: "roberta", 3: "albert"}
 
 
 def model_dir_name(model_type):
@@ -25,8 +25,7 @@ def model_dir_name(model_type):
     return name.decode() if name else None
 
 
-MODEL_DIRS = {mt: model_dir_name(mt) for mt in SentenceEmbeddingsModelType
-              if mt is not SentenceEmbeddingsModelType.ParaphraseAlbertSmallV2}
+MODEL_DIRS = {mt: model_dir_name(mt) for mt in SentenceEmbeddingsModelType}
 
 
 def parse_model_dir(directory):
@@ -41,7 +40,8 @@ def parse_model_dir(directory):
     desc = dict(vocab_size=d.vocab_size, hidden=d.hidden, layers=d.layers, heads=d.heads, intermediate=d.intermediate,
                 max_positions=d.max_positions, type_vocab=d.type_vocab, layer_norm_eps=d.layer_norm_eps, pooling=_POOL[d.pooling],
                 normalize=bool(d.normalize), dense_out=d.dense_out, dense_activation=_ACT[d.dense_activation],
-                max_seq_length=d.max_seq_length, arch=_ARCH[arch.value])
+                max_seq_length=d.max_seq_length, arch=_ARCH[arch.value], embedding_size=d.embedding_size,
+                shared_layers=bool(d.shared_layers), hidden_act="gelu_new" if d.hidden_act else "gelu")
     tok = dict(lower_case=bool(lower.value), strip_accents=None if strip.value < 0 else bool(strip.value))
     dense = dict(out=d.dense_out, activation=_ACT[d.dense_activation]) if d.dense_out else None
     return desc, tok, dense

@@ -73,6 +73,9 @@ pub struct pcv_model_desc {
     pub dense_activation: i32,
     pub max_seq_length: i32,
     pub compute: i32,
+    pub embedding_size: i32,
+    pub shared_layers: i32,
+    pub hidden_act: i32,
 }
 
 #[repr(C)]
@@ -95,6 +98,8 @@ pub const PCV_METRIC_DOT: c_int = 1;
 pub const PCV_KERNEL_AUTO: c_int = 0;
 pub const PCV_KERNEL_WAVE: c_int = 1;
 pub const PCV_KERNEL_MFMA: c_int = 2;
+pub const PCV_GELU_ERF: c_int = 0;
+pub const PCV_GELU_TANH: c_int = 1;
 pub const PCV_POOL_MEAN: c_int = 0;
 pub const PCV_POOL_CLS: c_int = 1;
 pub const PCV_POOL_MAX: c_int = 2;

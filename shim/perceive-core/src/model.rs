@@ -71,8 +71,7 @@ impl Model {
         let dir = model_type.directory();
         let c_dir = CString::new(dir.to_string_lossy().as_bytes()).map_err(|e| ModelError::ModelPanic(eyre::eyre!(e)))?;
         let mut handle: *mut ffi::pcv_model = ptr::null_mut();
-        // weights: model.safetensors read by the library.  (rust_model.ot, the reference's file, would go
-        // through load_weights = 0 + pcv_model_load_hf_tensor from the host's own reader.)
+        // weights: rust_model.ot (configs.rs:109), else model.safetensors / pytorch_model.bin, read by the library
         hip::check(unsafe { ffi::pcv_model_create_from_dir(ctx.0, c_dir.as_ptr(), ffi::PCV_COMPUTE_F32, 1, &mut handle) })?;
         let mut dim: i32 = 0;
         if let Err(e) = hip::check(unsafe { ffi::pcv_model_output_dim(handle, &mut dim) }) {

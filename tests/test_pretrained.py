@@ -63,12 +63,18 @@ def test_parse_model_dir(tmp_path, golden_dir):
     assert desc["pooling"] == "mean" and desc["normalize"] is True and desc["max_seq_length"] == 32
     assert desc["dense_out"] == 64 and desc["dense_activation"] == "tanh"
     assert tok == {"lower_case": True, "strip_accents": None}  # tokenizer_config wins over sentence_bert_config
-    # unsupported architectures fail loudly
+    assert desc["arch"] == "bert" and desc["embedding_size"] == 0 and not desc["shared_layers"] and desc["hidden_act"] == "gelu"
+    # an ALBERT config: factorised embeddings, shared layer weights, gelu_new
     cfg = json.loads((d / "config.json").read_text())
-    cfg["model_type"] = "albert"
+    cfg.update(model_type="albert", embedding_size=128, num_hidden_groups=1, inner_group_num=1, hidden_act="gelu_new")
     (d / "config.json").write_text(json.dumps(cfg))
-    with pytest.raises(pa.ModelError):
-        pa.parse_model_dir(str(d))
+    desc, _, _ = pa.parse_model_dir(str(d))
+    assert desc["arch"] == "albert" and desc["embedding_size"] == 128 and desc["shared_layers"] and desc["hidden_act"] == "gelu_new"
+    # unsupported architectures / shapes fail loudly
+    for bad in (dict(model_type="t5"), dict(num_hidden_groups=2), dict(hidden_act="relu")):
+        (d / "config.json").write_text(json.dumps({**cfg, **bad}))
+        with pytest.raises(pa.ModelError):
+            pa.parse_model_dir(str(d))
     with pytest.raises(pa.ModelError):
         pa.parse_model_dir(str(tmp_path / "nope"))
 
@@ -100,8 +106,6 @@ def test_new_pretrained_matches_hf(ctx, tmp_path, golden_dir, fmt, with_dense):
     m.close()
     with pytest.raises(pa.ModelError):  # no such directory
         pa.new_pretrained(ctx, pa.SentenceEmbeddingsModelType.MsMarcoDistilbertDotV5, model_data_dir=str(tmp_path))
-    with pytest.raises(pa.ModelError):  # the ALBERT variant is not built
-        pa.new_pretrained(ctx, pa.SentenceEmbeddingsModelType.ParaphraseAlbertSmallV2, model_data_dir=str(tmp_path))
 
 
 def make_distilbert_dir(tmp_path, golden_dir, name, pooling_cls, normalize):
@@ -214,4 +218,75 @@ def test_roberta_checkpoint_matches_hf(ctx, tmp_path, golden_dir):
         pooled = (h * msk).sum(1) / msk.sum(1).clamp_min(1e-9)
         ref = (pooled / pooled.norm(dim=1, keepdim=True).clamp_min(1e-12)).numpy()
     assert np.abs(out - ref).max() < 1e-4
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compute", ["f32", "bf16x3", "f16x2"])
+def test_albert_checkpoint_matches_hf(ctx, tmp_path, golden_dir, compute):
+    # ModelType::Albert (paraphrase-albert-small-v2, configs.rs:35): SentencePiece tokenizer, embeddings at width 128
+    # mapped up to hidden, ONE set of layer weights run num_hidden_layers times, gelu_new.  Expected values: HF
+    # AlbertModel on ids the sentencepiece library makes from the prepared text (tests/golden/gen_spm_golden.py).
+    import sys
+
+    import sentencepiece as spm
+    import torch
+    from transformers import AlbertConfig, AlbertModel
+
+    sys.path.insert(0, golden_dir)
+    try:
+        import gen_spm_golden as gen
+    finally:
+        sys.path.remove(golden_dir)
+    torch.manual_seed(13)
+    mt = pa.SentenceEmbeddingsModelType.ParaphraseAlbertSmallV2
+    d = tmp_path / pa.pretrained.MODEL_DIRS[mt]
+    assert d.name == "paraphrase-albert-small-v2"
+    d.mkdir(parents=True)
+    shutil.copy(os.path.join(golden_dir, "spiece.model"), d / "spiece.model")
+    sp = spm.SentencePieceProcessor(model_file=str(d / "spiece.model"))
+    cfg = AlbertConfig(vocab_size=sp.get_piece_size(), embedding_size=128, hidden_size=256, num_hidden_layers=3, num_hidden_groups=1,
+                       inner_group_num=1, num_attention_heads=4, intermediate_size=512, max_position_embeddings=64, type_vocab_size=2,
+                       layer_norm_eps=1e-12, hidden_act="gelu_new", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                       classifier_dropout_prob=0.0, pad_token_id=0, bos_token_id=2, eos_token_id=3)
+    hf = AlbertModel(cfg, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for k, v in hf.state_dict().items():
+            if "LayerNorm.weight" in k or "layer_norm.weight" in k:
+                v.copy_(1.0 + 0.2 * torch.randn_like(v))
+            elif k.endswith("bias"):
+                v.copy_(0.1 * torch.randn_like(v))
+            elif v.dim() == 2:
+                v.mul_(3.0)
+    hf.save_pretrained(d, safe_serialization=True)
+    (d / "1_Pooling").mkdir()
+    (d / "1_Pooling" / "config.json").write_text(json.dumps({
+        "word_embedding_dimension": 256, "pooling_mode_cls_token": False, "pooling_mode_mean_tokens": True,
+        "pooling_mode_max_tokens": False, "pooling_mode_mean_sqrt_len_tokens": False}))
+    (d / "modules.json").write_text(json.dumps([
+        {"idx": 0, "name": "0", "path": "", "type": "sentence_transformers.models.Transformer"},
+        {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]))
+    (d / "sentence_bert_config.json").write_text(json.dumps({"max_seq_length": 48, "do_lower_case": False}))
+    (d / "tokenizer_config.json").write_text(json.dumps({"do_lower_case": True, "keep_accents": False, "remove_space": True}))
+    m = pa.new_pretrained(ctx, mt, model_data_dir=str(tmp_path), compute=compute)
+    assert m.model_type.model_id == 4 and m.pad_token_id == 0
+    assert m.desc.embedding_size == 128 and m.desc.shared_layers == 1 and m.desc.hidden_act == 1 and m.desc.layers == 3
+    texts = ["Hello world", "The search of embeddings, really? In 1999, about 1,000 items", "returns a new string " * 20, "Café naïve"]
+    out = m.encode(texts)
+    rows = []
+    for t in texts:
+        pieces = gen.albert_pieces(sp, gen.prepare(t, True, True))
+        rows.append([2] + [sp.piece_to_id(p) for p in pieces][:46] + [3])
+    L = max(len(r) for r in rows)
+    ids = torch.tensor([r + [0] * (L - len(r)) for r in rows])
+    am = (ids != 0).long()
+    with torch.no_grad():
+        h = hf(input_ids=ids, attention_mask=am).last_hidden_state
+        msk = am.unsqueeze(-1).float()
+        ref = ((h * msk).sum(1) / msk.sum(1).clamp_min(1e-9)).numpy()
+    assert out.shape == ref.shape == (4, 256)
+    assert np.abs(out - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    # highlight runs on the SentencePiece offsets as on any other tokenizer
+    hl = m.highlight("string", ["nothing here", "it returns a new string object with the characters reversed and joined " * 3])
+    assert len(hl) == 2
     m.close()
