@@ -156,6 +156,18 @@ pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel);
  * lists).  A pass that needs more repeats itself with larger lists (pcv_scan_stats.overflow_reruns). */
 pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candidates);
 
+/* Screening copy: next to the f32 rows a segment can hold the same rows already scaled and rounded to bf16 —
+ * exactly the operand the coarse (bf16 MFMA) screen builds from them.  The scan then streams 2 bytes per feature
+ * instead of 4 and reads f32 rows only for the rows that pass the coarse screen; results are identical (same
+ * screening arithmetic, same exact rescoring).  Costs half as much HBM again (100M x 384: 153.6 + 76.8 GB).
+ *   PCV_SCREEN_COPY_AUTO (default): built at finalize; given up — for good, on this searcher — when an allocation
+ *                                   for rows or for a copy fails (the f32 rows are scanned then)
+ *   PCV_SCREEN_COPY_ON            : a failed copy allocation is an error at finalize
+ *   PCV_SCREEN_COPY_OFF           : never built; existing copies are freed
+ * Takes effect at the next finalize (OFF: at once). */
+enum { PCV_SCREEN_COPY_OFF = 0, PCV_SCREEN_COPY_ON = 1, PCV_SCREEN_COPY_AUTO = 2 };
+pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode);
+
 /* Searcher::search_vector (search.rs:157-182), batched over `n_queries` query vectors.
  *   queries      [n_queries][dim] f32
  *   source_ids   sources to search (search.rs:166 filter): NULL = all sources (n_sources ignored);
@@ -258,9 +270,10 @@ typedef struct pcv_scan_stats {
     int32_t scan_launches;       /* scan kernel launches (reruns after overflow included)        */
     int32_t overflow_reruns;     /* passes repeated because a candidate list overflowed          */
     int32_t kernel_used;         /* PCV_KERNEL_WAVE or PCV_KERNEL_MFMA                           */
-    int32_t reserved;
+    int32_t screening_copy;      /* 1: the scan streamed the bf16 screening copies (last pass)   */
     float host_enqueue_ms;       /* host time spent queueing the passes (copies + launches)      */
     float host_wait_ms;          /* host time blocked until the stream had drained               */
+    int64_t bytes_streamed;      /* rows_scanned * dim * (2 with the screening copy, else 4)     */
 } pcv_scan_stats;
 pcv_status pcv_searcher_last_stats(pcv_searcher* s, pcv_scan_stats* out);
 

@@ -37,9 +37,10 @@ class ScanStats(C.Structure):
         ("scan_launches", C.c_int32),
         ("overflow_reruns", C.c_int32),
         ("kernel_used", C.c_int32),
-        ("reserved", C.c_int32),
+        ("screening_copy", C.c_int32),
         ("host_enqueue_ms", C.c_float),
         ("host_wait_ms", C.c_float),
+        ("bytes_streamed", C.c_int64),
     ]
 
 
@@ -113,6 +114,7 @@ SYMBOLS = {
     "pcv_searcher_source_num_rows": (C.c_int, [_P, C.c_int64, _I64P]),
     "pcv_searcher_get_rows": (C.c_int, [_P, _I64P, C.c_int64, _F32P, _I64P]),
     "pcv_searcher_set_kernel": (C.c_int, [_P, C.c_int]),
+    "pcv_searcher_set_screening_copy": (C.c_int, [_P, C.c_int]),
     "pcv_searcher_set_candidate_capacity": (C.c_int, [_P, C.c_uint32]),
     "pcv_searcher_search": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
     "pcv_searcher_set_shard_offset": (C.c_int, [_P, C.c_int64]),

@@ -7,6 +7,12 @@
 //   so one wave instruction (lanes r=0..31 | h=0,1) reads two contiguous 512-byte runs and each
 //   lane receives exactly the 8 consecutive features an MFMA 32x32x16 A-fragment wants.
 //   Same bytes as row-major f32 (plus zero padding), permuted at 16-byte granularity.
+//
+// Screening copy (optional, one per segment): the same rows, already multiplied by their scale and rounded to
+// bf16 — exactly the A operand the MFMA screen builds from the f32 rows — in 16-byte pieces of 8 features:
+//       blk16[(b * D8 + f8) * 32 + r]          D8 = Dp/8
+// The coarse screen then streams 2 bytes per feature instead of 4; the f32 rows are read only for the coarse
+// survivors (fine screen) and the finalists (exact rescoring), so results are unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,6 +43,7 @@ struct SegDesc {
     uint32_t nblocks;
     uint32_t blk0;       // first block index of this segment in the launch's block numbering
     uint32_t pad;
+    const uint4* blk16;  // screening copy (see below), or nullptr
 };
 
 struct pcv_hit_dev {
@@ -75,7 +82,8 @@ struct ScanParams {
     pcv_hit_dev* flag_rec;   // overflow record behind a shard's hit list (device), or nullptr
     uint32_t cand_cap;
     uint32_t seed_blocks;    // leading blocks of segment 0 ranked by the seed kernel
-    uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bits 8..15: workgroups per CU override (tuning)
+    uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bit 4: every segment has its screening
+                             // copy, stream that; bits 8..15: workgroups per CU override; bits 16..23: seed workgroups; bits 24..27: chunk buffers override (tuning)
     float eps16, eps32;      // |s - c| bounds of the bf16 / f32 screening scores, relative to |q||x|
     float max_norm;          // upper bound of |x| over the corpus (dot metric margins)
 };
@@ -97,6 +105,9 @@ void launch_iota_ids(hipStream_t st, int64_t* ids, int64_t first, int64_t n);
 // scales of the rows in blocks [first_block, nblocks) of a segment
 void launch_row_scales(hipStream_t st, const float4* blk, uint32_t first_block, uint32_t nblocks, uint32_t nrows, int D4,
                        int metric, float* scale, uint32_t* max_norm_bits);
+// screening copy of the rows in blocks [first_block, nblocks): bf16(row * scale), zeros where scale == 0
+void launch_coarse_pack(hipStream_t st, const float4* blk, const float* scale, uint4* blk16, uint32_t first_block, uint32_t nblocks,
+                        int D4);
 void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nrows, uint32_t row0, int D, int D4, uint64_t seed,
                        int64_t first_row, int normalize, uint32_t n_clusters, float noise);
 void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const int64_t* d_pos, int64_t n, int D,

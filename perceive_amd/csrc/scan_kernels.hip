@@ -89,6 +89,7 @@ struct SegCursor {
     uint32_t begin = 0, end = 0;  // launch-wide block range of segment si
     const float4* blk = nullptr;
     const float* scale = nullptr;
+    const uint4* blk16 = nullptr;
 };
 __device__ __forceinline__ void seek_seg(const ScanParams& p, SegCursor& c, uint32_t gb) {
     if (gb < c.end) return;
@@ -105,6 +106,7 @@ __device__ __forceinline__ void seek_seg(const ScanParams& p, SegCursor& c, uint
     c.end = c.begin + gld(&p.seg[lo].nblocks);
     c.blk = gld(&p.seg[lo].blk);
     c.scale = gld(&p.seg[lo].scale);
+    c.blk16 = gld(&p.seg[lo].blk16);
 }
 
 // slots[q][0..k) always hold f32 scores of k DISTINCT rows (or -inf), each slot only ever grows, so
@@ -238,6 +240,29 @@ __global__ __launch_bounds__(256) void row_scales_kernel(const float4* __restric
     }
     scale[row] = out;
 }
+
+// Screening copy of blocks [first_block, nblocks): piece f8 of row r = bf16(RNE) of features 8*f8..8*f8+7 times the
+// row's scale; rows that are not searchable (scale 0: padding, bad norm) become exact zeros.
+__global__ __launch_bounds__(256) void coarse_pack_kernel(const float4* __restrict__ blk, const float* __restrict__ scale,
+                                                          uint4* __restrict__ blk16, uint32_t first_block, uint32_t nblocks, int D4) {
+    const int D8 = D4 >> 1;
+    const size_t per_block = (size_t)D8 * 32;
+    const size_t total = (size_t)(nblocks - first_block) * per_block;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const uint32_t b = first_block + (uint32_t)(i / per_block);
+        const uint32_t rem = (uint32_t)(i % per_block);
+        const uint32_t f8 = rem >> 5, r = rem & 31;
+        const float sc = scale[(size_t)b * 32 + r];
+        uint4 out = make_uint4(0, 0, 0, 0);
+        if (sc != 0.0f) {
+            const float4 lo = blk[((size_t)b * D4 + 2 * f8) * 32 + r], hi = blk[((size_t)b * D4 + 2 * f8 + 1) * 32 + r];
+            const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            out = __builtin_bit_cast(uint4, __builtin_convertvector(v * sc, bf16x8));  // the conversion the f32 scan kernel does
+        }
+        blk16[((size_t)b * D8 + f8) * 32 + r] = out;
+    }
+}
+
 
 struct SynthShape {  // n_clusters == 0: plain i.i.d. rows
     uint32_t n_clusters;
@@ -778,8 +803,10 @@ __device__ __forceinline__ float wave_dot_f32(const float* qf, const float4* row
     return part;
 }
 
-template <int NT, bool NTL, int WPB, int NBUF>
-__global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void scan_mfma_kernel(
+// SRC16: stream the segments' screening copies (bf16, scale folded in: scan.h) instead of converting the f32 rows —
+// half the bytes per row and no conversion work; a chunk is then 4 pieces per lane instead of 8.
+template <int NT, bool NTL, int WPB, int NBUF, bool SRC16>
+__global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 2) ? 3 : 2) : 2) void scan_mfma_kernel(
     const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
     extern __shared__ uint4 lq[];  // [NT*32][Dp/8] 16-byte pieces of 8 bf16, swizzled
@@ -822,7 +849,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
         if (gb < p.total_blocks) {
             seek_seg(p, k.sc, gb);
             k.lb = gb - k.sc.begin;
-            k.base = k.sc.blk + (size_t)k.lb * D4 * 32 + h * 64 + c;
+            if constexpr (SRC16)
+                k.base = (const float4*)k.sc.blk16 + (size_t)k.lb * (D4 >> 1) * 32 + h * 32 + c;
+            else
+                k.base = k.sc.blk + (size_t)k.lb * D4 * 32 + h * 64 + c;
         }
     };
     BlockCursor cons, prod;  // consumer (MFMA) and producer (loads) positions; prod runs NBUF-1 chunks ahead
@@ -831,18 +861,25 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
     // scale of this lane's row (1/|x|, 1 or 0): multiplied into the A operand before the bf16
     // rounding, so the accumulators are final screening scores.  sc_next belongs to the block the
     // producer has entered but the consumer has not.
-    float sc_cur = gld(&cons.sc.scale[(size_t)cons.lb * 32 + c]), sc_next = 0.0f;
+    float sc_cur = SRC16 ? 1.0f : gld(&cons.sc.scale[(size_t)cons.lb * 32 + c]), sc_next = 0.0f;
 
-    float4 buf[NBUF][8];
-    // lane's pieces of k-step ks of a chunk: f4 = chunk*16 + ks*4 + 2h + e  (2h folded into base)
-    auto produce = [&](float4 (&b)[8]) {
+    constexpr int PCS = SRC16 ? 4 : 8;  // 16-byte pieces a lane loads per chunk of 64 features
+    float4 buf[NBUF][PCS];
+    // lane's pieces of k-step ks of a chunk: f4 = chunk*16 + ks*4 + 2h + e  (2h folded into base);
+    // screening copy: f8 = chunk*8 + ks*2 + h  (h folded into base)
+    auto produce = [&](float4 (&b)[PCS]) {
         if (prod.gb >= p.total_blocks) return;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 16 + (i >> 1) * 4 + (i & 1)) * 32);
+        for (int i = 0; i < PCS; ++i) {
+            if constexpr (SRC16)
+                b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 8 + i * 2) * 32);
+            else
+                b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 16 + (i >> 1) * 4 + (i & 1)) * 32);
+        }
         if (++prod.ch == NCH) {
             enter_block(prod, prod.gb + total_waves);
-            if (prod.gb < p.total_blocks) sc_next = gld(&prod.sc.scale[(size_t)prod.lb * 32 + c]);
+            if constexpr (!SRC16)
+                if (prod.gb < p.total_blocks) sc_next = gld(&prod.sc.scale[(size_t)prod.lb * 32 + c]);
         }
     };
 
@@ -918,13 +955,18 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     };
 
-    auto consume = [&](const float4 (&b)[8]) {
+    auto consume = [&](const float4 (&b)[PCS]) {
         if (NCH >= 2 && cons.ch == NCH - 2) tau_prefetch();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            f32x8 v = {b[2 * ks].x,     b[2 * ks].y,     b[2 * ks].z,     b[2 * ks].w,
-                       b[2 * ks + 1].x, b[2 * ks + 1].y, b[2 * ks + 1].z, b[2 * ks + 1].w};
-            const bf16x8 a = __builtin_convertvector(v * sc_cur, bf16x8);
+            bf16x8 a;
+            if constexpr (SRC16) {
+                a = __builtin_bit_cast(bf16x8, b[ks]);
+            } else {
+                f32x8 v = {b[2 * ks].x,     b[2 * ks].y,     b[2 * ks].z,     b[2 * ks].w,
+                           b[2 * ks + 1].x, b[2 * ks + 1].y, b[2 * ks + 1].z, b[2 * ks + 1].w};
+                a = __builtin_convertvector(v * sc_cur, bf16x8);
+            }
             const int pc = 2 * (cons.ch * 4 + ks) + h;
             const int ph = (pc & ~15) | ((pc ^ c) & 15);
 #pragma unroll
@@ -952,13 +994,35 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? (NBUF == 2 ? 3 : 2) : 2) void 
             PCV_STEP(1, 0)
             PCV_STEP(0, 1)
         }
-    } else {
-        static_assert(NBUF == 3, "2 or 3 chunk buffers");
+    } else if constexpr (NBUF == 3) {
         produce(buf[1]);
         while (true) {
             PCV_STEP(2, 0)
             PCV_STEP(0, 1)
             PCV_STEP(1, 2)
+        }
+    } else if constexpr (NBUF == 4) {
+        produce(buf[1]);
+        produce(buf[2]);
+        while (true) {
+            PCV_STEP(3, 0)
+            PCV_STEP(0, 1)
+            PCV_STEP(1, 2)
+            PCV_STEP(2, 3)
+        }
+    } else {
+        static_assert(NBUF == 6, "2, 3, 4 or 6 chunk buffers");
+        produce(buf[1]);
+        produce(buf[2]);
+        produce(buf[3]);
+        produce(buf[4]);
+        while (true) {
+            PCV_STEP(5, 0)
+            PCV_STEP(0, 1)
+            PCV_STEP(1, 2)
+            PCV_STEP(2, 3)
+            PCV_STEP(3, 4)
+            PCV_STEP(4, 5)
         }
     }
 #undef PCV_STEP
@@ -1411,15 +1475,32 @@ int mfma_pass_queries(int Dp) {
 
 uint32_t mfma_tile_rows(int B) { return B <= 32 ? 32u : (B <= 64 ? 64u : 128u); }
 
-template <int NT, bool NTL, int WPB, int NBUF>
+template <int NT, bool NTL, int WPB, int NBUF, bool SRC16>
 static void launch_mfma_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
     static size_t lds_allowed = 64 * 1024;  // one per instantiation; the static LDS of the kernel comes on top
     if (lds > lds_allowed) {
-        PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma_kernel<NT, NTL, WPB, NBUF>,
+        PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma_kernel<NT, NTL, WPB, NBUF, SRC16>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_allowed = lds;
     }
-    scan_mfma_kernel<NT, NTL, WPB, NBUF><<<grid, WPB * 64, lds, st>>>(dp);
+    scan_mfma_kernel<NT, NTL, WPB, NBUF, SRC16><<<grid, WPB * 64, lds, st>>>(dp);
+}
+
+template <int NT, bool NTL>
+static void launch_mfma_shape(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds, bool wide, bool src16, unsigned nbuf) {
+    if (src16) {
+        // the screening copy moves half the bytes per chunk: twice the chunks in flight for the same bytes in flight
+        if (NT == 4 || wide) {
+            if (nbuf == 4) launch_mfma_variant<NT, NTL, 8, 4, true>(st, dp, grid, lds);
+            else launch_mfma_variant<NT, NTL, 8, 6, true>(st, dp, grid, lds);
+        } else if constexpr (NT < 4) {
+            if (nbuf == 6) launch_mfma_variant<NT, NTL, 4, 6, true>(st, dp, grid, lds);
+            else launch_mfma_variant<NT, NTL, 4, 4, true>(st, dp, grid, lds);
+        }
+        return;
+    }
+    if (NT == 4 || wide) launch_mfma_variant<NT, NTL, 8, 3, false>(st, dp, grid, lds);
+    else if constexpr (NT < 4) launch_mfma_variant<NT, NTL, 4, 2, false>(st, dp, grid, lds);
 }
 
 void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
@@ -1427,7 +1508,9 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
     const int NT = p.B <= 32 ? 1 : (p.B <= 64 ? 2 : 4);
     const size_t lds = (size_t)NT * 32 * p.D4 * 4 * sizeof(uint16_t);
     const unsigned gm = (p.flags >> 8) & 0xff;
+    const unsigned nbuf = (p.flags >> 24) & 0xf;
     const bool ntl = (p.flags & 1) == 0;   // non-temporal corpus loads unless flag bit 0 is set
+    const bool src16 = (p.flags & 16) != 0;
     // small tiles: 256-thread workgroups, 3 per CU.  Tiles too big for that (B > 64, or dim > ~440):
     // 512-thread workgroups sharing one tile, as many per CU as the LDS holds.
     const bool wide = NT == 4 || lds * 3 > 156 * 1024;
@@ -1436,19 +1519,25 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
     unsigned grid = (unsigned)num_cus * (gm ? gm : per_cu);
     const unsigned need = (p.total_blocks + wpb - 1) / wpb;
     if (grid > need) grid = need;
-#define PCV_MFMA(NT_, NTL_)                                                      \
-    if (wide)                                                                    \
-        launch_mfma_variant<NT_, NTL_, 8, 3>(st, dp, grid, lds);                 \
-    else                                                                         \
-        launch_mfma_variant<NT_, NTL_, 4, 2>(st, dp, grid, lds);
     if (NT == 1) {
-        if (ntl) { PCV_MFMA(1, true) } else { PCV_MFMA(1, false) }
+        if (ntl) launch_mfma_shape<1, true>(st, dp, grid, lds, wide, src16, nbuf);
+        else launch_mfma_shape<1, false>(st, dp, grid, lds, wide, src16, nbuf);
     } else if (NT == 2) {
-        if (ntl) { PCV_MFMA(2, true) } else { PCV_MFMA(2, false) }
+        if (ntl) launch_mfma_shape<2, true>(st, dp, grid, lds, wide, src16, nbuf);
+        else launch_mfma_shape<2, false>(st, dp, grid, lds, wide, src16, nbuf);
     } else {
-        if (ntl) { launch_mfma_variant<4, true, 8, 3>(st, dp, grid, lds); } else { launch_mfma_variant<4, false, 8, 3>(st, dp, grid, lds); }
+        if (ntl) launch_mfma_shape<4, true>(st, dp, grid, lds, wide, src16, nbuf);
+        else launch_mfma_shape<4, false>(st, dp, grid, lds, wide, src16, nbuf);
     }
-#undef PCV_MFMA
+    PCV_LAUNCHED();
+}
+
+void launch_coarse_pack(hipStream_t st, const float4* blk, const float* scale, uint4* blk16, uint32_t first_block, uint32_t nblocks,
+                        int D4) {
+    if (first_block >= nblocks) return;
+    const size_t total = (size_t)(nblocks - first_block) * (D4 >> 1) * 32;
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 1u << 16);
+    coarse_pack_kernel<<<grid, 256, 0, st>>>(blk, scale, blk16, first_block, nblocks, D4);
     PCV_LAUNCHED();
 }
 

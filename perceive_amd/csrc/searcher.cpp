@@ -27,9 +27,11 @@ struct Segment {
     float4* blk = nullptr;
     float* scale = nullptr;
     int64_t* ids = nullptr;  // nullptr -> implicit ids id0 + row (synthetic rows)
+    uint4* blk16 = nullptr;  // screening copy (scan.h), built at finalize for the rows that have their scale
     int64_t id0 = 0;
     int64_t pos0 = 0;
     uint32_t nrows = 0, cap_rows = 0, scaled_rows = 0;
+    uint32_t copied_rows = 0;  // rows the screening copy covers
     uint32_t nblocks() const { return (nrows + kBlockRows - 1) / kBlockRows; }
 };
 
@@ -108,6 +110,9 @@ struct pcv_searcher {
     bool state_clean = false;  // tau / slots / counters are in the state a pass starts from
     uint32_t cand_cap = 8192;
     uint32_t scan_flags = 0;  // tuning knobs, PCV_SCAN_FLAGS
+    int screen_copy = PCV_SCREEN_COPY_AUTO;  // pcv_searcher_set_screening_copy
+    bool screen_copy_gave_way = false;       // AUTO: the copies were dropped to make room for rows
+    bool copies_complete = false;            // every row of every segment is covered by a screening copy
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // a pass queued by enqueue_pass and not yet collected by finish_pass
     struct Pending {
@@ -115,6 +120,7 @@ struct pcv_searcher {
         bool done = false;  // nothing was launched (no selected rows): only the stream has to drain
         int B = 0;
         int64_t rows = 0;
+        bool src16 = false;  // the scan streamed the screening copies
     } pending;
 
     Source* find_source(int64_t id) {
@@ -136,7 +142,19 @@ void free_segment(Segment& g) {
     if (g.blk) (void)hipFree(g.blk);
     if (g.scale) (void)hipFree(g.scale);
     if (g.ids) (void)hipFree(g.ids);
+    if (g.blk16) (void)hipFree(g.blk16);
     g = Segment();
+}
+
+void drop_screening_copies(pcv_searcher* s) {
+    s->copies_complete = false;
+    for (auto& src : s->sources)
+        for (auto& g : src.segs)
+            if (g.blk16) {
+                (void)hipFree(g.blk16);
+                g.blk16 = nullptr;
+                g.copied_rows = 0;
+            }
 }
 
 // Allocate a segment with room for `cap_rows` rows; zero-filled so padding rows / features are exact
@@ -148,6 +166,14 @@ Segment alloc_segment(pcv_searcher* s, int64_t cap_rows, bool with_ids) {
     g.cap_rows = nblk * kBlockRows;
     const size_t bytes = (size_t)nblk * s->D4 * 32 * sizeof(float4);
     hipError_t e = hipMalloc((void**)&g.blk, bytes);
+    if (e != hipSuccess && s->screen_copy == PCV_SCREEN_COPY_AUTO && !s->screen_copy_gave_way) {
+        // the rows themselves come first: give the screening copies back and scan the f32 rows from now on
+        (void)hipGetLastError();
+        PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+        drop_screening_copies(s);
+        s->screen_copy_gave_way = true;
+        e = hipMalloc((void**)&g.blk, bytes);
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         PCV_FAIL(PCV_ERR_DEVICE, "hipMalloc of %.2f GB for %lld corpus rows failed: %s", bytes / 1e9,
@@ -248,6 +274,34 @@ void append_rows(pcv_searcher* s, Source& src, const int64_t* ids, const void* r
     src.next_implicit_id += n;
 }
 
+// Screening copies (scan.h) of the rows that got their scale since the last finalize.  ON: a failed allocation
+// is an error; AUTO: it switches the copies off for this searcher (the f32 rows are scanned instead).
+void build_screening_copies(pcv_searcher* s, Source& src) {
+    if (s->screen_copy == PCV_SCREEN_COPY_OFF || s->screen_copy_gave_way) return;
+    hipStream_t st = s->ctx->stream;
+    for (auto& g : src.segs) {
+        if (g.nrows == 0 || g.copied_rows >= g.scaled_rows) continue;
+        if (!g.blk16) {
+            const size_t bytes = (size_t)(g.cap_rows / kBlockRows) * (s->D4 / 2) * 32 * sizeof(uint4);
+            const hipError_t e = hipMalloc((void**)&g.blk16, bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                g.blk16 = nullptr;
+                if (s->screen_copy == PCV_SCREEN_COPY_ON)
+                    PCV_FAIL(PCV_ERR_DEVICE, "hipMalloc of %.2f GB for the screening copy of %u rows failed: %s", bytes / 1e9, g.cap_rows,
+                             hipGetErrorString(e));
+                PCV_HIP(hipStreamSynchronize(st));
+                drop_screening_copies(s);
+                s->screen_copy_gave_way = true;
+                return;
+            }
+            g.copied_rows = 0;
+        }
+        launch_coarse_pack(st, g.blk, g.scale, g.blk16, g.copied_rows / kBlockRows, g.nblocks(), s->D4);
+        g.copied_rows = g.scaled_rows;
+    }
+}
+
 void do_finalize(pcv_searcher* s) {
     hipStream_t st = s->ctx->stream;
     for (auto& src : s->sources) {
@@ -257,6 +311,7 @@ void do_finalize(pcv_searcher* s) {
                               s->d_max_norm_bits);
             g.scaled_rows = g.nrows;
         }
+        build_screening_copies(s, src);
         // a reserved but never filled tail is given back
         while (!src.segs.empty() && src.segs.back().nrows == 0) {
             PCV_HIP(hipStreamSynchronize(st));
@@ -270,6 +325,10 @@ void do_finalize(pcv_searcher* s) {
                                     [](const Source& x) { return x.segs.empty(); }),
                      s->sources.end());
     assign_positions(s);
+    s->copies_complete = s->screen_copy != PCV_SCREEN_COPY_OFF && !s->sources.empty();
+    for (const auto& src : s->sources)
+        for (const auto& g : src.segs)
+            if (g.nrows > 0 && (g.blk16 == nullptr || g.copied_rows < g.nrows)) s->copies_complete = false;
     uint32_t bits = 0;
     PCV_HIP(hipMemcpyAsync(&bits, s->d_max_norm_bits, 4, hipMemcpyDeviceToHost, st));
     PCV_HIP(hipStreamSynchronize(st));
@@ -360,9 +419,11 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p = ScanParams{};
     uint32_t blk0 = 0;
     int64_t rows = 0;
+    bool src16 = kernel == PCV_KERNEL_MFMA && s->screen_copy != PCV_SCREEN_COPY_OFF;
     for (int i = 0; i < nseg; ++i) {
         const Segment& g = *segs[i].g;
-        tab[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), blk0, 0};
+        tab[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), blk0, 0, g.blk16};
+        src16 = src16 && g.blk16 != nullptr && g.copied_rows >= g.nrows;
         PCV_REQUIRE((uint64_t)blk0 + g.nblocks() < 0xffffff00ull, "search: more than 2^32 row blocks in one launch");
         blk0 += g.nblocks();
         rows += g.nrows;
@@ -392,7 +453,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.cnt_host = s->pin->cnt;
     p.flag_rec = d_flag;
     p.cand_cap = s->cand_cap;
-    p.flags = s->scan_flags;
+    p.flags = (s->scan_flags & ~16u) | (src16 ? 16u : 0u);
     const uint32_t seed_parts = ((s->scan_flags >> 16) & 0xff) ? ((s->scan_flags >> 16) & 0xff) : kSeedParts;  // tuning
     p.seed_blocks = std::min<uint32_t>(std::min<uint32_t>(seed_parts, kSeedParts) * kSeedPartRows / kBlockRows, segs[0].g->nblocks());
     // |s - c| bounds of the screening scores, relative to |q||x| (DESIGN.md §screening error): an f32 FMA
@@ -422,6 +483,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     s->pending.done = false;
     s->pending.B = B;
     s->pending.rows = rows;
+    s->pending.src16 = src16;
     s->stats.host_enqueue_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
@@ -448,6 +510,8 @@ bool finish_pass(pcv_searcher* s) {
     s->stats.scan_launches += 1;
     s->stats.rows_scanned += rows;
     s->stats.bytes_algorithmic += rows * (int64_t)s->D * 4;
+    s->stats.bytes_streamed += rows * (int64_t)s->D * (s->pending.src16 ? 2 : 4);
+    s->stats.screening_copy = s->pending.src16 ? 1 : 0;
 
     const uint32_t* cnt = s->pin->cnt;
     uint32_t mx = 0;
@@ -489,6 +553,8 @@ int pick_kernel(const pcv_searcher* s, int B) {
     if (s->kernel == PCV_KERNEL_MFMA && !mfma_ok)
         PCV_FAIL(PCV_ERR_UNSUPPORTED, "the MFMA kernel cannot hold a %d-d query tile in LDS", s->D);
     if (s->kernel == PCV_KERNEL_WAVE || s->kernel == PCV_KERNEL_MFMA) return s->kernel;
+    // with screening copies the MFMA kernel streams half the bytes of the wave kernel, whatever the batch
+    if (mfma_ok && s->copies_complete) return PCV_KERNEL_MFMA;
     return (B <= kMaxWaveQueries || !mfma_ok) ? PCV_KERNEL_WAVE : PCV_KERNEL_MFMA;
 }
 
@@ -598,6 +664,10 @@ pcv_status pcv_searcher_create(pcv_ctx* ctx, int dim, int metric, pcv_searcher**
         s->D4 = s->Dp / 4;
         s->metric = metric;
         if (const char* f = getenv("PCV_SCAN_FLAGS")) s->scan_flags = (uint32_t)strtoul(f, nullptr, 0);
+        if (const char* f = getenv("PCV_SCREEN_COPY")) {  // 0 off, 1 on, 2 auto
+            const int mode = atoi(f);
+            if (mode >= PCV_SCREEN_COPY_OFF && mode <= PCV_SCREEN_COPY_AUTO) s->screen_copy = mode;
+        }
         PCV_HIP(hipMalloc((void**)&s->d_max_norm_bits, 4));
         // on the stream the row_scales atomics will run on (the context stream does not wait for the null stream)
         hipError_t e = hipMemsetAsync(s->d_max_norm_bits, 0, 4, ctx->stream);
@@ -850,6 +920,22 @@ pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel) {
         PCV_REQUIRE(kernel >= PCV_KERNEL_AUTO && kernel <= PCV_KERNEL_MFMA, "set_kernel: unknown kernel %d", kernel);
         std::lock_guard<std::mutex> lk(s->mu);
         s->kernel = kernel;
+    });
+}
+
+pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "searcher_set_screening_copy: searcher is NULL");
+        PCV_REQUIRE(mode == PCV_SCREEN_COPY_OFF || mode == PCV_SCREEN_COPY_ON || mode == PCV_SCREEN_COPY_AUTO,
+                    "searcher_set_screening_copy: unknown mode %d", mode);
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        if (mode == PCV_SCREEN_COPY_OFF) {
+            PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+            drop_screening_copies(s);
+        }
+        s->screen_copy = mode;
+        s->screen_copy_gave_way = false;
     });
 }
 
@@ -1162,6 +1248,8 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
             total.host_enqueue_ms += s->stats.host_enqueue_ms;
             total.host_wait_ms += s->stats.host_wait_ms;
             total.kernel_used = s->stats.kernel_used;
+            total.bytes_streamed += s->stats.bytes_streamed;
+            total.screening_copy = s->stats.screening_copy;
         };
         for (int q0 = 0; q0 < n_queries; q0 += qstep) {
             const int B = std::min(qstep, n_queries - q0);

@@ -223,6 +223,11 @@ class Searcher:
         """Initial rows per query of a pass's candidate lists (tuning; a pass that needs more repeats itself)."""
         _ffi.check(_ffi.lib().pcv_searcher_set_candidate_capacity(self._handle, int(n_candidates)))
 
+    def set_screening_copy(self, mode="auto"):
+        """"off" | "on" | "auto": keep a bf16 copy of the scaled rows next to the f32 rows so that the coarse screen
+        streams half the bytes (pcv_searcher_set_screening_copy); built at the next finalize."""
+        _ffi.check(_ffi.lib().pcv_searcher_set_screening_copy(self._handle, {"off": 0, "on": 1, "auto": 2}[mode]))
+
     def set_shard_offset(self, first_global_pos):
         _ffi.check(_ffi.lib().pcv_searcher_set_shard_offset(self._handle, int(first_global_pos)))
 

@@ -51,9 +51,10 @@ pub struct pcv_scan_stats {
     pub scan_launches: i32,
     pub overflow_reruns: i32,
     pub kernel_used: i32,
-    pub reserved: i32,
+    pub screening_copy: i32,
     pub host_enqueue_ms: f32,
     pub host_wait_ms: f32,
+    pub bytes_streamed: i64,
 }
 
 #[repr(C)]
@@ -98,6 +99,9 @@ pub const PCV_METRIC_DOT: c_int = 1;
 pub const PCV_KERNEL_AUTO: c_int = 0;
 pub const PCV_KERNEL_WAVE: c_int = 1;
 pub const PCV_KERNEL_MFMA: c_int = 2;
+pub const PCV_SCREEN_COPY_OFF: c_int = 0;
+pub const PCV_SCREEN_COPY_ON: c_int = 1;
+pub const PCV_SCREEN_COPY_AUTO: c_int = 2;
 pub const PCV_GELU_ERF: c_int = 0;
 pub const PCV_GELU_TANH: c_int = 1;
 pub const PCV_POOL_MEAN: c_int = 0;
@@ -152,6 +156,7 @@ extern "C" {
     pub fn pcv_searcher_get_rows(s: *mut pcv_searcher, positions: *const i64, n: i64, out_rows: *mut f32, out_ids: *mut i64) -> c_int;
     pub fn pcv_searcher_set_kernel(s: *mut pcv_searcher, kernel: c_int) -> c_int;
     pub fn pcv_searcher_set_candidate_capacity(s: *mut pcv_searcher, n_candidates: u32) -> c_int;
+    pub fn pcv_searcher_set_screening_copy(s: *mut pcv_searcher, mode: c_int) -> c_int;
     pub fn pcv_searcher_search(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;
     pub fn pcv_searcher_set_shard_offset(s: *mut pcv_searcher, first_global_pos: i64) -> c_int;
     pub fn pcv_searcher_search_device(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void, async_: c_int) -> c_int;

@@ -129,19 +129,29 @@ def test_headline_config_100m_b64_k10_mfma(big, oracle):
     ids, sc, cnt = big.search_vectors(None, k, q)
     st = big.last_stats()
     assert st["kernel_used"] == 2 and st["scan_launches"] == 1 and st["rows_scanned"] == N
+    assert st["screening_copy"] == 1 and st["bytes_streamed"] == N * D * 2  # 153.6 GB of rows + 76.8 GB of bf16 copy are resident
     assert st["overflow_reruns"] == 0 and (cnt == k).all()
     np.testing.assert_array_equal(ids[slots, 0], pos)
     np.testing.assert_allclose(sc[slots, 0], 1.0, atol=1e-6)
     _verify_topk(big, oracle, q, ids, sc, k, N, rng)
     big.set_kernel("wave")  # 16 passes of 4 queries through the independent f32 kernel
     ids_w, sc_w, _ = big.search_vectors(None, k, q)
-    big.set_kernel("auto")
     np.testing.assert_array_equal(ids, ids_w)
     np.testing.assert_array_equal(sc, sc_w)
+    big.set_kernel("mfma")
+    big.set_screening_copy("off")  # the same MFMA screen fed from the f32 rows
+    ids_f, sc_f, _ = big.search_vectors(None, k, q)
+    assert big.last_stats()["screening_copy"] == 0 and big.last_stats()["bytes_streamed"] == N * D * 4
+    np.testing.assert_array_equal(ids, ids_f)
+    np.testing.assert_array_equal(sc, sc_f)
+    big.set_screening_copy("auto")
+    big.finalize()  # rebuilds the copy for the tests that follow
+    big.set_kernel("auto")
 
 
-def test_config2_10m_b1_k10_wave(ctx, oracle):
-    # BASELINE configs[1]: 10M x 384, batch 1, top-10, the wave-reduction kernel
+def test_config2_10m_b1_k10(ctx, oracle):
+    # BASELINE configs[1]: 10M x 384, batch 1, top-10: with the screening copy the MFMA kernel (one query tile), checked
+    # against the f32 wave-reduction kernel and the copy-less MFMA kernel
     n = 10_000_000
     s = pa.Searcher(ctx, D, "cosine")
     s.add_synthetic(1, n, 0x5EED)
@@ -150,14 +160,21 @@ def test_config2_10m_b1_k10_wave(ctx, oracle):
     q = oracle.synth_rows(0x5EED + 1, 0, 1, D)
     ids, sc, cnt = s.search_vectors(None, 10, q)
     st = s.last_stats()
-    assert st["kernel_used"] == 1 and st["scan_launches"] == 1 and st["rows_scanned"] == n and cnt[0] == 10
+    assert st["kernel_used"] == 2 and st["screening_copy"] == 1 and st["scan_launches"] == 1 and st["rows_scanned"] == n and cnt[0] == 10
     _verify_topk(s, oracle, q, ids, sc, 10, n, rng, sample=1024)
     # a planted row, and agreement with the MFMA kernel on the same query
     qp = oracle.synth_rows(0x5EED, 9_999_999, 1, D)
     got, gsc, _ = s.search_vectors(None, 10, qp)
     assert got[0, 0] == 9_999_999 and abs(gsc[0, 0] - 1.0) < 1e-6
+    s.set_kernel("wave")  # the independent f32 kernel
+    ids_w, sc_w, _ = s.search_vectors(None, 10, q)
+    assert s.last_stats()["kernel_used"] == 1 and s.last_stats()["screening_copy"] == 0
+    np.testing.assert_array_equal(ids, ids_w)
+    np.testing.assert_array_equal(sc, sc_w)
     s.set_kernel("mfma")
+    s.set_screening_copy("off")
     ids_m, sc_m, _ = s.search_vectors(None, 10, q)
+    assert s.last_stats()["kernel_used"] == 2 and s.last_stats()["screening_copy"] == 0
     np.testing.assert_array_equal(ids, ids_m)
     np.testing.assert_array_equal(sc, sc_m)
     s.close()
