@@ -1487,7 +1487,8 @@ static void launch_mfma_variant(hipStream_t st, const ScanParams* dp, unsigned g
 }
 
 template <int NT, bool NTL>
-static void launch_mfma_shape(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds, bool wide, bool src16, unsigned nbuf) {
+static void launch_mfma_shape(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds, bool wide, bool src16, unsigned nbuf,
+                              unsigned wpb) {
     if (src16) {
         // the screening copy moves half the bytes per chunk: twice the chunks in flight for the same bytes in flight
         if (NT == 4 || wide) {
@@ -1514,20 +1515,22 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
     // small tiles: 256-thread workgroups, 3 per CU.  Tiles too big for that (B > 64, or dim > ~440):
     // 512-thread workgroups sharing one tile, as many per CU as the LDS holds.
     const bool wide = NT == 4 || lds * 3 > 156 * 1024;
-    const unsigned wpb = wide ? 8 : 4;
     const unsigned per_cu = wide ? (unsigned)std::max<size_t>(1, std::min<size_t>(2, (156 * 1024) / lds)) : 3;
+    // (12 waves sharing a tile that fits once per CU — 3 per SIMD — were tried for 128 queries: the 168-VGPR cap spills
+    // 113 registers and the pass takes 11.3 ms instead of 6.8 ms for 50M rows)
+    const unsigned wpb = wide ? 8 : 4;
     unsigned grid = (unsigned)num_cus * (gm ? gm : per_cu);
     const unsigned need = (p.total_blocks + wpb - 1) / wpb;
     if (grid > need) grid = need;
     if (NT == 1) {
-        if (ntl) launch_mfma_shape<1, true>(st, dp, grid, lds, wide, src16, nbuf);
-        else launch_mfma_shape<1, false>(st, dp, grid, lds, wide, src16, nbuf);
+        if (ntl) launch_mfma_shape<1, true>(st, dp, grid, lds, wide, src16, nbuf, wpb);
+        else launch_mfma_shape<1, false>(st, dp, grid, lds, wide, src16, nbuf, wpb);
     } else if (NT == 2) {
-        if (ntl) launch_mfma_shape<2, true>(st, dp, grid, lds, wide, src16, nbuf);
-        else launch_mfma_shape<2, false>(st, dp, grid, lds, wide, src16, nbuf);
+        if (ntl) launch_mfma_shape<2, true>(st, dp, grid, lds, wide, src16, nbuf, wpb);
+        else launch_mfma_shape<2, false>(st, dp, grid, lds, wide, src16, nbuf, wpb);
     } else {
-        if (ntl) launch_mfma_shape<4, true>(st, dp, grid, lds, wide, src16, nbuf);
-        else launch_mfma_shape<4, false>(st, dp, grid, lds, wide, src16, nbuf);
+        if (ntl) launch_mfma_shape<4, true>(st, dp, grid, lds, wide, src16, nbuf, wpb);
+        else launch_mfma_shape<4, false>(st, dp, grid, lds, wide, src16, nbuf, wpb);
     }
     PCV_LAUNCHED();
 }
