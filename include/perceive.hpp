@@ -173,6 +173,14 @@ public:
     }
     // capacity hint: the rows about to be added to `source_id` land in one device segment
     void reserve(int64_t source_id, int64_t n_rows) { check(pcv_searcher_reserve(h_, source_id, n_rows)); }
+    // bf16 screening copy of the rows next to the f32 rows (half the bytes per scan, same results):
+    // PCV_SCREEN_COPY_{OFF, ON, AUTO}; built by the next rebuild / finalize
+    void set_screening_copy(int mode) { check(pcv_searcher_set_screening_copy(h_, mode)); }
+    pcv_scan_stats last_stats() const {
+        pcv_scan_stats st;
+        check(pcv_searcher_last_stats(h_, &st));
+        return st;
+    }
     pcv_searcher* handle() const { return h_; }
 
 private:
@@ -197,6 +205,30 @@ enum class SentenceEmbeddingsModelType {
     MsMarcoBertBaseDotV5 = 7,
 };
 inline uint32_t model_id(SentenceEmbeddingsModelType t) { return (uint32_t)t; }
+
+// One tensor of a checkpoint file (model.safetensors, rust_model.ot, pytorch_model.bin) as pcv_checkpoint_visit reports it
+struct CheckpointTensor {
+    std::string name;
+    std::vector<int64_t> shape;
+    int dtype = PCV_TENSOR_OTHER;
+    std::vector<float> values;  // empty for integer tensors
+};
+inline std::vector<CheckpointTensor> read_checkpoint(const std::string& path) {
+    std::vector<CheckpointTensor> out;
+    auto visit = [](void* user, const char* name, const int64_t* shape, int rank, int dtype, const float* values, int64_t numel) -> int {
+        auto* v = static_cast<std::vector<CheckpointTensor>*>(user);
+        CheckpointTensor t;
+        t.name = name;
+        t.shape.assign(shape, shape + rank);
+        t.dtype = dtype;
+        if (values) t.values.assign(values, values + numel);
+        v->push_back(std::move(t));
+        return 0;
+    };
+    const pcv_status st = pcv_checkpoint_visit(path.c_str(), visit, &out);
+    if (st != PCV_OK) throw ModelError(st, pcv_last_error());
+    return out;
+}
 
 // SentenceEmbeddingsTokenizerOuput of tokenize.rs:9-57: right-padded ids, mask = id != pad
 struct TokenTensors {

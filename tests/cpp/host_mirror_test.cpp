@@ -62,6 +62,16 @@ int main(int argc, char** argv) {
         }
     }
     EXPECT(s->search_vector({}, 10, q).empty());
+    {  // the bf16 screening copy is on by default and changes nothing but the bytes streamed
+        auto with = s->search_vector({1, 2}, 10, q);
+        EXPECT(s->last_stats().screening_copy == 1 && s->last_stats().bytes_streamed == (int64_t)N * D * 2);
+        s->set_screening_copy(PCV_SCREEN_COPY_OFF);
+        auto without = s->search_vector({1, 2}, 10, q);
+        EXPECT(s->last_stats().screening_copy == 0 && s->last_stats().bytes_streamed == (int64_t)N * D * 4);
+        EXPECT(with.size() == without.size());
+        for (size_t j = 0; j < with.size() && j < without.size(); ++j) EXPECT(with[j].id == without[j].id && with[j].score == without[j].score);
+        s->set_screening_copy(PCV_SCREEN_COPY_AUTO);
+    }
     {  // the sharded form at world size 1 (RCCL communicator owned by the library) gives the same items
         Comm comm(ctx, 1, 0, Comm::unique_id());
         auto a = s->search_vector({1}, 10, q), b = s->search_vector_sharded(comm, {1}, 10, q);
@@ -116,6 +126,22 @@ int main(int argc, char** argv) {
         if (hl[0]) EXPECT(hl[0]->data() >= docs[0].data() && hl[0]->data() + hl[0]->size() <= docs[0].data() + docs[0].size());
         try {
             Model missing(ctx, std::string(argv[1]) + "/nope");
+            EXPECT(false);
+        } catch (const ModelError& e) {
+            EXPECT(e.status == PCV_ERR_IO);
+        }
+    }
+
+    // a checkpoint file walked through the C ABI (argv[2]: the rust_model.ot fixture written by libtorch)
+    if (argc > 2) {
+        auto tensors = read_checkpoint(argv[2]);
+        EXPECT(tensors.size() == 2 && tensors[0].name == "linear.weight" && tensors[1].name == "linear.bias");
+        if (tensors.size() == 2) {
+            EXPECT(tensors[0].shape == (std::vector<int64_t>{64, 128}) && tensors[0].values.size() == 64 * 128 && tensors[0].dtype == PCV_TENSOR_F32);
+            EXPECT(tensors[1].shape == (std::vector<int64_t>{64}) && tensors[1].values.size() == 64);
+        }
+        try {
+            read_checkpoint(std::string(argv[2]) + ".missing");
             EXPECT(false);
         } catch (const ModelError& e) {
             EXPECT(e.status == PCV_ERR_IO);

@@ -47,6 +47,7 @@ def test_cpp_mirror_runs_on_gpu(tmp_path, golden_dir):
     if not os.path.exists(BIN):
         compile_mirror()
     write_model_dir(str(tmp_path / "model"), golden_dir)
-    r = subprocess.run([BIN, str(tmp_path / "model")], capture_output=True, text=True, timeout=300)
+    ot = os.path.join(golden_dir, "ot", "2_Dense", "rust_model.ot")
+    r = subprocess.run([BIN, str(tmp_path / "model"), ot], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host_mirror_test: ok" in r.stdout
