@@ -141,11 +141,11 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
         launches += st["scan_launches"]
     ctx.synchronize()
     wall = time.perf_counter() - t0
-    kname = "scan_mfma_kernel" if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel"
+    kname = ("scan_mfma8_kernel" if searcher.last_stats()["screening_copy"] == 2 else "scan_mfma_kernel") if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel"
     kernel_ms = float(np.sum(scan_ms)) / max(launches, 1)
     gbps = rows * dim * 4 / (kernel_ms * 1e-3) / 1e9
-    copy = bool(searcher.last_stats()["screening_copy"])
-    streamed_gbps = gbps / 2 if copy else gbps  # the screening copy is 2 bytes per feature
+    copy = {0: None, 1: "bf16", 2: "int8"}[searcher.last_stats()["screening_copy"]]
+    streamed_gbps = gbps / {None: 1, "bf16": 2, "int8": 4}[copy]  # bytes per feature of what the scan streams: 4, 2, 1
     rec = {
         "workload": f"{rows} x {dim} f32 synthetic" + (" clustered" if clustered else "") + f" corpus, batch={batch}, top-{k}, 1 MI355X",
         "kernel": kname, "ms_per_step": 1e3 * wall / steps, "kernel_ms": kernel_ms,
@@ -220,7 +220,7 @@ def e2e_leg(pa, ctx, searcher, rows, steps=3, warmup=1, batch=256, seq=256, k=10
     }
 
 
-def measured_traffic(kernel, rows, dim, screening_copy=False):
+def measured_traffic(kernel, rows, dim, streamed_per_row):
     """HBM bytes per launch from the committed PMC pass of this command (profiles/traffic.json,
     written by tools/summarize_profiles.py; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 guide), scaled by
     rows.  bench.py cannot collect PMC counters on itself; None when no pass covers this kernel."""
@@ -228,7 +228,7 @@ def measured_traffic(kernel, rows, dim, screening_copy=False):
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
         if t["dim"] != dim or not t["bytes_per_row"]:
             return None, None
-        if (t["bytes_per_row"] < 0.75 * dim * 4) != bool(screening_copy):  # the pass was taken in the other streaming mode
+        if not (0.9 * streamed_per_row <= t["bytes_per_row"] <= 1.25 * streamed_per_row):  # the pass was taken in another streaming mode
             return None, None
         return t["bytes_per_row"] * rows, t["source"]
     except Exception:
@@ -372,11 +372,11 @@ def main():
         vectors_per_s = total_rows * args.steps / elapsed
         per_launch_bytes = float(np.mean(scan_bytes))  # this rank's shard: rows * dim * 4
         achieved = per_launch_bytes / (mean_scan_ms * 1e-3) / 1e9
-        copy = bool(searcher.last_stats()["screening_copy"])
+        copy = {0: None, 1: "bf16", 2: "int8"}[searcher.last_stats()["screening_copy"]]
         streamed = float(np.mean(streamed_bytes)) / (mean_scan_ms * 1e-3) / 1e9  # what the scan kernel actually pulls from HBM
         ids, scores, counts = last
-        kname = "scan_mfma_kernel" if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel"
-        traffic, traffic_src = measured_traffic(kname, (hi - lo), args.dim, copy)
+        kname = ("scan_mfma8_kernel" if copy == "int8" else "scan_mfma_kernel") if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel"
+        traffic, traffic_src = measured_traffic(kname, (hi - lo), args.dim, float(np.mean(streamed_bytes)) / max(1, hi - lo))
         out = {
             "metric": f"vectors scanned/sec (exact cosine top-{k}, {args.dim}-d f32, batch={B})",
             "value": vectors_per_s,
@@ -389,11 +389,12 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "screen": ("coarse screen streams the resident bf16 screening copy of the rows (768 B/vector; the f32 rows, 1536 B/vector, "
-                       "are read for its survivors only); bf16 MFMA coarse screen + exact-f32 fine screen with certified margins, "
-                       "survivors ranked in f64: exact top-k" if copy else
-                       "rows are read as f32 (1536 B/vector); bf16 MFMA coarse screen + exact-f32 fine screen with certified margins, "
-                       "survivors ranked in f64: exact top-k") if searcher.last_stats()["kernel_used"] == 2 else
+            "screen": ({"int8": "coarse screen = exact integer dot product of per-row int8-quantised rows (resident screening copy, 384 B/vector "
+                                "+ 4 B scale) and the int8-quantised query on v_mfma_i32_32x32x32_i8, with a certified quantisation margin; ",
+                        "bf16": "coarse screen = bf16 MFMA over the resident bf16 screening copy of the rows (768 B/vector); ",
+                        None: "rows are read as f32 (1536 B/vector), bf16 MFMA coarse screen; "}[copy]
+                       + "the f32 rows are read for the coarse survivors only: exact-f32 fine screen with certified margins, survivors "
+                         "ranked in f64: exact top-k") if searcher.last_stats()["kernel_used"] == 2 else
                       "f32 FMA screen with a certified margin, survivors ranked in f64: exact top-k",
             "data": "synthetic clustered" if args.clustered else "synthetic",
             "config": {

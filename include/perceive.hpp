@@ -173,8 +173,8 @@ public:
     }
     // capacity hint: the rows about to be added to `source_id` land in one device segment
     void reserve(int64_t source_id, int64_t n_rows) { check(pcv_searcher_reserve(h_, source_id, n_rows)); }
-    // bf16 screening copy of the rows next to the f32 rows (half the bytes per scan, same results):
-    // PCV_SCREEN_COPY_{OFF, ON, AUTO}; built by the next rebuild / finalize
+    // narrow screening copy of the rows next to the f32 rows (a half / a quarter of the bytes per scan, same results):
+    // PCV_SCREEN_COPY_{OFF, BF16, INT8, AUTO}; built by the next rebuild / finalize
     void set_screening_copy(int mode) { check(pcv_searcher_set_screening_copy(h_, mode)); }
     pcv_scan_stats last_stats() const {
         pcv_scan_stats st;

@@ -156,16 +156,21 @@ pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel);
  * lists).  A pass that needs more repeats itself with larger lists (pcv_scan_stats.overflow_reruns). */
 pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candidates);
 
-/* Screening copy: next to the f32 rows a segment can hold the same rows already scaled and rounded to bf16 —
- * exactly the operand the coarse (bf16 MFMA) screen builds from them.  The scan then streams 2 bytes per feature
- * instead of 4 and reads f32 rows only for the rows that pass the coarse screen; results are identical (same
- * screening arithmetic, same exact rescoring).  Costs half as much HBM again (100M x 384: 153.6 + 76.8 GB).
- *   PCV_SCREEN_COPY_AUTO (default): built at finalize; given up — for good, on this searcher — when an allocation
- *                                   for rows or for a copy fails (the f32 rows are scanned then)
- *   PCV_SCREEN_COPY_ON            : a failed copy allocation is an error at finalize
- *   PCV_SCREEN_COPY_OFF           : never built; existing copies are freed
- * Takes effect at the next finalize (OFF: at once). */
-enum { PCV_SCREEN_COPY_OFF = 0, PCV_SCREEN_COPY_ON = 1, PCV_SCREEN_COPY_AUTO = 2 };
+/* Screening copy: next to the f32 rows a segment can hold the same rows, already scaled, in a narrow form that
+ * only the coarse screen reads; the f32 rows are then read for the rows that pass it (fine screen) and for the
+ * finalists (exact ranking), so results are identical — the screens are certified bounds, not approximations.
+ *   PCV_SCREEN_COPY_BF16 : the operand of the bf16 MFMA screen ready-made, 2 bytes per feature (+50 % HBM);
+ *                          coarse margin 2^-8 relative
+ *   PCV_SCREEN_COPY_INT8 : rows quantised per row to int8, 1 byte per feature + 4 bytes per row (+25 % HBM), screened
+ *                          by an exact integer dot product with the quantised query; coarse margin
+ *                          ~ (|q|_1 / max|q_i| ... ) 0.03 in cosine for 384-d unit rows: more rows reach the fine screen,
+ *                          a quarter of the bytes are streamed
+ *   PCV_SCREEN_COPY_AUTO (default): INT8, built at finalize; given up — for good, on this searcher — when an
+ *                          allocation for rows or for a copy fails (the f32 rows are scanned then)
+ *   PCV_SCREEN_COPY_OFF  : never built; existing copies are freed
+ * BF16 / INT8 asked for explicitly: a failed copy allocation is an error at finalize.  Takes effect at the next
+ * finalize (OFF: at once).  100M x 384: 153.6 GB of rows + 38.8 GB (INT8) or 76.8 GB (BF16). */
+enum { PCV_SCREEN_COPY_OFF = 0, PCV_SCREEN_COPY_BF16 = 1, PCV_SCREEN_COPY_AUTO = 2, PCV_SCREEN_COPY_INT8 = 3 };
 pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode);
 
 /* Searcher::search_vector (search.rs:157-182), batched over `n_queries` query vectors.
@@ -270,10 +275,10 @@ typedef struct pcv_scan_stats {
     int32_t scan_launches;       /* scan kernel launches (reruns after overflow included)        */
     int32_t overflow_reruns;     /* passes repeated because a candidate list overflowed          */
     int32_t kernel_used;         /* PCV_KERNEL_WAVE or PCV_KERNEL_MFMA                           */
-    int32_t screening_copy;      /* 1: the scan streamed the bf16 screening copies (last pass)   */
+    int32_t screening_copy;      /* what the scan streamed (last pass): 0 f32 rows, 1 bf16 copy, 2 int8 copy */
     float host_enqueue_ms;       /* host time spent queueing the passes (copies + launches)      */
     float host_wait_ms;          /* host time blocked until the stream had drained               */
-    int64_t bytes_streamed;      /* rows_scanned * dim * (2 with the screening copy, else 4)     */
+    int64_t bytes_streamed;      /* rows_scanned * dim * (4 f32 rows, 2 bf16 copy, 1 int8 copy)  */
 } pcv_scan_stats;
 pcv_status pcv_searcher_last_stats(pcv_searcher* s, pcv_scan_stats* out);
 

@@ -13,6 +13,14 @@
 //       blk16[(b * D8 + f8) * 32 + r]          D8 = Dp/8
 // The coarse screen then streams 2 bytes per feature instead of 4; the f32 rows are read only for the coarse
 // survivors (fine screen) and the finalists (exact rescoring), so results are unchanged.
+//
+// Int8 screening copy (PCV_SCREEN_COPY_INT8): y = row x scale quantised per row, x^_i = rint(y_i * s_row) in [-127, 127],
+// s_row = 127 / max|y_i|, in 16-byte pieces of 16 features (feature dimension padded to a multiple of 128):
+//       blk8[(b * D16 + f16) * 32 + r]         D16 = roundup(Dp, 128) / 16;      scale8[row] = s_row
+// The screen is then an exact integer dot product (v_mfma_i32_32x32x32_i8) of quantised row and quantised query,
+// 384 B per 384-d vector, with the certified bound
+//       |c - acc / (s_row s_q)| <= |q'|_1 * 0.5 / s_row  +  |x^|_1 / s_row * 0.5 / s_q        (+ the f32 term eps32)
+// and |x^|_1 <= sqrt(D) (s_row |y|_2 + 0.5 sqrt(D)), so one float per row (s_row) is all the test needs.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,7 +51,9 @@ struct SegDesc {
     uint32_t nblocks;
     uint32_t blk0;       // first block index of this segment in the launch's block numbering
     uint32_t pad;
-    const uint4* blk16;  // screening copy (see below), or nullptr
+    const uint4* blk16;  // bf16 screening copy (see below), or nullptr
+    const uint4* blk8;   // int8 screening copy, or nullptr
+    const float* scale8; // [nblocks*32] quantisation scale of the int8 copy's rows (NaN = row not searchable)
 };
 
 struct pcv_hit_dev {
@@ -68,6 +78,8 @@ struct ScanParams {
     const float* queries;    // [B][D]    raw queries as the caller passed them
     float* qf32;             // [B][Dp]   scan-side query (normalised for cosine), zero padded
     uint16_t* qbf16;         // [128][Dp] same, rounded to bf16
+    int8_t* q8;              // [128][Dp8] same, quantised per query to int8 (int8 screen; Dp8 = Dp rounded up to 128)
+    float* q8c;              // [128][2]  s_q (quantisation scale, 0 = dead query) and V_q of the int8 test (scan_mfma8_kernel)
     float* qraw;             // [B][Dp]   original query values, zero padded (exact rescoring)
     float* margin;           // [B]  coarse screen: rows with s16 < tau - margin are dropped       (eps16 + eps32)
     float* margin32;         // [B]  fine screen:   rows with s32 < tau - margin32 are dropped     (2 * eps32)
@@ -82,8 +94,8 @@ struct ScanParams {
     pcv_hit_dev* flag_rec;   // overflow record behind a shard's hit list (device), or nullptr
     uint32_t cand_cap;
     uint32_t seed_blocks;    // leading blocks of segment 0 ranked by the seed kernel
-    uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bit 4: every segment has its screening
-                             // copy, stream that; bits 8..15: workgroups per CU override; bits 16..23: seed workgroups; bits 24..27: chunk buffers override (tuning)
+    uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bit 4: every segment has its bf16 screening
+                             // copy, stream that; bit 6: every segment has its int8 screening copy, stream that; bits 8..15: workgroups per CU override; bits 16..23: seed workgroups; bits 24..27: chunk buffers override (tuning)
     float eps16, eps32;      // |s - c| bounds of the bf16 / f32 screening scores, relative to |q||x|
     float max_norm;          // upper bound of |x| over the corpus (dot metric margins)
 };
@@ -108,6 +120,11 @@ void launch_row_scales(hipStream_t st, const float4* blk, uint32_t first_block, 
 // screening copy of the rows in blocks [first_block, nblocks): bf16(row * scale), zeros where scale == 0
 void launch_coarse_pack(hipStream_t st, const float4* blk, const float* scale, uint4* blk16, uint32_t first_block, uint32_t nblocks,
                         int D4);
+// int8 screening copy + quantisation scales of the rows in blocks [first_block, nblocks)
+void launch_coarse_pack8(hipStream_t st, const float4* blk, const float* scale, uint4* blk8, float* scale8, uint32_t first_block,
+                         uint32_t nblocks, int D4);
+void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);  // quantises the queries first
+int mfma8_pass_queries(int Dp);  // queries one int8 MFMA pass can take (LDS-limited)
 void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nrows, uint32_t row0, int D, int D4, uint64_t seed,
                        int64_t first_row, int normalize, uint32_t n_clusters, float noise);
 void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const int64_t* d_pos, int64_t n, int D,

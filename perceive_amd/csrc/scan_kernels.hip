@@ -90,6 +90,8 @@ struct SegCursor {
     const float4* blk = nullptr;
     const float* scale = nullptr;
     const uint4* blk16 = nullptr;
+    const uint4* blk8 = nullptr;
+    const float* scale8 = nullptr;
 };
 __device__ __forceinline__ void seek_seg(const ScanParams& p, SegCursor& c, uint32_t gb) {
     if (gb < c.end) return;
@@ -107,6 +109,8 @@ __device__ __forceinline__ void seek_seg(const ScanParams& p, SegCursor& c, uint
     c.blk = gld(&p.seg[lo].blk);
     c.scale = gld(&p.seg[lo].scale);
     c.blk16 = gld(&p.seg[lo].blk16);
+    c.blk8 = gld(&p.seg[lo].blk8);
+    c.scale8 = gld(&p.seg[lo].scale8);
 }
 
 // slots[q][0..k) always hold f32 scores of k DISTINCT rows (or -inf), each slot only ever grows, so
@@ -260,6 +264,49 @@ __global__ __launch_bounds__(256) void coarse_pack_kernel(const float4* __restri
             out = __builtin_bit_cast(uint4, __builtin_convertvector(v * sc, bf16x8));  // the conversion the f32 scan kernel does
         }
         blk16[((size_t)b * D8 + f8) * 32 + r] = out;
+    }
+}
+
+
+// Int8 screening copy of blocks [first_block, nblocks), one wave per block: lane (r, h) owns row r and every
+// other 16-feature piece.  Pass 1: max |y_i| of the row (y = x * scale); pass 2: x^_i = rint(y_i * s_row),
+// s_row = 127 / max.  Rows that are not searchable get zeros and scale8 = NaN (no comparison with a NaN
+// threshold succeeds, so the scan drops them without looking); an all-zero searchable row (dot metric) gets s_row = 1.
+__global__ __launch_bounds__(256) void coarse_pack8_kernel(const float4* __restrict__ blk, const float* __restrict__ scale,
+                                                           uint4* __restrict__ blk8, float* __restrict__ scale8, uint32_t first_block,
+                                                           uint32_t nblocks, int D4) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int D16 = ((D4 * 4 + 127) & ~127) >> 4;
+    for (uint32_t b = first_block + blockIdx.x * 4 + (threadIdx.x >> 6); b < nblocks; b += gridDim.x * 4) {
+        const float sc = scale[(size_t)b * 32 + r];
+        const float4* src = blk + (size_t)b * D4 * 32 + r;
+        float mx = 0.0f;
+        for (int g = h; g < D16; g += 2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e < D4) {
+                    const float4 v = src[(size_t)(4 * g + e) * 32];
+                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x * sc), fabsf(v.y * sc)), fmaxf(fabsf(v.z * sc), fabsf(v.w * sc))));
+                }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const bool searchable = sc != 0.0f && mx < __builtin_inff();  // (NaN features: fmaxf ignores them; such rows have scale 0)
+        const float s_row = !searchable ? 0.0f : (mx > 0.0f ? 127.0f / mx : 1.0f);
+        for (int g = h; g < D16; g += 2) {
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (searchable && 4 * g + e < D4) {
+                    const float4 v = src[(size_t)(4 * g + e) * 32];
+                    const float y[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int qv = max(-127, min(127, (int)rintf(y[j] * s_row)));
+                        w[e] |= (uint32_t)(qv & 0xff) << (8 * j);
+                    }
+                }
+            blk8[((size_t)b * D16 + g) * 32 + r] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        if (h == 0) scale8[(size_t)b * 32 + r] = searchable ? s_row : __builtin_nanf("");
     }
 }
 
@@ -803,6 +850,51 @@ __device__ __forceinline__ float wave_dot_f32(const float* qf, const float4* row
     return part;
 }
 
+// The coarse survivors of one (row block, 32-query tile) of an MFMA scan: `mask` = this lane's surviving
+// accumulators (bit i = row (i&3) + 8*(i>>2) + 4*(lane>>5) of the block, query 32*t + (lane&31)).
+// Rare path (a few hundred coarse survivors per query over 10^8 rows; every wave also takes it a handful of
+// times while the thresholds are still loose).  Each survivor is handled by the whole wave: exact-f32 score
+// from a read of that f32 row, fine test against the current threshold, and only then the list append and
+// the offer to the running top-k.
+__device__ __forceinline__ void fine_survivors(const ScanParams& p, uint32_t mask, int t, const SegCursor& esc, uint32_t elb,
+                                               const uint32_t* ltau0, int lane, int D4) {
+    unsigned long long ball = __ballot(mask != 0);
+    if (!ball) return;
+    const bool feeds = !(esc.si == 0 && elb < p.seed_blocks);
+    const float* scp = esc.scale + (size_t)elb * 32;
+    const float4* bbase = esc.blk + (size_t)elb * D4 * 32;
+    const int Dp = D4 * 4;
+    while (ball) {
+        const int src = __builtin_ctzll(ball);
+        ball &= ball - 1;
+        uint32_t m = __builtin_amdgcn_readlane(mask, src);
+        const int q = 32 * t + (src & 31), hh = src >> 5;
+        const float m32 = gld(&p.margin32[q]);
+        while (m) {
+            const int i = __builtin_ctz(m);
+            m &= m - 1;
+            const int rib = (i & 3) + 8 * (i >> 2) + 4 * hh;  // row of the block this accumulator holds
+            // row scale, threshold and the row itself are requested together: one memory round trip
+            // per survivor (tested one after the other they were three, ~6 us under a saturated stream)
+            const float sc = gld(&scp[rib]);
+            const uint32_t tkey = ld_relaxed(&p.tau[q * kHot]);
+            const float dot = wave_dot_f32(p.qf32 + (size_t)q * Dp, bbase + rib, D4, lane);
+            if (sc == 0.0f) continue;  // padding / unsearchable row
+            const float s32 = dot * sc;
+            const float taun = key_f32(max(ltau0[q], tkey));
+            if (s32 < taun - m32) continue;
+            if (lane == 0) {
+                const uint32_t at = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
+                if (at < p.cand_cap) {
+                    gst(&p.cand[(size_t)q * p.cand_cap + at], ((uint64_t)(uint32_t)esc.si << 32) | (elb * 32 + (uint32_t)rib));
+                    gst(&p.cand_s[(size_t)q * p.cand_cap + at], s32);
+                }
+            }
+            if (feeds && isfinite(s32) && s32 > taun) offer_slot_wave(p, q, s32, lane);
+        }
+    }
+}
+
 // SRC16: stream the segments' screening copies (bf16, scale folded in: scan.h) instead of converting the f32 rows —
 // half the bytes per row and no conversion work; a chunk is then 4 pieces per lane instead of 8.
 template <int NT, bool NTL, int WPB, int NBUF, bool SRC16>
@@ -903,50 +995,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
             for (int i = 0; i < 16; ++i) any |= !(acc[t][i] < thr[t]);
         }
         if (__any(any)) {
-            // Rare path (a few hundred coarse survivors per query over 10^8 rows; every wave also takes it
-            // a handful of times while the thresholds are still loose).  Each survivor is handled by the
-            // whole wave: exact-f32 score from a second read of that row, fine test against the current
-            // threshold, and only then the list append and the offer to the running top-k.
-            const bool feeds = !(esc.si == 0 && elb < p.seed_blocks);
-            const float* scp = esc.scale + (size_t)elb * 32;
-            const float4* bbase = esc.blk + (size_t)elb * D4 * 32;
-            const int Dp = D4 * 4;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 uint32_t mask = 0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mask |= (!(acc[t][i] < thr[t])) ? (1u << i) : 0u;
-                unsigned long long ball = __ballot(mask != 0);
-                while (ball) {
-                    const int src = __builtin_ctzll(ball);
-                    ball &= ball - 1;
-                    uint32_t m = __builtin_amdgcn_readlane(mask, src);
-                    const int q = 32 * t + (src & 31), hh = src >> 5;
-                    const float m32 = gld(&p.margin32[q]);
-                    while (m) {
-                        const int i = __builtin_ctz(m);
-                        m &= m - 1;
-                        const int rib = (i & 3) + 8 * (i >> 2) + 4 * hh;  // row of the block this accumulator holds
-                        // row scale, threshold and the row itself are requested together: one memory round trip
-                        // per survivor (tested one after the other they were three, ~6 us under a saturated stream)
-                        const float sc = gld(&scp[rib]);
-                        const uint32_t tkey = ld_relaxed(&p.tau[q * kHot]);
-                        const float dot = wave_dot_f32(p.qf32 + (size_t)q * Dp, bbase + rib, D4, lane);
-                        if (sc == 0.0f) continue;  // padding / unsearchable row
-                        const float s32 = dot * sc;
-                        const float taun = key_f32(max(ltau0[q], tkey));
-                        if (s32 < taun - m32) continue;
-                        if (lane == 0) {
-                            const uint32_t at = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
-                            if (at < p.cand_cap) {
-                                gst(&p.cand[(size_t)q * p.cand_cap + at],
-                                    ((uint64_t)(uint32_t)esc.si << 32) | (elb * 32 + (uint32_t)rib));
-                                gst(&p.cand_s[(size_t)q * p.cand_cap + at], s32);
-                            }
-                        }
-                        if (feeds && isfinite(s32) && s32 > taun) offer_slot_wave(p, q, s32, lane);
-                    }
-                }
+                fine_survivors(p, mask, t, esc, elb, ltau0, lane, D4);
             }
         }
 #pragma unroll
@@ -1024,6 +1078,210 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
             PCV_STEP(3, 4)
             PCV_STEP(4, 5)
         }
+    }
+#undef PCV_STEP
+}
+
+// MFMA scan over the int8 screening copies (scan.h): the same flat (block, chunk) stream as scan_mfma_kernel with
+// chunks of 128 features (4 k-steps of v_mfma_i32_32x32x32_i8, 4 pieces of 16 bytes per lane), 384 B per 384-d row.
+// The query tile is quantised by every workgroup itself while it is staged (q^_i = rint(q'_i * s_q), s_q = 127 / max|q'_i|),
+// rows padded to an odd number of 16-byte pieces so the 16-lane ds_read_b128 groups are conflict-free without a swizzle.
+// Coarse test on the exact integer dot product `acc` of row r and query q (proof: scan.h):
+//     keep  iff  acc >= s_row * U_q - V_q,     U_q = (tau_q - eps32') s_q - 0.5 sqrt(D) |y|,   V_q = 0.5 |q'|_1 s_q + 0.25 D
+// (|y| = 1 for cosine, max row norm for dot; constants carry rounding slack).  Survivors take the same wave-cooperative
+// exact-f32 fine screen as in scan_mfma_kernel.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// Queries of the pass -> int8 tile of the int8 screen, one wave per tile row: q^_i = rint(q'_i * s_q), s_q = 127 / max|q'_i|
+// (q' = the scan-side query prep_seed wrote), and the per-query constants of the test (scan_mfma8_kernel).  Tile rows
+// beyond the batch are zeros with s_q = 0.
+__global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int Dp = p.D4 * 4, Dp8 = (Dp + 127) & ~127;
+    const bool have = q < p.B;
+    const float* src = p.qf32 + (size_t)q * Dp;
+    float x[40];  // Dp <= 2560 (the LDS bound of the tile keeps it far below)
+    float mx = 0.0f, l1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 40; ++j) {
+        const int i = lane + 64 * j;
+        x[j] = (have && i < Dp) ? gld(&src[i]) : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 40; ++j) {
+        mx = fmaxf(mx, fabsf(x[j]));
+        l1 += fabsf(x[j]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+        l1 += __shfl_xor(l1, off);
+    }
+    const float s_q = (mx > 0.0f && mx < __builtin_inff() && l1 < __builtin_inff()) ? 127.0f / mx : 0.0f;
+    int8_t* row = p.q8 + (size_t)q * Dp8;
+#pragma unroll
+    for (int j = 0; j < 40; ++j) {
+        const int i = lane + 64 * j;
+        if (i < Dp8) row[i] = (int8_t)max(-127, min(127, (int)rintf((s_q != 0.0f ? x[j] : 0.0f) * s_q)));
+    }
+    if (lane == 0) {
+        p.q8c[2 * q] = s_q;
+        p.q8c[2 * q + 1] = 0.5002f * l1 * s_q + 0.2501f * (float)Dp8 + 4.0f;
+    }
+}
+
+template <int NT, bool NTL, int WPB, int NBUF>
+__global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
+    extern __shared__ uint4 lq8[];  // [NT*32][LDQ] pieces of 16 int8
+    const int D4 = p.D4;
+    const int Dp = D4 * 4;
+    const int Dp8 = (Dp + 127) & ~127;
+    const int P16 = Dp8 >> 4;   // pieces per row
+    const int LDQ = P16 + 1;    // odd
+    const int NCH = Dp8 >> 7;   // chunks of 128 features
+    __shared__ uint32_t ltau0[NT * 32];
+    __shared__ float lsq[NT * 32], lvq[NT * 32];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < NT * 32 * P16; i += WPB * 64) {  // the tile quantize_queries_kernel prepared
+        const int q = i / P16, pc = i - q * P16;
+        lq8[(size_t)q * LDQ + pc] = __builtin_bit_cast(uint4, gld4((const float4*)p.q8 + i));
+    }
+    for (int q = threadIdx.x; q < NT * 32; q += WPB * 64) {
+        lsq[q] = gld(&p.q8c[2 * q]);
+        lvq[q] = gld(&p.q8c[2 * q + 1]);
+    }
+    for (int q = threadIdx.x >> 2; q < NT * 32; q += WPB * 16) {
+        const uint32_t key = seed_threshold_key(p, q, threadIdx.x & 3);
+        if ((threadIdx.x & 3) == 0) ltau0[q] = key;
+    }
+    __syncthreads();
+    const int c = lane & 31, h = lane >> 5;
+    const float nrm = (p.metric == PCV_METRIC_DOT) ? p.max_norm : 1.0f;
+    const float c1 = 0.5002f * sqrtf((float)Dp8) * nrm;
+    float sq[NT], vq[NT], e32[NT];
+    uint32_t tau0[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bool live = 32 * t + c < p.B;
+        sq[t] = lsq[32 * t + c];
+        vq[t] = lvq[32 * t + c];
+        e32[t] = live ? 0.5f * gld(&p.margin32[32 * t + c]) : 0.0f;
+        tau0[t] = ltau0[32 * t + c];
+    }
+
+    const uint32_t total_waves = gridDim.x * WPB;
+    if (blockIdx.x * WPB + wave >= p.total_blocks) return;
+
+    i32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0;
+
+    auto enter_block = [&](BlockCursor& k, uint32_t gb) {
+        k.gb = gb;
+        k.ch = 0;
+        if (gb < p.total_blocks) {
+            seek_seg(p, k.sc, gb);
+            k.lb = gb - k.sc.begin;
+            k.base = (const float4*)k.sc.blk8 + (size_t)k.lb * P16 * 32 + h * 32 + c;
+        }
+    };
+    BlockCursor cons, prod;
+    enter_block(cons, blockIdx.x * WPB + wave);
+    prod = cons;
+
+    float4 buf[NBUF][4];
+    // lane's piece of k-step ks of a chunk: f16 = chunk*8 + ks*2 + h  (h folded into base)
+    auto produce = [&](float4 (&b)[4]) {
+        if (prod.gb >= p.total_blocks) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 8 + i * 2) * 32);
+        if (++prod.ch == NCH) enter_block(prod, prod.gb + total_waves);
+    };
+
+    // thresholds and the quantisation scales of the block being finished, requested one chunk ahead of the epilogue:
+    // lane (c, h) tests rows 4h + {0..3, 8..11, 16..19, 24..27} of the block
+    uint32_t tauk[NT];
+    float srv = 0.0f;  // lane (c, h) holds the scale of row c of the block; the epilogue reads the rows it tests across lanes
+    auto prefetch = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? max(tau0[t], ld_relaxed(&p.tau[(32 * t + c) * kHot])) : 0u;
+        srv = gld(cons.sc.scale8 + (size_t)cons.lb * 32 + c);
+    };
+
+    auto epilogue = [&](const SegCursor& esc, uint32_t elb) {
+        if (NCH < 2) prefetch();
+        float sr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r0 = (i & 3) + 8 * (i >> 2);  // row of accumulator i for h = 0; h = 1 holds row r0 + 4
+            const int lo = __builtin_amdgcn_readlane(__builtin_bit_cast(int, srv), r0);
+            const int hi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, srv), r0 + 4);
+            sr[i] = __builtin_bit_cast(float, h ? hi : lo);
+        }
+        float U[NT];
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int q = 32 * t + c;
+            const float T = (key_f32(tauk[t]) - e32[t]) * sq[t];
+            // lowered by 2e-6 relative (f32 rounding of T and of the product with s_row) and by the |x^|_1 term
+            U[t] = (q < p.B) ? (sq[t] != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : -__builtin_inff()) : __builtin_inff();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= (float)acc[t][i] >= fmaf(sr[i], U[t], -vq[t]);
+        }
+        if (__any(any)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint32_t mask = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mask |= ((float)acc[t][i] >= fmaf(sr[i], U[t], -vq[t])) ? (1u << i) : 0u;
+                fine_survivors(p, mask, t, esc, elb, ltau0, lane, D4);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0;
+    };
+
+    auto consume = [&](const float4 (&b)[4]) {
+        if (NCH >= 2 && cons.ch == NCH - 2) prefetch();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const i32x4 a = __builtin_bit_cast(i32x4, b[ks]);
+            const int pc = 2 * (cons.ch * 4 + ks) + h;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const i32x4 q8 = *(const i32x4*)&lq8[(size_t)(32 * t + c) * LDQ + pc];
+                acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
+            }
+        }
+        if (++cons.ch == NCH) {
+            epilogue(cons.sc, cons.lb);
+            enter_block(cons, cons.gb + total_waves);
+        }
+    };
+
+#define PCV_STEP(REFILL, CONS)          \
+    produce(buf[REFILL]);               \
+    consume(buf[CONS]);                 \
+    if (cons.gb >= p.total_blocks) return;
+    produce(buf[0]);
+    static_assert(NBUF == 4, "four chunk buffers");
+    produce(buf[1]);
+    produce(buf[2]);
+    while (true) {
+        PCV_STEP(3, 0)
+        PCV_STEP(0, 1)
+        PCV_STEP(1, 2)
+        PCV_STEP(2, 3)
     }
 #undef PCV_STEP
 }
@@ -1532,6 +1790,59 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
         if (ntl) launch_mfma_shape<4, true>(st, dp, grid, lds, wide, src16, nbuf, wpb);
         else launch_mfma_shape<4, false>(st, dp, grid, lds, wide, src16, nbuf, wpb);
     }
+    PCV_LAUNCHED();
+}
+
+// (32*NT rows x (P16+1) pieces) of int8 query tile per workgroup
+static size_t mfma8_lds(int nt, int Dp) { return (size_t)nt * 32 * ((((Dp + 127) & ~127) >> 4) + 1) * 16; }
+int mfma8_pass_queries(int Dp) {
+    for (int nt : {4, 2, 1})
+        if (mfma8_lds(nt, Dp) <= 156 * 1024) return nt * 32;
+    return 0;
+}
+
+template <int NT, bool NTL>
+static void launch_mfma8_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
+    static size_t lds_allowed = 64 * 1024;
+    if (lds > lds_allowed) {
+        PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_kernel<NT, NTL, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_allowed = lds;
+    }
+    scan_mfma8_kernel<NT, NTL, 4, 4><<<grid, 256, lds, st>>>(dp);
+}
+
+void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
+    if (p.total_blocks == 0) return;
+    const int NT = p.B <= 32 ? 1 : (p.B <= 64 ? 2 : 4);
+    const size_t lds = mfma8_lds(NT, p.D4 * 4);
+    const unsigned gm = (p.flags >> 8) & 0xff;
+    const bool ntl = (p.flags & 1) == 0;
+    const unsigned most = NT == 4 ? 2 : 3;  // waves per SIMD the register budget allows = 256-thread workgroups per CU
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(most, (156 * 1024) / lds));
+    unsigned grid = (unsigned)num_cus * (gm ? gm : per_cu);
+    const unsigned need = (p.total_blocks + 3) / 4;
+    if (grid > need) grid = need;
+    if (p.D4 * 4 > 2560) PCV_FAIL(PCV_ERR_UNSUPPORTED, "int8 screen: dimension %d is too large", p.D);
+    quantize_queries_kernel<<<NT * 32 / 4, 256, 0, st>>>(dp);
+    PCV_LAUNCHED();
+    if (NT == 1) {
+        if (ntl) launch_mfma8_variant<1, true>(st, dp, grid, lds);
+        else launch_mfma8_variant<1, false>(st, dp, grid, lds);
+    } else if (NT == 2) {
+        if (ntl) launch_mfma8_variant<2, true>(st, dp, grid, lds);
+        else launch_mfma8_variant<2, false>(st, dp, grid, lds);
+    } else {
+        if (ntl) launch_mfma8_variant<4, true>(st, dp, grid, lds);
+        else launch_mfma8_variant<4, false>(st, dp, grid, lds);
+    }
+    PCV_LAUNCHED();
+}
+
+void launch_coarse_pack8(hipStream_t st, const float4* blk, const float* scale, uint4* blk8, float* scale8, uint32_t first_block,
+                         uint32_t nblocks, int D4) {
+    if (first_block >= nblocks) return;
+    const unsigned grid = (unsigned)std::min<uint32_t>((nblocks - first_block + 3) / 4, 1u << 16);
+    coarse_pack8_kernel<<<grid, 256, 0, st>>>(blk, scale, blk8, scale8, first_block, nblocks, D4);
     PCV_LAUNCHED();
 }
 

@@ -27,7 +27,9 @@ struct Segment {
     float4* blk = nullptr;
     float* scale = nullptr;
     int64_t* ids = nullptr;  // nullptr -> implicit ids id0 + row (synthetic rows)
-    uint4* blk16 = nullptr;  // screening copy (scan.h), built at finalize for the rows that have their scale
+    uint4* blk16 = nullptr;  // bf16 screening copy (scan.h), built at finalize for the rows that have their scale
+    uint4* blk8 = nullptr;   // int8 screening copy + its per-row quantisation scales
+    float* scale8 = nullptr;
     int64_t id0 = 0;
     int64_t pos0 = 0;
     uint32_t nrows = 0, cap_rows = 0, scaled_rows = 0;
@@ -92,6 +94,8 @@ struct pcv_searcher {
     // per-search workspace (sized for one pass of <= 128 queries)
     DevBuf<float> d_qf32, d_qraw, d_margin, d_margin32;
     DevBuf<uint16_t> d_qbf16;
+    DevBuf<int8_t> d_q8;
+    DevBuf<float> d_q8c;
     DevBuf<float> d_cand_s;
     DevBuf<uint32_t> d_tau, d_slots, d_cnt;
     DevBuf<uint64_t> d_cand;
@@ -112,7 +116,7 @@ struct pcv_searcher {
     uint32_t scan_flags = 0;  // tuning knobs, PCV_SCAN_FLAGS
     int screen_copy = PCV_SCREEN_COPY_AUTO;  // pcv_searcher_set_screening_copy
     bool screen_copy_gave_way = false;       // AUTO: the copies were dropped to make room for rows
-    bool copies_complete = false;            // every row of every segment is covered by a screening copy
+    int copies_kind = 0;                     // 0: not every row of every segment is covered by a screening copy; 1 bf16; 2 int8
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // a pass queued by enqueue_pass and not yet collected by finish_pass
     struct Pending {
@@ -120,7 +124,7 @@ struct pcv_searcher {
         bool done = false;  // nothing was launched (no selected rows): only the stream has to drain
         int B = 0;
         int64_t rows = 0;
-        bool src16 = false;  // the scan streamed the screening copies
+        int src = 0;  // what the scan streamed: 0 f32 rows, 1 bf16 copies, 2 int8 copies
     } pending;
 
     Source* find_source(int64_t id) {
@@ -143,18 +147,28 @@ void free_segment(Segment& g) {
     if (g.scale) (void)hipFree(g.scale);
     if (g.ids) (void)hipFree(g.ids);
     if (g.blk16) (void)hipFree(g.blk16);
+    if (g.blk8) (void)hipFree(g.blk8);
+    if (g.scale8) (void)hipFree(g.scale8);
     g = Segment();
 }
 
 void drop_screening_copies(pcv_searcher* s) {
-    s->copies_complete = false;
+    s->copies_kind = 0;
     for (auto& src : s->sources)
-        for (auto& g : src.segs)
-            if (g.blk16) {
-                (void)hipFree(g.blk16);
-                g.blk16 = nullptr;
-                g.copied_rows = 0;
-            }
+        for (auto& g : src.segs) {
+            if (g.blk16) (void)hipFree(g.blk16);
+            if (g.blk8) (void)hipFree(g.blk8);
+            if (g.scale8) (void)hipFree(g.scale8);
+            g.blk16 = g.blk8 = nullptr;
+            g.scale8 = nullptr;
+            g.copied_rows = 0;
+        }
+}
+
+// the form AUTO stands for
+inline int copy_kind_wanted(const pcv_searcher* s) {
+    if (s->screen_copy == PCV_SCREEN_COPY_OFF || s->screen_copy_gave_way) return 0;
+    return s->screen_copy == PCV_SCREEN_COPY_BF16 ? 1 : 2;
 }
 
 // Allocate a segment with room for `cap_rows` rows; zero-filled so padding rows / features are exact
@@ -274,20 +288,39 @@ void append_rows(pcv_searcher* s, Source& src, const int64_t* ids, const void* r
     src.next_implicit_id += n;
 }
 
-// Screening copies (scan.h) of the rows that got their scale since the last finalize.  ON: a failed allocation
-// is an error; AUTO: it switches the copies off for this searcher (the f32 rows are scanned instead).
+// Screening copies (scan.h) of the rows that got their scale since the last finalize.  Asked for explicitly: a failed
+// allocation is an error; AUTO: it switches the copies off for this searcher (the f32 rows are scanned instead).
 void build_screening_copies(pcv_searcher* s, Source& src) {
-    if (s->screen_copy == PCV_SCREEN_COPY_OFF || s->screen_copy_gave_way) return;
+    const int kind = copy_kind_wanted(s);
+    if (kind == 0) return;
     hipStream_t st = s->ctx->stream;
     for (auto& g : src.segs) {
-        if (g.nrows == 0 || g.copied_rows >= g.scaled_rows) continue;
-        if (!g.blk16) {
-            const size_t bytes = (size_t)(g.cap_rows / kBlockRows) * (s->D4 / 2) * 32 * sizeof(uint4);
-            const hipError_t e = hipMalloc((void**)&g.blk16, bytes);
+        if (g.nrows == 0) continue;
+        const bool present = kind == 1 ? g.blk16 != nullptr : g.blk8 != nullptr;
+        if (present && g.copied_rows >= g.scaled_rows) continue;
+        if (!present) {
+            // (a copy of the other kind, left from a mode change, goes first)
+            if (g.blk16) (void)hipFree(g.blk16);
+            if (g.blk8) (void)hipFree(g.blk8);
+            if (g.scale8) (void)hipFree(g.scale8);
+            g.blk16 = g.blk8 = nullptr;
+            g.scale8 = nullptr;
+            g.copied_rows = 0;
+            const size_t nblk = g.cap_rows / kBlockRows;
+            const size_t bytes = kind == 1 ? nblk * (s->D4 / 2) * 32 * sizeof(uint4) : nblk * (size_t)(((s->Dp + 127) & ~127) / 16) * 32 * sizeof(uint4);
+            hipError_t e = hipMalloc(kind == 1 ? (void**)&g.blk16 : (void**)&g.blk8, bytes);
+            if (e == hipSuccess && kind == 2) {
+                e = hipMalloc((void**)&g.scale8, (size_t)g.cap_rows * sizeof(float));
+                if (e != hipSuccess) {
+                    (void)hipFree(g.blk8);
+                    g.blk8 = nullptr;
+                }
+            }
             if (e != hipSuccess) {
                 (void)hipGetLastError();
-                g.blk16 = nullptr;
-                if (s->screen_copy == PCV_SCREEN_COPY_ON)
+                g.blk16 = g.blk8 = nullptr;
+                g.scale8 = nullptr;
+                if (s->screen_copy != PCV_SCREEN_COPY_AUTO)
                     PCV_FAIL(PCV_ERR_DEVICE, "hipMalloc of %.2f GB for the screening copy of %u rows failed: %s", bytes / 1e9, g.cap_rows,
                              hipGetErrorString(e));
                 PCV_HIP(hipStreamSynchronize(st));
@@ -295,9 +328,11 @@ void build_screening_copies(pcv_searcher* s, Source& src) {
                 s->screen_copy_gave_way = true;
                 return;
             }
-            g.copied_rows = 0;
         }
-        launch_coarse_pack(st, g.blk, g.scale, g.blk16, g.copied_rows / kBlockRows, g.nblocks(), s->D4);
+        if (kind == 1)
+            launch_coarse_pack(st, g.blk, g.scale, g.blk16, g.copied_rows / kBlockRows, g.nblocks(), s->D4);
+        else
+            launch_coarse_pack8(st, g.blk, g.scale, g.blk8, g.scale8, g.copied_rows / kBlockRows, g.nblocks(), s->D4);
         g.copied_rows = g.scaled_rows;
     }
 }
@@ -325,10 +360,10 @@ void do_finalize(pcv_searcher* s) {
                                     [](const Source& x) { return x.segs.empty(); }),
                      s->sources.end());
     assign_positions(s);
-    s->copies_complete = s->screen_copy != PCV_SCREEN_COPY_OFF && !s->sources.empty();
+    s->copies_kind = s->sources.empty() ? 0 : copy_kind_wanted(s);
     for (const auto& src : s->sources)
         for (const auto& g : src.segs)
-            if (g.nrows > 0 && (g.blk16 == nullptr || g.copied_rows < g.nrows)) s->copies_complete = false;
+            if (g.nrows > 0 && ((s->copies_kind == 1 ? g.blk16 == nullptr : g.blk8 == nullptr) || g.copied_rows < g.nrows)) s->copies_kind = 0;
     uint32_t bits = 0;
     PCV_HIP(hipMemcpyAsync(&bits, s->d_max_norm_bits, 4, hipMemcpyDeviceToHost, st));
     PCV_HIP(hipStreamSynchronize(st));
@@ -362,6 +397,8 @@ void ensure_workspace(pcv_searcher* s) {
     s->d_qf32.ensure(Q * s->Dp);
     s->d_qraw.ensure(Q * s->Dp);
     s->d_qbf16.ensure(Q * s->Dp);
+    s->d_q8.ensure(Q * (size_t)((s->Dp + 127) & ~127));
+    s->d_q8c.ensure(Q * 2);
     s->d_margin.ensure(Q);
     s->d_margin32.ensure(Q);
     s->d_tau.ensure(Q * kHot);
@@ -419,11 +456,13 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p = ScanParams{};
     uint32_t blk0 = 0;
     int64_t rows = 0;
-    bool src16 = kernel == PCV_KERNEL_MFMA && s->screen_copy != PCV_SCREEN_COPY_OFF;
+    // stream the screening copies iff every selected segment has one of the kind the searcher keeps
+    int src_kind = (kernel == PCV_KERNEL_MFMA) ? copy_kind_wanted(s) : 0;
+    if (src_kind == 2 && (mfma8_pass_queries(s->Dp) < B || s->Dp > 2560 || getenv("PCV_NO_INT8_SCAN"))) src_kind = 0;
     for (int i = 0; i < nseg; ++i) {
         const Segment& g = *segs[i].g;
-        tab[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), blk0, 0, g.blk16};
-        src16 = src16 && g.blk16 != nullptr && g.copied_rows >= g.nrows;
+        tab[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), blk0, 0, g.blk16, g.blk8, g.scale8};
+        if ((src_kind == 1 ? g.blk16 == nullptr : (src_kind == 2 ? g.blk8 == nullptr : false)) || g.copied_rows < g.nrows) src_kind = 0;
         PCV_REQUIRE((uint64_t)blk0 + g.nblocks() < 0xffffff00ull, "search: more than 2^32 row blocks in one launch");
         blk0 += g.nblocks();
         rows += g.nrows;
@@ -440,6 +479,8 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.queries = reinterpret_cast<const float*>(s->d_pass + L.off_q);
     p.qf32 = s->d_qf32.p;
     p.qbf16 = s->d_qbf16.p;
+    p.q8 = s->d_q8.p;
+    p.q8c = s->d_q8c.p;
     p.qraw = s->d_qraw.p;
     p.margin = s->d_margin.p;
     p.margin32 = s->d_margin32.p;
@@ -453,7 +494,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.cnt_host = s->pin->cnt;
     p.flag_rec = d_flag;
     p.cand_cap = s->cand_cap;
-    p.flags = (s->scan_flags & ~16u) | (src16 ? 16u : 0u);
+    p.flags = (s->scan_flags & ~(16u | 64u)) | (src_kind == 1 ? 16u : 0u) | (src_kind == 2 ? 64u : 0u);
     const uint32_t seed_parts = ((s->scan_flags >> 16) & 0xff) ? ((s->scan_flags >> 16) & 0xff) : kSeedParts;  // tuning
     p.seed_blocks = std::min<uint32_t>(std::min<uint32_t>(seed_parts, kSeedParts) * kSeedPartRows / kBlockRows, segs[0].g->nblocks());
     // |s - c| bounds of the screening scores, relative to |q||x| (DESIGN.md §screening error): an f32 FMA
@@ -472,7 +513,9 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     launch_upload(st, s->pin_pass, s->d_pass, bytes);
     launch_prep_seed(st, p, dp, tab[0]);
     PCV_HIP(hipEventRecord(s->ev[1], st));
-    if (kernel == PCV_KERNEL_MFMA)
+    if (kernel == PCV_KERNEL_MFMA && src_kind == 2)
+        launch_scan_mfma8(st, p, dp, s->ctx->num_cus);
+    else if (kernel == PCV_KERNEL_MFMA)
         launch_scan_mfma(st, p, dp, s->ctx->num_cus);
     else
         launch_scan_wave(st, p, dp, s->ctx->num_cus);
@@ -483,7 +526,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     s->pending.done = false;
     s->pending.B = B;
     s->pending.rows = rows;
-    s->pending.src16 = src16;
+    s->pending.src = src_kind;
     s->stats.host_enqueue_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
@@ -510,8 +553,8 @@ bool finish_pass(pcv_searcher* s) {
     s->stats.scan_launches += 1;
     s->stats.rows_scanned += rows;
     s->stats.bytes_algorithmic += rows * (int64_t)s->D * 4;
-    s->stats.bytes_streamed += rows * (int64_t)s->D * (s->pending.src16 ? 2 : 4);
-    s->stats.screening_copy = s->pending.src16 ? 1 : 0;
+    s->stats.bytes_streamed += rows * (int64_t)s->D * (s->pending.src == 2 ? 1 : (s->pending.src == 1 ? 2 : 4));
+    s->stats.screening_copy = s->pending.src;
 
     const uint32_t* cnt = s->pin->cnt;
     uint32_t mx = 0;
@@ -554,7 +597,7 @@ int pick_kernel(const pcv_searcher* s, int B) {
         PCV_FAIL(PCV_ERR_UNSUPPORTED, "the MFMA kernel cannot hold a %d-d query tile in LDS", s->D);
     if (s->kernel == PCV_KERNEL_WAVE || s->kernel == PCV_KERNEL_MFMA) return s->kernel;
     // with screening copies the MFMA kernel streams half the bytes of the wave kernel, whatever the batch
-    if (mfma_ok && s->copies_complete) return PCV_KERNEL_MFMA;
+    if (mfma_ok && s->copies_kind != 0) return PCV_KERNEL_MFMA;
     return (B <= kMaxWaveQueries || !mfma_ok) ? PCV_KERNEL_WAVE : PCV_KERNEL_MFMA;
 }
 
@@ -666,7 +709,7 @@ pcv_status pcv_searcher_create(pcv_ctx* ctx, int dim, int metric, pcv_searcher**
         if (const char* f = getenv("PCV_SCAN_FLAGS")) s->scan_flags = (uint32_t)strtoul(f, nullptr, 0);
         if (const char* f = getenv("PCV_SCREEN_COPY")) {  // 0 off, 1 on, 2 auto
             const int mode = atoi(f);
-            if (mode >= PCV_SCREEN_COPY_OFF && mode <= PCV_SCREEN_COPY_AUTO) s->screen_copy = mode;
+            if (mode >= PCV_SCREEN_COPY_OFF && mode <= PCV_SCREEN_COPY_INT8) s->screen_copy = mode;
         }
         PCV_HIP(hipMalloc((void**)&s->d_max_norm_bits, 4));
         // on the stream the row_scales atomics will run on (the context stream does not wait for the null stream)
@@ -693,6 +736,8 @@ pcv_status pcv_searcher_destroy(pcv_searcher* s) {
         s->d_margin.release();
         s->d_margin32.release();
         s->d_qbf16.release();
+        s->d_q8.release();
+        s->d_q8c.release();
         s->d_cand_s.release();
         s->d_tau.release();
         s->d_slots.release();
@@ -926,8 +971,7 @@ pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel) {
 pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr, "searcher_set_screening_copy: searcher is NULL");
-        PCV_REQUIRE(mode == PCV_SCREEN_COPY_OFF || mode == PCV_SCREEN_COPY_ON || mode == PCV_SCREEN_COPY_AUTO,
-                    "searcher_set_screening_copy: unknown mode %d", mode);
+        PCV_REQUIRE(mode >= PCV_SCREEN_COPY_OFF && mode <= PCV_SCREEN_COPY_INT8, "searcher_set_screening_copy: unknown mode %d", mode);
         std::lock_guard<std::mutex> lk(s->mu);
         PCV_HIP(hipSetDevice(s->ctx->device));
         if (mode == PCV_SCREEN_COPY_OFF) {

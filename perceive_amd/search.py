@@ -224,9 +224,10 @@ class Searcher:
         _ffi.check(_ffi.lib().pcv_searcher_set_candidate_capacity(self._handle, int(n_candidates)))
 
     def set_screening_copy(self, mode="auto"):
-        """"off" | "on" | "auto": keep a bf16 copy of the scaled rows next to the f32 rows so that the coarse screen
-        streams half the bytes (pcv_searcher_set_screening_copy); built at the next finalize."""
-        _ffi.check(_ffi.lib().pcv_searcher_set_screening_copy(self._handle, {"off": 0, "on": 1, "auto": 2}[mode]))
+        """"off" | "bf16" | "int8" | "auto" (= int8): keep a narrow copy of the scaled rows next to the f32 rows so that
+        the coarse screen streams a half / a quarter of the bytes (pcv_searcher_set_screening_copy); built at the next
+        finalize.  Results do not depend on it."""
+        _ffi.check(_ffi.lib().pcv_searcher_set_screening_copy(self._handle, {"off": 0, "bf16": 1, "on": 1, "auto": 2, "int8": 3}[mode]))
 
     def set_shard_offset(self, first_global_pos):
         _ffi.check(_ffi.lib().pcv_searcher_set_shard_offset(self._handle, int(first_global_pos)))

@@ -100,8 +100,9 @@ pub const PCV_KERNEL_AUTO: c_int = 0;
 pub const PCV_KERNEL_WAVE: c_int = 1;
 pub const PCV_KERNEL_MFMA: c_int = 2;
 pub const PCV_SCREEN_COPY_OFF: c_int = 0;
-pub const PCV_SCREEN_COPY_ON: c_int = 1;
+pub const PCV_SCREEN_COPY_BF16: c_int = 1;
 pub const PCV_SCREEN_COPY_AUTO: c_int = 2;
+pub const PCV_SCREEN_COPY_INT8: c_int = 3;
 pub const PCV_GELU_ERF: c_int = 0;
 pub const PCV_GELU_TANH: c_int = 1;
 pub const PCV_POOL_MEAN: c_int = 0;

@@ -62,9 +62,9 @@ int main(int argc, char** argv) {
         }
     }
     EXPECT(s->search_vector({}, 10, q).empty());
-    {  // the bf16 screening copy is on by default and changes nothing but the bytes streamed
+    {  // a screening copy (int8) is kept by default and changes nothing but the bytes streamed
         auto with = s->search_vector({1, 2}, 10, q);
-        EXPECT(s->last_stats().screening_copy == 1 && s->last_stats().bytes_streamed == (int64_t)N * D * 2);
+        EXPECT(s->last_stats().screening_copy == 2 && s->last_stats().bytes_streamed == (int64_t)N * D);
         s->set_screening_copy(PCV_SCREEN_COPY_OFF);
         auto without = s->search_vector({1, 2}, 10, q);
         EXPECT(s->last_stats().screening_copy == 0 && s->last_stats().bytes_streamed == (int64_t)N * D * 4);

@@ -129,7 +129,7 @@ def test_headline_config_100m_b64_k10_mfma(big, oracle):
     ids, sc, cnt = big.search_vectors(None, k, q)
     st = big.last_stats()
     assert st["kernel_used"] == 2 and st["scan_launches"] == 1 and st["rows_scanned"] == N
-    assert st["screening_copy"] == 1 and st["bytes_streamed"] == N * D * 2  # 153.6 GB of rows + 76.8 GB of bf16 copy are resident
+    assert st["screening_copy"] == 2 and st["bytes_streamed"] == N * D  # 153.6 GB of rows + 38.8 GB of int8 screening copy are resident
     assert st["overflow_reruns"] == 0 and (cnt == k).all()
     np.testing.assert_array_equal(ids[slots, 0], pos)
     np.testing.assert_allclose(sc[slots, 0], 1.0, atol=1e-6)
@@ -144,8 +144,14 @@ def test_headline_config_100m_b64_k10_mfma(big, oracle):
     assert big.last_stats()["screening_copy"] == 0 and big.last_stats()["bytes_streamed"] == N * D * 4
     np.testing.assert_array_equal(ids, ids_f)
     np.testing.assert_array_equal(sc, sc_f)
+    big.set_screening_copy("bf16")  # the bf16 copy (76.8 GB) in place of the int8 one
+    big.finalize()
+    ids_h, sc_h, _ = big.search_vectors(None, k, q)
+    assert big.last_stats()["screening_copy"] == 1 and big.last_stats()["bytes_streamed"] == N * D * 2
+    np.testing.assert_array_equal(ids, ids_h)
+    np.testing.assert_array_equal(sc, sc_h)
     big.set_screening_copy("auto")
-    big.finalize()  # rebuilds the copy for the tests that follow
+    big.finalize()  # back to the int8 copy for the tests that follow
     big.set_kernel("auto")
 
 
@@ -160,7 +166,7 @@ def test_config2_10m_b1_k10(ctx, oracle):
     q = oracle.synth_rows(0x5EED + 1, 0, 1, D)
     ids, sc, cnt = s.search_vectors(None, 10, q)
     st = s.last_stats()
-    assert st["kernel_used"] == 2 and st["screening_copy"] == 1 and st["scan_launches"] == 1 and st["rows_scanned"] == n and cnt[0] == 10
+    assert st["kernel_used"] == 2 and st["screening_copy"] == 2 and st["scan_launches"] == 1 and st["rows_scanned"] == n and cnt[0] == 10
     _verify_topk(s, oracle, q, ids, sc, 10, n, rng, sample=1024)
     # a planted row, and agreement with the MFMA kernel on the same query
     qp = oracle.synth_rows(0x5EED, 9_999_999, 1, D)

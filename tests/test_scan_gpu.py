@@ -37,10 +37,10 @@ def g77(golden_dir):
     return np.load(os.path.join(golden_dir, "scan_n77_d100.npz"))
 
 
-@pytest.mark.parametrize("screen", ["auto", "off"])
+@pytest.mark.parametrize("screen", ["int8", "bf16", "off"])
 @pytest.mark.parametrize("kernel,B", [("auto", 1), ("auto", 3), ("auto", 64), ("wave", 64), ("mfma", 1), ("mfma", 33)])
 def test_golden_1000(ctx, oracle, g1000, kernel, B, screen):
-    # screen: with ("auto") and without ("off") the resident bf16 screening copy of the rows
+    # screen: which resident screening copy of the rows the coarse screen streams (none: the f32 rows themselves)
     k = int(g1000["k"])
     s = build(ctx, g1000["corpus"], kernel=kernel, screen=screen)
     q = g1000["queries"][:B]
@@ -55,10 +55,10 @@ def test_golden_1000(ctx, oracle, g1000, kernel, B, screen):
     assert np.abs(scores - ref32).max() < TOL
     np.testing.assert_allclose(scores, osc.astype(np.float32), rtol=0, atol=1e-7)
     st = s.last_stats()
-    mfma = kernel == "mfma" or (kernel == "auto" and (B > 4 or screen == "auto"))  # with copies the MFMA kernel streams half the bytes
+    mfma = kernel == "mfma" or (kernel == "auto" and (B > 4 or screen != "off"))  # with copies the MFMA kernel streams fewer bytes
     assert st["kernel_used"] == (2 if mfma else 1)
-    assert st["screening_copy"] == (1 if (mfma and screen == "auto") else 0)
-    assert st["bytes_streamed"] == st["rows_scanned"] * 384 * (2 if st["screening_copy"] else 4)
+    assert st["screening_copy"] == ({"int8": 2, "bf16": 1, "off": 0}[screen] if mfma else 0)
+    assert st["bytes_streamed"] == st["rows_scanned"] * 384 * {0: 4, 1: 2, 2: 1}[st["screening_copy"]]
     assert st["rows_scanned"] >= 1000 and st["overflow_reruns"] == 0
     s.close()
 
@@ -885,26 +885,28 @@ def test_screening_copy_is_invisible_in_the_results(ctx, oracle):
     rows added later, cleared sources and source filters keep it in step."""
     n, D = 300_000, 384
     for clusters in (0, 40):
-        on = pa.Searcher(ctx, D, "cosine")
-        on.set_screening_copy("on")
         off = pa.Searcher(ctx, D, "cosine")
         off.set_screening_copy("off")
-        for s in (on, off):
-            s.add_synthetic(1, n, 0xC0FFEE, n_clusters=clusters, noise=0.01 if clusters else 0.0)
-            s.finalize()
+        off.add_synthetic(1, n, 0xC0FFEE, n_clusters=clusters, noise=0.01 if clusters else 0.0)
+        off.finalize()
         rng = np.random.default_rng(3 + clusters)
-        probe = on.get_rows(rng.integers(0, n, 128))[0]
+        probe = off.get_rows(rng.integers(0, n, 128))[0]
         q = (probe + 0.3 * rng.standard_normal(probe.shape)).astype(np.float32) if clusters else rng.standard_normal((128, D)).astype(np.float32)
-        for B in (1, 4, 5, 33, 64, 128):
-            a = on.search_vectors(None, 10, q[:B])
-            assert on.last_stats()["screening_copy"] == 1 and on.last_stats()["kernel_used"] == 2
-            b = off.search_vectors(None, 10, q[:B])
-            assert off.last_stats()["screening_copy"] == 0
-            np.testing.assert_array_equal(a[0], b[0])
-            np.testing.assert_array_equal(a[1], b[1])
-        opos, _, _ = oracle.topk(q[:3], on.get_rows(np.arange(n))[0], 10)
-        np.testing.assert_array_equal(on.search_vectors(None, 10, q[:3])[0], opos)
-        on.close()
+        opos, _, _ = oracle.topk(q[:3], off.get_rows(np.arange(n))[0], 10)
+        for mode, code in (("int8", 2), ("bf16", 1)):
+            on = pa.Searcher(ctx, D, "cosine")
+            on.set_screening_copy(mode)
+            on.add_synthetic(1, n, 0xC0FFEE, n_clusters=clusters, noise=0.01 if clusters else 0.0)
+            on.finalize()
+            for B in (1, 4, 5, 33, 64, 128):
+                a = on.search_vectors(None, 10, q[:B])
+                assert on.last_stats()["screening_copy"] == code and on.last_stats()["kernel_used"] == 2
+                b = off.search_vectors(None, 10, q[:B])
+                assert off.last_stats()["screening_copy"] == 0
+                np.testing.assert_array_equal(a[0], b[0])
+                np.testing.assert_array_equal(a[1], b[1])
+            np.testing.assert_array_equal(on.search_vectors(None, 10, q[:3])[0], opos)
+            on.close()
         off.close()
     # incremental adds, a second source, clearing: the copy follows at every finalize
     rng = np.random.default_rng(9)
@@ -912,14 +914,14 @@ def test_screening_copy_is_invisible_in_the_results(ctx, oracle):
     s = pa.Searcher(ctx, 128, "cosine")
     s.add_rows(1, base, np.arange(5000))
     s.finalize()
-    assert s.search_vectors(None, 1, base[77:78])[0][0, 0] == 77 and s.last_stats()["screening_copy"] == 1
+    assert s.search_vectors(None, 1, base[77:78])[0][0, 0] == 77 and s.last_stats()["screening_copy"] == 2  # auto = int8
     extra = rng.standard_normal((333, 128)).astype(np.float32)  # lands in the spare room of the same segment, mid-block
     s.add_rows(1, extra, 5000 + np.arange(333))
     s.add_rows(2, -extra, 9000 + np.arange(333))
     s.finalize()
     got = s.search_vectors(None, 1, extra[10:11])
-    assert got[0][0, 0] == 5010 and abs(got[1][0, 0] - 1.0) < 1e-6 and s.last_stats()["screening_copy"] == 1
-    assert s.search_vectors([2], 1, -extra[5:6])[0][0, 0] == 9005 and s.last_stats()["screening_copy"] == 1
+    assert got[0][0, 0] == 5010 and abs(got[1][0, 0] - 1.0) < 1e-6 and s.last_stats()["screening_copy"] == 2
+    assert s.search_vectors([2], 1, -extra[5:6])[0][0, 0] == 9005 and s.last_stats()["screening_copy"] == 2
     everything = np.concatenate([base, extra, -extra])
     qs = rng.standard_normal((7, 128)).astype(np.float32)
     ref_ids = np.concatenate([np.arange(5333), 9000 + np.arange(333)])[oracle.topk(qs, everything, 10)[0]]
@@ -927,15 +929,19 @@ def test_screening_copy_is_invisible_in_the_results(ctx, oracle):
     s.set_screening_copy("off")  # frees the copies at once
     np.testing.assert_array_equal(s.search_vectors(None, 10, qs)[0], ref_ids)
     assert s.last_stats()["screening_copy"] == 0
-    s.set_screening_copy("auto")  # rebuilt by the next finalize
+    s.set_screening_copy("bf16")  # built by the next finalize
     np.testing.assert_array_equal(s.search_vectors(None, 10, qs)[0], ref_ids)
     assert s.last_stats()["screening_copy"] == 0
     s.finalize()
     np.testing.assert_array_equal(s.search_vectors(None, 10, qs)[0], ref_ids)
     assert s.last_stats()["screening_copy"] == 1
+    s.set_screening_copy("auto")  # the other kind replaces it at the next finalize
+    s.finalize()
+    np.testing.assert_array_equal(s.search_vectors(None, 10, qs)[0], ref_ids)
+    assert s.last_stats()["screening_copy"] == 2
     s.rebuild_source([], 1)  # clears source 1
     assert s.search_vectors(None, 1, -extra[5:6])[0][0, 0] == 9005 and s.num_rows == 333
-    assert s.last_stats()["screening_copy"] == 1
+    assert s.last_stats()["screening_copy"] == 2
     # dot metric: the copy holds the rows themselves (scale 1)
     d = pa.Searcher(ctx, 128, "dot")
     d.add_rows(1, base, np.arange(5000))
@@ -945,7 +951,16 @@ def test_screening_copy_is_invisible_in_the_results(ctx, oracle):
     dd.add_rows(1, base, np.arange(5000))
     dd.finalize()
     a, b = d.search_vectors(None, 10, qs), dd.search_vectors(None, 10, qs)
-    assert d.last_stats()["screening_copy"] == 1 and dd.last_stats()["screening_copy"] == 0
+    assert d.last_stats()["screening_copy"] == 2 and dd.last_stats()["screening_copy"] == 0
+    db = pa.Searcher(ctx, 128, "dot")
+    db.set_screening_copy("bf16")
+    db.add_rows(1, base, np.arange(5000))
+    db.finalize()
+    c_ = db.search_vectors(None, 10, qs)
+    assert db.last_stats()["screening_copy"] == 1
+    np.testing.assert_array_equal(c_[0], b[0])
+    np.testing.assert_array_equal(c_[1], b[1])
+    db.close()
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
     for x in (s, d, dd):
