@@ -895,6 +895,14 @@ __device__ __forceinline__ void fine_survivors(const ScanParams& p, uint32_t mas
     }
 }
 
+// Place of 16-byte piece `pc` of query row `q` inside the row's P8 pieces of the LDS tile: XOR with the row number
+// inside groups of 16 pieces, so that the 16 lanes of a ds_read_b128 group (16 consecutive rows, one piece index) hit 16
+// distinct bank quads.  P8 is a multiple of 8 (dimension padded to 64), not always of 16: a trailing group of 8 pieces is
+// swizzled inside itself (2-way conflicts there; XOR with four bits would leave the row).
+__device__ __forceinline__ int swizzle_piece(int pc, int q, int P8) {
+    return pc < (P8 & ~15) ? ((pc & ~15) | ((pc ^ q) & 15)) : ((pc & ~7) | ((pc ^ q) & 7));
+}
+
 // SRC16: stream the segments' screening copies (bf16, scale folded in: scan.h) instead of converting the f32 rows —
 // half the bytes per row and no conversion work; a chunk is then 4 pieces per lane instead of 8.
 template <int NT, bool NTL, int WPB, int NBUF, bool SRC16>
@@ -907,7 +915,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
     const int NCH = D4 >> 4;  // chunks of 64 features
     for (int i = threadIdx.x; i < NT * 32 * P8; i += WPB * 64) {
         const int q = i / P8, pc = i - q * P8;
-        lq[q * P8 + ((pc & ~15) | ((pc ^ q) & 15))] = __builtin_bit_cast(uint4, gld4((const float4*)p.qbf16 + i));
+        lq[q * P8 + swizzle_piece(pc, q, P8)] = __builtin_bit_cast(uint4, gld4((const float4*)p.qbf16 + i));
     }
     __shared__ uint32_t ltau0[NT * 32];  // what the seed rows alone justify, per query (see seed_threshold_key)
     for (int q = threadIdx.x >> 2; q < NT * 32; q += WPB * 16) {
@@ -1022,7 +1030,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
                 a = __builtin_convertvector(v * sc_cur, bf16x8);
             }
             const int pc = 2 * (cons.ch * 4 + ks) + h;
-            const int ph = (pc & ~15) | ((pc ^ c) & 15);
+            const int ph = swizzle_piece(pc, c, P8);  // (query row 32*t + c: the same low four bits as c)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const bf16x8 q8 = *(const bf16x8*)&lq[(32 * t + c) * P8 + ph];
@@ -1103,15 +1111,15 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
     const int Dp = p.D4 * 4, Dp8 = (Dp + 127) & ~127;
     const bool have = q < p.B;
     const float* src = p.qf32 + (size_t)q * Dp;
-    float x[40];  // Dp <= 2560 (the LDS bound of the tile keeps it far below)
+    float x[16];  // Dp <= 1024: |acc| <= 1024 * 127^2 < 2^24, so the integer dot product converts to f32 exactly
     float mx = 0.0f, l1 = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 40; ++j) {
+    for (int j = 0; j < 16; ++j) {
         const int i = lane + 64 * j;
         x[j] = (have && i < Dp) ? gld(&src[i]) : 0.0f;
     }
 #pragma unroll
-    for (int j = 0; j < 40; ++j) {
+    for (int j = 0; j < 16; ++j) {
         mx = fmaxf(mx, fabsf(x[j]));
         l1 += fabsf(x[j]);
     }
@@ -1123,7 +1131,7 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
     const float s_q = (mx > 0.0f && mx < __builtin_inff() && l1 < __builtin_inff()) ? 127.0f / mx : 0.0f;
     int8_t* row = p.q8 + (size_t)q * Dp8;
 #pragma unroll
-    for (int j = 0; j < 40; ++j) {
+    for (int j = 0; j < 16; ++j) {
         const int i = lane + 64 * j;
         if (i < Dp8) row[i] = (int8_t)max(-127, min(127, (int)rintf((s_q != 0.0f ? x[j] : 0.0f) * s_q)));
     }
@@ -1232,7 +1240,10 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
             const int q = 32 * t + c;
             const float T = (key_f32(tauk[t]) - e32[t]) * sq[t];
             // lowered by 2e-6 relative (f32 rounding of T and of the product with s_row) and by the |x^|_1 term
-            U[t] = (q < p.B) ? (sq[t] != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : -__builtin_inff()) : __builtin_inff();
+            // s_q = 0: a dead query.  Cosine: no row has a score, none is kept; dot (an all-zero query): every row scores 0,
+            // all are kept and the fine screen sorts it out.
+            const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
+            U[t] = (q < p.B) ? (sq[t] != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
 #pragma unroll
             for (int i = 0; i < 16; ++i) any |= (float)acc[t][i] >= fmaf(sr[i], U[t], -vq[t]);
         }
@@ -1822,7 +1833,7 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
     unsigned grid = (unsigned)num_cus * (gm ? gm : per_cu);
     const unsigned need = (p.total_blocks + 3) / 4;
     if (grid > need) grid = need;
-    if (p.D4 * 4 > 2560) PCV_FAIL(PCV_ERR_UNSUPPORTED, "int8 screen: dimension %d is too large", p.D);
+    if (p.D4 * 4 > 1024) PCV_FAIL(PCV_ERR_UNSUPPORTED, "int8 screen: dimension %d is too large", p.D);
     quantize_queries_kernel<<<NT * 32 / 4, 256, 0, st>>>(dp);
     PCV_LAUNCHED();
     if (NT == 1) {

@@ -965,3 +965,47 @@ def test_screening_copy_is_invisible_in_the_results(ctx, oracle):
     np.testing.assert_array_equal(a[1], b[1])
     for x in (s, d, dd):
         x.close()
+
+
+@pytest.mark.parametrize("D", [384, 320, 192, 96])  # 320, 192: padded width 64 mod 128 (half-filled last swizzle group of the query tile)
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_int8_screen_on_rows_that_quantise_badly(ctx, oracle, D, metric):
+    """The int8 screen's margin is certified per (row, query) from the quantisation steps: rows it represents badly may
+    only cost extra fine-screen work, never a wrong answer.  Heavy-tailed rows, one-hot rows, thousands of rows within
+    one quantisation step of the query, norms across 30 decades (cosine) and within a factor 1e3 (dot)."""
+    rng = np.random.default_rng(D + len(metric))
+    n = 6000
+    heavy = rng.standard_cauchy((n, D)).astype(np.float32)                     # one feature dominates each row
+    onehot = np.zeros((500, D), np.float32)
+    onehot[np.arange(500), rng.integers(0, D, 500)] = rng.standard_normal(500).astype(np.float32)
+    q0 = rng.standard_normal(D).astype(np.float32)
+    near = (q0[None, :] * (1.0 + 1e-4 * rng.standard_normal((3000, 1))) + 2e-4 * rng.standard_normal((3000, D))).astype(np.float32)
+    gauss = rng.standard_normal((n, D)).astype(np.float32)
+    corpus = np.concatenate([heavy, onehot, near, gauss])
+    if metric == "cosine":
+        corpus *= (10.0 ** rng.uniform(-15, 15, (corpus.shape[0], 1))).astype(np.float32)
+    else:
+        corpus *= (10.0 ** rng.uniform(-1.5, 1.5, (corpus.shape[0], 1))).astype(np.float32)
+    corpus = corpus[rng.permutation(corpus.shape[0])]
+    queries = np.concatenate([q0[None, :], rng.standard_normal((5, D)).astype(np.float32), rng.standard_cauchy((3, D)).astype(np.float32),
+                              np.eye(D, dtype=np.float32)[:2], corpus[:3]])
+    for mode, code in (("int8", 2), ("bf16", 1), ("off", 0)):
+        s = build(ctx, corpus, metric=metric, screen=mode, kernel="mfma")
+        for lo, hi in ((0, 1), (0, len(queries))):
+            ids, scores, counts = s.search_vectors(None, 10, queries[lo:hi])
+            assert s.last_stats()["screening_copy"] == code
+            opos, osc, _ = oracle.topk(queries[lo:hi], corpus, 10, metric=1 if metric == "dot" else 0)
+            np.testing.assert_array_equal(ids, opos)
+        s.close()
+
+
+def test_int8_screen_leaves_wide_rows_to_the_other_paths(ctx, oracle):
+    # beyond 1024 padded features the integer dot product no longer converts to f32 exactly: such corpora are screened from the f32 rows
+    rng = np.random.default_rng(11)
+    m = rng.standard_normal((400, 1100)).astype(np.float32)
+    q = rng.standard_normal((6, 1100)).astype(np.float32)
+    s = build(ctx, m, kernel="mfma")
+    ids, _, _ = s.search_vectors(None, 5, q)
+    np.testing.assert_array_equal(ids, oracle.topk(q, m, 5)[0])
+    assert s.last_stats()["kernel_used"] == 2 and s.last_stats()["screening_copy"] == 0
+    s.close()
