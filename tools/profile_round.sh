@@ -14,6 +14,13 @@ run() {  # run <dir under gpurun_out> <rocprof args...> -- <program...>
 }
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-extra"
 run prof_default     --kernel-trace --stats --output-format csv -d $G/prof_default     -o p -- $BENCH --steps 10
+export PCV_SCREEN_COPY=1   # the bf16 screening copy, then the f32 rows themselves, on the same workload
+run prof_default_bf16 --kernel-trace --stats --output-format csv -d $G/prof_default_bf16 -o p -- $BENCH --steps 10
+run pmc_fetch_bf16    --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/pmc_fetch_bf16 -o p -- $BENCH --steps 3 --warmup 1
+run pmc_write_bf16    --pmc WRITE_SIZE --kernel-trace --output-format csv -d $G/pmc_write_bf16 -o p -- $BENCH --steps 3 --warmup 1
+export PCV_SCREEN_COPY=0
+run prof_default_f32  --kernel-trace --stats --output-format csv -d $G/prof_default_f32  -o p -- $BENCH --steps 10
+unset PCV_SCREEN_COPY
 run prof_10m_b1      --kernel-trace --stats --output-format csv -d $G/prof_10m_b1      -o p -- $BENCH --steps 20 --rows 10000000 --batch 1
 run prof_clustered   --kernel-trace --stats --output-format csv -d $G/prof_clustered   -o p -- $BENCH --steps 10 --clustered
 run prof_12p5m       --kernel-trace --stats --output-format csv -d $G/prof_12p5m       -o p -- $BENCH --steps 20 --rows 12500000

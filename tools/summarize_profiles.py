@@ -50,10 +50,12 @@ def main():
     summary = {}
     cases = [
         # (label, stats dir, fetch dir, write dir, kernel, rows, dim)
-        ("100m_b64_mfma", "prof_default", "pmc_fetch", "pmc_write", "scan_mfma_kernel", 100_000_000, 384),
-        ("10m_b1_mfma", "prof_10m_b1", "pmc_fetch_10m_b1", "pmc_write_10m_b1", "scan_mfma_kernel", 10_000_000, 384),
-        ("12p5m_b64_mfma", "prof_12p5m", None, None, "scan_mfma_kernel", 12_500_000, 384),
-        ("100m_b64_mfma_clustered", "prof_clustered", None, None, "scan_mfma_kernel", 100_000_000, 384),
+        ("100m_b64_int8", "prof_default", "pmc_fetch", "pmc_write", "scan_mfma8_kernel", 100_000_000, 384),
+        ("100m_b64_bf16", "prof_default_bf16", "pmc_fetch_bf16", "pmc_write_bf16", "scan_mfma_kernel", 100_000_000, 384),
+        ("100m_b64_f32rows", "prof_default_f32", None, None, "scan_mfma_kernel", 100_000_000, 384),
+        ("10m_b1_int8", "prof_10m_b1", "pmc_fetch_10m_b1", "pmc_write_10m_b1", "scan_mfma8_kernel", 10_000_000, 384),
+        ("12p5m_b64_int8", "prof_12p5m", None, None, "scan_mfma8_kernel", 12_500_000, 384),
+        ("100m_b64_int8_clustered", "prof_clustered", None, None, "scan_mfma8_kernel", 100_000_000, 384),
     ]
     for c in ("f32", "bf16x3", "f16x2"):  # encoder forward per kernel
         for f in newest(os.path.join(GO, f"prof_enc_{c}", "*", "*_kernel_stats.csv")):
@@ -68,7 +70,7 @@ def main():
         fixed = {}
         for f in newest(os.path.join(GO, sdir, "*", "*_kernel_stats.csv")):
             for row in csv.DictReader(open(f)):
-                for k in ("upload_kernel", "prep_seed", "rescore_select"):
+                for k in ("upload_kernel", "prep_seed", "rescore_select", "quantize_queries"):
                     if k in row["Name"]:
                         fixed[k + "_avg_us"] = float(row["AverageNs"]) / 1e3
         entry = {
