@@ -162,9 +162,9 @@ pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candi
  *   PCV_SCREEN_COPY_BF16 : the operand of the bf16 MFMA screen ready-made, 2 bytes per feature (+50 % HBM);
  *                          coarse margin 2^-8 relative
  *   PCV_SCREEN_COPY_INT8 : rows quantised per row to int8, 1 byte per feature + 4 bytes per row (+25 % HBM), screened
- *                          by an exact integer dot product with the quantised query; coarse margin
- *                          ~ (|q|_1 / max|q_i| ... ) 0.03 in cosine for 384-d unit rows: more rows reach the fine screen,
- *                          a quarter of the bytes are streamed
+ *                          by an exact integer dot product with the quantised query; coarse margin ~0.024 in cosine
+ *                          for 384-d unit rows (certified per row and query from the quantisation steps): more rows
+ *                          reach the fine screen, a quarter of the bytes are streamed; dimensions up to 1024
  *   PCV_SCREEN_COPY_AUTO (default): INT8, built at finalize; given up — for good, on this searcher — when an
  *                          allocation for rows or for a copy fails (the f32 rows are scanned then)
  *   PCV_SCREEN_COPY_OFF  : never built; existing copies are freed
