@@ -22,14 +22,14 @@ out = open(G + "/pmc_scan_summary.txt", "w")
 for i in range(1, 7):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
-    for f in glob.glob(f"{G}/pmc_scan_{i}/*/*counter_collection.csv"):
+    for f in glob.glob(f"{G}/pmc_scan_{i}/*counter_collection.csv") + glob.glob(f"{G}/pmc_scan_{i}/*/*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "scan_mfma_kernel" not in k: continue
+            if "scan_mfma" not in k: continue
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             calls[(k, row["Counter_Name"])] += 1
     for k, c in agg.items():
-        short = k[k.find("scan_mfma_kernel"):][:60]
+        short = k[k.find("scan_mfma"):][:60]
         for name, v in c.items():
             line = f"set {i}  {short:62s} {name:28s} {v / max(1, calls[(k, name)]):.4g} per launch"
             print(line); out.write(line + "\n")
