@@ -308,7 +308,9 @@ void build_screening_copies(pcv_searcher* s, Source& src) {
             g.copied_rows = 0;
             const size_t nblk = g.cap_rows / kBlockRows;
             const size_t bytes = kind == 1 ? nblk * (s->D4 / 2) * 32 * sizeof(uint4) : nblk * (size_t)(((s->Dp + 127) & ~127) / 16) * 32 * sizeof(uint4);
-            hipError_t e = hipMalloc(kind == 1 ? (void**)&g.blk16 : (void**)&g.blk8, bytes);
+            // (PCV_TEST_FAIL_COPY_ALLOC: the tests' way to reach the out-of-memory branch)
+            hipError_t e = getenv("PCV_TEST_FAIL_COPY_ALLOC") ? hipErrorOutOfMemory
+                                                              : hipMalloc(kind == 1 ? (void**)&g.blk16 : (void**)&g.blk8, bytes);
             if (e == hipSuccess && kind == 2) {
                 e = hipMalloc((void**)&g.scale8, (size_t)g.cap_rows * sizeof(float));
                 if (e != hipSuccess) {

@@ -1009,3 +1009,38 @@ def test_int8_screen_leaves_wide_rows_to_the_other_paths(ctx, oracle):
     np.testing.assert_array_equal(ids, oracle.topk(q, m, 5)[0])
     assert s.last_stats()["kernel_used"] == 2 and s.last_stats()["screening_copy"] == 0
     s.close()
+
+
+def test_screening_copy_gives_way_when_memory_is_short(ctx, oracle, monkeypatch):
+    """AUTO: a failed allocation of a screening copy switches the copies off for the searcher and the f32 rows are scanned;
+    asked for explicitly, the same failure is an error at finalize."""
+    rng = np.random.default_rng(21)
+    m = rng.standard_normal((3000, 128)).astype(np.float32)
+    q = rng.standard_normal((9, 128)).astype(np.float32)
+    ref = oracle.topk(q, m, 10)[0]
+    s = pa.Searcher(ctx, 128, "cosine")
+    s.add_rows(1, m[:2000], np.arange(2000))
+    s.finalize()
+    np.testing.assert_array_equal(s.search_vectors(None, 10, q)[0], oracle.topk(q, m[:2000], 10)[0])
+    assert s.last_stats()["screening_copy"] == 2
+    monkeypatch.setenv("PCV_TEST_FAIL_COPY_ALLOC", "1")
+    s.add_rows(2, m[2000:], 2000 + np.arange(1000))  # a second source = a new segment, whose copy cannot be allocated
+    s.finalize()
+    np.testing.assert_array_equal(s.search_vectors(None, 10, q)[0], ref)
+    assert s.last_stats()["screening_copy"] == 0 and s.last_stats()["kernel_used"] == 2  # every copy was given back
+    monkeypatch.delenv("PCV_TEST_FAIL_COPY_ALLOC")
+    s.finalize()  # still off for this searcher: it gave way for good
+    np.testing.assert_array_equal(s.search_vectors(None, 10, q)[0], ref)
+    assert s.last_stats()["screening_copy"] == 0
+    s.set_screening_copy("auto")  # asked again: rebuilt at the next finalize
+    s.finalize()
+    np.testing.assert_array_equal(s.search_vectors(None, 10, q)[0], ref)
+    assert s.last_stats()["screening_copy"] == 2
+    s.close()
+    monkeypatch.setenv("PCV_TEST_FAIL_COPY_ALLOC", "1")
+    e = pa.Searcher(ctx, 128, "cosine")
+    e.set_screening_copy("int8")
+    e.add_rows(1, m)
+    with pytest.raises(pa.PcvError):
+        e.finalize()
+    e.close()
