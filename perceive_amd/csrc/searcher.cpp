@@ -118,6 +118,24 @@ struct pcv_searcher {
     bool screen_copy_gave_way = false;       // AUTO: the copies were dropped to make room for rows
     int copies_kind = 0;                     // 0: not every row of every segment is covered by a screening copy; 1 bf16; 2 int8
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // A pass is five short launches and four event records: on small corpora its cost is the queueing.  The second time
+    // a pass of the same shape comes by, its launch sequence is captured into a hipGraph and replayed from then on (what
+    // changes between passes — parameters, segment table, queries — travels in the pinned block the first kernel reads).
+    struct PassShape {
+        int B = -1, k = 0, kernel = 0, src_kind = 0, nseg = 0;
+        uint32_t total_blocks = 0, seed_blocks = 0, flags = 0, seg0_rows = 0;
+        size_t bytes = 0;
+        const void *pin = nullptr, *dev = nullptr, *seg0_blk = nullptr, *seg0_scale = nullptr;
+        bool operator==(const PassShape& o) const {
+            return B == o.B && k == o.k && kernel == o.kernel && src_kind == o.src_kind && nseg == o.nseg && total_blocks == o.total_blocks &&
+                   seed_blocks == o.seed_blocks && flags == o.flags && seg0_rows == o.seg0_rows && bytes == o.bytes && pin == o.pin &&
+                   dev == o.dev && seg0_blk == o.seg0_blk && seg0_scale == o.seg0_scale;
+        }
+    };
+    PassShape graph_shape, last_shape;
+    hipGraphExec_t graph_exec = nullptr;
+    int shape_seen = 0;
+    bool use_graph = true;
     // a pass queued by enqueue_pass and not yet collected by finish_pass
     struct Pending {
         bool active = false;
@@ -511,19 +529,68 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
         bytes += (size_t)B * s->D * sizeof(float);
     }
     const ScanParams* dp = reinterpret_cast<const ScanParams*>(s->d_pass);
-    PCV_HIP(hipEventRecord(s->ev[0], st));
-    launch_upload(st, s->pin_pass, s->d_pass, bytes);
-    launch_prep_seed(st, p, dp, tab[0]);
-    PCV_HIP(hipEventRecord(s->ev[1], st));
-    if (kernel == PCV_KERNEL_MFMA && src_kind == 2)
-        launch_scan_mfma8(st, p, dp, s->ctx->num_cus);
-    else if (kernel == PCV_KERNEL_MFMA)
-        launch_scan_mfma(st, p, dp, s->ctx->num_cus);
-    else
-        launch_scan_wave(st, p, dp, s->ctx->num_cus);
-    PCV_HIP(hipEventRecord(s->ev[2], st));
-    launch_rescore_select(st, p, dp);
-    PCV_HIP(hipEventRecord(s->ev[3], st));
+    auto launch_pass = [&] {
+        PCV_HIP(hipEventRecord(s->ev[0], st));
+        launch_upload(st, s->pin_pass, s->d_pass, bytes);
+        launch_prep_seed(st, p, dp, tab[0]);
+        PCV_HIP(hipEventRecord(s->ev[1], st));
+        if (kernel == PCV_KERNEL_MFMA && src_kind == 2)
+            launch_scan_mfma8(st, p, dp, s->ctx->num_cus);
+        else if (kernel == PCV_KERNEL_MFMA)
+            launch_scan_mfma(st, p, dp, s->ctx->num_cus);
+        else
+            launch_scan_wave(st, p, dp, s->ctx->num_cus);
+        PCV_HIP(hipEventRecord(s->ev[2], st));
+        launch_rescore_select(st, p, dp);
+        PCV_HIP(hipEventRecord(s->ev[3], st));
+    };
+    pcv_searcher::PassShape shape;
+    shape.B = B;
+    shape.k = k;
+    shape.kernel = kernel;
+    shape.src_kind = src_kind;
+    shape.nseg = nseg;
+    shape.total_blocks = blk0;
+    shape.seed_blocks = p.seed_blocks;
+    shape.flags = p.flags;
+    shape.seg0_rows = tab[0].nrows;
+    shape.bytes = bytes;
+    shape.pin = s->pin_pass;
+    shape.dev = s->d_pass;
+    shape.seg0_blk = tab[0].blk;
+    shape.seg0_scale = tab[0].scale;
+    if (s->use_graph && s->graph_exec && shape == s->graph_shape) {
+        PCV_HIP(hipGraphLaunch(s->graph_exec, st));
+    } else if (s->use_graph && shape == s->last_shape && ++s->shape_seen >= 2) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            try {
+                launch_pass();
+            } catch (...) {
+                ok = false;
+            }
+            ok = (hipStreamEndCapture(st, &graph) == hipSuccess) && ok && graph != nullptr;
+        }
+        if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+            s->graph_exec = exec;
+            s->graph_shape = shape;
+            PCV_HIP(hipGraphLaunch(exec, st));
+        } else {  // capture is not possible here: stay with plain launches for good
+            (void)hipGetLastError();
+            s->use_graph = false;
+            launch_pass();
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+    } else {
+        if (!(shape == s->last_shape)) {
+            s->last_shape = shape;
+            s->shape_seen = 1;
+        }
+        launch_pass();
+    }
     s->pending.active = true;
     s->pending.done = false;
     s->pending.B = B;
@@ -709,6 +776,7 @@ pcv_status pcv_searcher_create(pcv_ctx* ctx, int dim, int metric, pcv_searcher**
         s->D4 = s->Dp / 4;
         s->metric = metric;
         if (const char* f = getenv("PCV_SCAN_FLAGS")) s->scan_flags = (uint32_t)strtoul(f, nullptr, 0);
+        if (getenv("PCV_NO_SCAN_GRAPH")) s->use_graph = false;
         if (const char* f = getenv("PCV_SCREEN_COPY")) {  // 0 off, 1 on, 2 auto
             const int mode = atoi(f);
             if (mode >= PCV_SCREEN_COPY_OFF && mode <= PCV_SCREEN_COPY_INT8) s->screen_copy = mode;
@@ -746,6 +814,7 @@ pcv_status pcv_searcher_destroy(pcv_searcher* s) {
         s->d_cnt.release();
         s->d_cand.release();
         s->d_hits.release();
+        if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
         if (s->pin) (void)hipHostFree(s->pin);
         if (s->pin_pass) (void)hipHostFree(s->pin_pass);
         if (s->d_pass) (void)hipFree(s->d_pass);
