@@ -269,7 +269,8 @@ pcv_status pcv_cosine_similarity(pcv_ctx* ctx, const float* a, int B, const floa
 typedef struct pcv_scan_stats {
     int64_t rows_scanned;        /* rows streamed by the scan kernel(s), padding excluded        */
     int64_t bytes_algorithmic;   /* rows_scanned * dim * 4                                       */
-    float scan_ms;               /* hipEvent time of the scan kernel launches only               */
+    float scan_ms;               /* hipEvent time of the scan kernel launches only (a pass over <= 4M rows replayed as a
+                                    hipGraph is timed as a whole: then total_ms times the share last measured) */
     float total_ms;              /* hipEvent time of the whole device pipeline                   */
     int64_t candidates;          /* rows rescored exactly, summed over queries                   */
     int32_t scan_launches;       /* scan kernel launches (reruns after overflow included)        */
