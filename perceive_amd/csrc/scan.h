@@ -53,7 +53,8 @@ struct SegDesc {
     uint32_t pad;
     const uint4* blk16;  // bf16 screening copy (see below), or nullptr
     const uint4* blk8;   // int8 screening copy, or nullptr
-    const float* scale8; // [nblocks*32] quantisation scale of the int8 copy's rows (NaN = row not searchable)
+    const float* scale8; // [nblocks*32] quantisation scale of the int8 copy's rows (NaN = row not searchable), within a block in
+                         // the order of the MFMA accumulators: row 8g + 4h + j at 16h + 4g + j
 };
 
 struct pcv_hit_dev {

@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256) void coarse_pack8_kernel(const float4* __restr
                 }
             blk8[((size_t)b * D16 + g) * 32 + r] = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        if (h == 0) scale8[(size_t)b * 32 + r] = searchable ? s_row : __builtin_nanf("");
+        // stored in the order the scan's accumulators hold the rows of a block (row 8g + 4h' + j at 16h' + 4g + j), so that
+        // a lane of the scan finds the 16 scales it tests next to each other
+        if (h == 0) scale8[(size_t)b * 32 + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3)] = searchable ? s_row : __builtin_nanf("");
     }
 }
 
@@ -1216,25 +1218,18 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     // thresholds and the quantisation scales of the block being finished, requested one chunk ahead of the epilogue:
     // lane (c, h) tests rows 4h + {0..3, 8..11, 16..19, 24..27} of the block
     uint32_t tauk[NT];
-    float srv = 0.0f;  // lane (c, h) holds the scale of row c of the block; the epilogue reads the rows it tests across lanes
+    // every 16-lane row of the wave holds, lane i of the row, the scale of the row that accumulator i of those lanes tests
+    // (scale8 is stored in that order): the epilogue gets it with one row broadcast per accumulator
+    float srv = 0.0f;
     auto prefetch = [&]() {
 #pragma unroll
         for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? max(tau0[t], ld_relaxed(&p.tau[(32 * t + c) * kHot])) : 0u;
-        srv = gld(cons.sc.scale8 + (size_t)cons.lb * 32 + c);
+        srv = gld(cons.sc.scale8 + (size_t)cons.lb * 32 + 16 * h + (lane & 15));
     };
 
     auto epilogue = [&](const SegCursor& esc, uint32_t elb) {
         if (NCH < 2) prefetch();
-        float sr[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r0 = (i & 3) + 8 * (i >> 2);  // row of accumulator i for h = 0; h = 1 holds row r0 + 4
-            const int lo = __builtin_amdgcn_readlane(__builtin_bit_cast(int, srv), r0);
-            const int hi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, srv), r0 + 4);
-            sr[i] = __builtin_bit_cast(float, h ? hi : lo);
-        }
         float U[NT];
-        bool any = false;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int q = 32 * t + c;
@@ -1244,17 +1239,26 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
             // all are kept and the fine screen sorts it out.
             const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
             U[t] = (q < p.B) ? (sq[t] != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
-#pragma unroll
-            for (int i = 0; i < 16; ++i) any |= (float)acc[t][i] >= fmaf(sr[i], U[t], -vq[t]);
         }
+        // accumulator I tests the row whose scale sits in lane I of this lane's 16-lane row: DPP row_newbcast:I (the
+        // control word is an immediate; the value is used at once, so no 16 registers are held)
+        uint32_t mask[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mask[t] = 0;
+#define PCV_TEST(I)                                                                                                            \
+    {                                                                                                                          \
+        const float s_row = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, srv), 0x150 + I, 0xf, 0xf, false)); \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) mask[t] |= ((float)acc[t][I] >= fmaf(s_row, U[t], -vq[t])) ? (1u << I) : 0u;  \
+    }
+        PCV_TEST(0) PCV_TEST(1) PCV_TEST(2) PCV_TEST(3) PCV_TEST(4) PCV_TEST(5) PCV_TEST(6) PCV_TEST(7)
+        PCV_TEST(8) PCV_TEST(9) PCV_TEST(10) PCV_TEST(11) PCV_TEST(12) PCV_TEST(13) PCV_TEST(14) PCV_TEST(15)
+#undef PCV_TEST
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) any |= mask[t] != 0;
         if (__any(any)) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                uint32_t mask = 0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mask |= ((float)acc[t][i] >= fmaf(sr[i], U[t], -vq[t])) ? (1u << i) : 0u;
-                fine_survivors(p, mask, t, esc, elb, ltau0, lane, D4);
-            }
+            for (int t = 0; t < NT; ++t) fine_survivors(p, mask[t], t, esc, elb, ltau0, lane, D4);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
