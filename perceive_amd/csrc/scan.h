@@ -37,6 +37,7 @@ constexpr int kMaxWaveQueries = 4;  // wave-reduction kernel handles 1..4 querie
 constexpr int kHot = 256;            // uint32 words between per-query hot words (tau, cand_cnt): 1 KB apart,
                                      // so the device-wide atomics on them do not queue on one HBM channel
 constexpr int kMfmaQueries = 128;   // MFMA kernel handles up to 128 queries per pass
+constexpr int kScale8Stride = 36;   // floats per block in SegDesc::scale8: 32 row scales + (min, max) of its two 16-row sets
 
 // One corpus segment as a scan launch sees it.  A launch walks any number of them: the table lives in
 // device memory next to the ScanParams (one source of the reference = one or more segments,
@@ -53,8 +54,9 @@ struct SegDesc {
     uint32_t pad;
     const uint4* blk16;  // bf16 screening copy (see below), or nullptr
     const uint4* blk8;   // int8 screening copy, or nullptr
-    const float* scale8; // [nblocks*32] quantisation scale of the int8 copy's rows (NaN = row not searchable), within a block in
-                         // the order of the MFMA accumulators: row 8g + 4h + j at 16h + 4g + j
+    const float* scale8; // [nblocks][kScale8Stride] quantisation scales of the int8 copy's rows (NaN = row not searchable), within a
+                         // block in the order of the MFMA accumulators (row 8g + 4h + j at 16h + 4g + j), then the smallest
+                         // and largest scale of set h = 0 and of set h = 1
 };
 
 struct pcv_hit_dev {

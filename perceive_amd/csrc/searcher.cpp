@@ -334,7 +334,7 @@ void build_screening_copies(pcv_searcher* s, Source& src) {
             hipError_t e = getenv("PCV_TEST_FAIL_COPY_ALLOC") ? hipErrorOutOfMemory
                                                               : hipMalloc(kind == 1 ? (void**)&g.blk16 : (void**)&g.blk8, bytes);
             if (e == hipSuccess && kind == 2) {
-                e = hipMalloc((void**)&g.scale8, (size_t)g.cap_rows * sizeof(float));
+                e = hipMalloc((void**)&g.scale8, (size_t)(g.cap_rows / kBlockRows) * kScale8Stride * sizeof(float));
                 if (e != hipSuccess) {
                     (void)hipFree(g.blk8);
                     g.blk8 = nullptr;
