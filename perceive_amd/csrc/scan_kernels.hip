@@ -1239,17 +1239,14 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     // every 16-lane row of the wave holds, lane i of the row, the scale of the row that accumulator i of those lanes tests
     // (scale8 is stored in that order): the epilogue gets it with one row broadcast per accumulator
     float srv = 0.0f;
-    constexpr bool kPretest = NT == 4;
     float2 smm = make_float2(0.0f, 0.0f);  // smallest / largest scale among the 16 rows this lane tests
     auto prefetch = [&]() {
 #pragma unroll
         for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? max(tau0[t], ld_relaxed(&p.tau[(32 * t + c) * kHot])) : 0u;
         const float* s8 = cons.sc.scale8 + (size_t)cons.lb * kScale8Stride;
         srv = gld(s8 + 16 * h + (lane & 15));
-        if constexpr (kPretest) {
-            smm.x = gld(s8 + 32 + 2 * h);
-            smm.y = gld(s8 + 33 + 2 * h);
-        }
+        smm.x = gld(s8 + 32 + 2 * h);
+        smm.y = gld(s8 + 33 + 2 * h);
     };
 
     auto epilogue = [&](const SegCursor& esc, uint32_t elb) {
@@ -1267,19 +1264,17 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         }
         // First the 16 rows of a lane at once: the largest accumulator against the smallest right-hand side any of them can
         // have (s_row U - V is monotone in s_row: the extreme scale of the set on U's side).  Nearly every block ends here.
-        // (Used where the register budget has room for it, the 128-query form: -6 %.  In the 64-query form, at 3 waves
-        // per SIMD, it spills 16 registers into the streaming loop and costs 8 %.)
-        bool hot = !kPretest;
-        if constexpr (kPretest) {
+        // (-6 % in the 128-query form, -4.5 % in the 64-query form — there with three chunk buffers instead of four: with
+        // four it spills 16 registers into the streaming loop at 3 waves per SIMD and costs 8 %.)
+        bool hot = false;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                int m = acc[t][0];
+        for (int t = 0; t < NT; ++t) {
+            int m = acc[t][0];
 #pragma unroll
-                for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
-                hot |= (float)m >= fmaf(U[t] >= 0.0f ? smm.x : smm.y, U[t], -vq[t]);
-            }
+            for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
+            hot |= (float)m >= fmaf(U[t] >= 0.0f ? smm.x : smm.y, U[t], -vq[t]);
         }
-        if (!kPretest || __any(hot)) {
+        if (__any(hot)) {
         // accumulator I tests the row whose scale sits in lane I of this lane's 16-lane row: DPP row_newbcast:I (the
         // control word is an immediate; the value is used at once, so no 16 registers are held)
         uint32_t mask[NT];
@@ -1330,14 +1325,23 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     consume(buf[CONS]);                 \
     if (cons.gb >= p.total_blocks) return;
     produce(buf[0]);
-    static_assert(NBUF == 4, "four chunk buffers");
-    produce(buf[1]);
-    produce(buf[2]);
-    while (true) {
-        PCV_STEP(3, 0)
-        PCV_STEP(0, 1)
-        PCV_STEP(1, 2)
-        PCV_STEP(2, 3)
+    if constexpr (NBUF == 3) {
+        produce(buf[1]);
+        while (true) {
+            PCV_STEP(2, 0)
+            PCV_STEP(0, 1)
+            PCV_STEP(1, 2)
+        }
+    } else {
+        static_assert(NBUF == 4, "three or four chunk buffers");
+        produce(buf[1]);
+        produce(buf[2]);
+        while (true) {
+            PCV_STEP(3, 0)
+            PCV_STEP(0, 1)
+            PCV_STEP(1, 2)
+            PCV_STEP(2, 3)
+        }
     }
 #undef PCV_STEP
 }
@@ -1857,14 +1861,14 @@ int mfma8_pass_queries(int Dp) {
     return 0;
 }
 
-template <int NT, bool NTL>
+template <int NT, bool NTL, int NBUF = (NT == 2 ? 3 : 4)>  // 64 queries: three chunk buffers leave the registers the block pre-test needs
 static void launch_mfma8_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
-        PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_kernel<NT, NTL, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_kernel<NT, NTL, 4, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_allowed = lds;
     }
-    scan_mfma8_kernel<NT, NTL, 4, 4><<<grid, 256, lds, st>>>(dp);
+    scan_mfma8_kernel<NT, NTL, 4, NBUF><<<grid, 256, lds, st>>>(dp);
 }
 
 void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
