@@ -165,7 +165,7 @@ pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candi
  *                          by an exact integer dot product with the quantised query; coarse margin ~0.024 in cosine
  *                          for 384-d unit rows (certified per row and query from the quantisation steps): more rows
  *                          reach the fine screen, a quarter of the bytes are streamed; dimensions up to 1024
- *   PCV_SCREEN_COPY_AUTO (default): INT8, built at finalize; given up — for good, on this searcher — when an
+ *   PCV_SCREEN_COPY_AUTO (default): INT8 (BF16 for rows wider than 1024 features), built at finalize; given up — for good, on this searcher — when an
  *                          allocation for rows or for a copy fails (the f32 rows are scanned then)
  *   PCV_SCREEN_COPY_OFF  : never built; existing copies are freed
  * BF16 / INT8 asked for explicitly: a failed copy allocation is an error at finalize.  Takes effect at the next

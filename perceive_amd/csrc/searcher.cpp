@@ -190,7 +190,11 @@ void drop_screening_copies(pcv_searcher* s) {
 // the form AUTO stands for
 inline int copy_kind_wanted(const pcv_searcher* s) {
     if (s->screen_copy == PCV_SCREEN_COPY_OFF || s->screen_copy_gave_way) return 0;
-    return s->screen_copy == PCV_SCREEN_COPY_BF16 ? 1 : 2;
+    if (s->screen_copy == PCV_SCREEN_COPY_BF16) return 1;
+    // the int8 screen goes up to 1024 padded features (scan_mfma8_kernel); AUTO keeps the bf16 form for wider rows, as
+    // long as the MFMA scan can stage their query tile at all
+    if (s->Dp > 1024) return (s->screen_copy == PCV_SCREEN_COPY_AUTO && mfma_pass_queries(s->Dp) > 0) ? 1 : (s->screen_copy == PCV_SCREEN_COPY_AUTO ? 0 : 2);
+    return 2;
 }
 
 // Allocate a segment with room for `cap_rows` rows; zero-filled so padding rows / features are exact
@@ -315,6 +319,8 @@ void append_rows(pcv_searcher* s, Source& src, const int64_t* ids, const void* r
 void build_screening_copies(pcv_searcher* s, Source& src) {
     const int kind = copy_kind_wanted(s);
     if (kind == 0) return;
+    if (kind == 2 && s->Dp > 1024)
+        PCV_FAIL(PCV_ERR_UNSUPPORTED, "the int8 screening copy goes up to 1024 features (this index has %d): use PCV_SCREEN_COPY_BF16 or AUTO", s->D);
     hipStream_t st = s->ctx->stream;
     for (auto& g : src.segs) {
         if (g.nrows == 0) continue;

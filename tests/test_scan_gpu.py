@@ -1000,15 +1000,23 @@ def test_int8_screen_on_rows_that_quantise_badly(ctx, oracle, D, metric):
 
 
 def test_int8_screen_leaves_wide_rows_to_the_other_paths(ctx, oracle):
-    # beyond 1024 padded features the integer dot product no longer converts to f32 exactly: such corpora are screened from the f32 rows
+    # beyond 1024 padded features the integer dot product no longer converts to f32 exactly: AUTO keeps the bf16 copy for such
+    # corpora, and asking for the int8 form is an error at finalize
     rng = np.random.default_rng(11)
     m = rng.standard_normal((400, 1100)).astype(np.float32)
     q = rng.standard_normal((6, 1100)).astype(np.float32)
     s = build(ctx, m, kernel="mfma")
     ids, _, _ = s.search_vectors(None, 5, q)
     np.testing.assert_array_equal(ids, oracle.topk(q, m, 5)[0])
-    assert s.last_stats()["kernel_used"] == 2 and s.last_stats()["screening_copy"] == 0
+    assert s.last_stats()["kernel_used"] == 2 and s.last_stats()["screening_copy"] == 1
     s.close()
+    e = pa.Searcher(ctx, 1100, "cosine")
+    e.set_screening_copy("int8")
+    e.add_rows(1, m)
+    with pytest.raises(pa.PcvError) as err:
+        e.finalize()
+    assert err.value.status == 3
+    e.close()
 
 
 def test_screening_copy_gives_way_when_memory_is_short(ctx, oracle, monkeypatch):
