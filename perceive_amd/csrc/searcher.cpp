@@ -488,7 +488,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     int64_t rows = 0;
     // stream the screening copies iff every selected segment has one of the kind the searcher keeps
     int src_kind = (kernel == PCV_KERNEL_MFMA) ? copy_kind_wanted(s) : 0;
-    if (src_kind == 2 && (mfma8_pass_queries(s->Dp) < B || s->Dp > 1024 || getenv("PCV_NO_INT8_SCAN"))) src_kind = 0;
+    if (src_kind == 2 && (mfma8_pass_queries(s->Dp) < B || s->Dp > 1024)) src_kind = 0;
     for (int i = 0; i < nseg; ++i) {
         const Segment& g = *segs[i].g;
         tab[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), blk0, 0, g.blk16, g.blk8, g.scale8};
