@@ -406,6 +406,144 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_ln_kernel(const float* __rest
     }
 }
 
+// The same tile, persistent and with eight waves (two row halves x four column quarters, 32 x N/4 per wave).
+// The workgroups of one launch move in step, so in the form above all K loops and then all epilogues
+// coincide and the epilogue's HBM time (residual in, normalised rows out) is exposed.  Here a workgroup
+// walks its tiles: the last K step of a tile already loads the next tile's first operands and the residual
+// rows of the epilogue, and the epilogue's stores drain under the next tile's MFMAs.
+template <int CT>
+__global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, const float* __restrict__ resid,
+                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                              float eps, float* __restrict__ C, int M, int K) {
+    constexpr int N = CT * 128;
+    constexpr int LDR = N + 4;
+    constexpr int Q = N / 64;
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    float* As = lsm;              // [64][LDT]
+    float* Ws = lsm + LBM * LDT;  // [N][LDT]
+    static_assert(32 * LDR <= (LBM + N) * LDT, "the epilogue's half tile fits the staging buffers");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int rh = wave & 1, wc = wave >> 1;
+    const int srow = tid >> 3, c4 = tid & 7;   // staging: float4 (row srow [+ 64u], 16-byte column c4)
+    const int erow = tid >> 4, ej = tid & 15;  // epilogue: 16 lanes per row, float4 columns ej + 16t
+    const int tiles = (M + LBM - 1) / LBM;
+    const int nk = K / BK;
+    int tile = blockIdx.x;
+    if (tile >= tiles) return;
+
+    const float* wg = W + (size_t)srow * K + c4 * 4;
+    const float* ag = A + (size_t)min(tile * LBM + srow, M - 1) * K + c4 * 4;
+    f32x4 ra = *(const f32x4*)ag, rw[2 * CT];
+#pragma unroll
+    for (int u = 0; u < 2 * CT; ++u) rw[u] = *(const f32x4*)(wg + (size_t)64 * u * K);
+    const float* ap0 = &As[(rh * 32 + i) * LDT + 16 * kk];
+    const float* bp0 = &Ws[(wc * CT * 32 + i) * LDT + 16 * kk];
+    float* tile_lds = lsm;
+
+    for (; tile < tiles; tile += gridDim.x) {
+        const int m0 = tile * LBM;
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+        auto to_lds = [&]() {
+            __syncthreads();  // the previous step's fragment reads / the previous tile's row reads are done
+            *(f32x4*)&As[srow * LDT + c4 * 4] = ra;
+#pragma unroll
+            for (int u = 0; u < 2 * CT; ++u) *(f32x4*)&Ws[(srow + 64 * u) * LDT + c4 * 4] = rw[u];
+            __syncthreads();
+        };
+        auto mfma_step = [&]() {
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {  // four k per lane half at a time
+                const f32x4 x = *(const f32x4*)(ap0 + 4 * hh);
+                f32x4 y[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) y[c] = *(const f32x4*)(bp0 + c * 32 * LDT + 4 * hh);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s], y[c][s], acc[c], 0, 0, 0);
+            }
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            to_lds();
+            const size_t koff = (size_t)(kt + 1) * BK;  // the next step's operands fly under this step's MFMAs
+            ra = *(const f32x4*)(ag + koff);
+#pragma unroll
+            for (int u = 0; u < 2 * CT; ++u) rw[u] = *(const f32x4*)(wg + (size_t)64 * u * K + koff);
+            mfma_step();
+        }
+        to_lds();
+        f32x4 rv[Q];  // under the last step: the residual rows of the epilogue's first half
+        {
+            const float* rrow = resid + (size_t)min(m0 + erow, M - 1) * N;
+#pragma unroll
+            for (int t = 0; t < Q; ++t) rv[t] = *(const f32x4*)(rrow + 4 * (ej + 16 * t));
+        }
+        mfma_step();
+
+        // epilogue: rows 0..31 (from the rh = 0 waves) then 32..63, row-major through LDS
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            __syncthreads();
+            if (rh == a) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tile_lds[acc_row(r, kk) * LDR + (wc * CT + c) * 32 + i] = acc[c][r];
+            }
+            __syncthreads();
+            const int row = m0 + a * 32 + erow;
+            f32x4 v[Q];
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < Q; ++t) {
+                const int col = 4 * (ej + 16 * t);
+                v[t] = *(const f32x4*)(tile_lds + erow * LDR + col) + *(const f32x4*)(bias + col) + rv[t];
+                sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+            }
+            if (a == 0) {  // the second half's residual rows fly under this half's arithmetic and stores
+                const float* rrow = resid + (size_t)min(row + 32, M - 1) * N;
+#pragma unroll
+                for (int t = 0; t < Q; ++t) rv[t] = *(const f32x4*)(rrow + 4 * (ej + 16 * t));
+            }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 4);
+            sum += __shfl_xor(sum, 8);
+            const float mean = sum / (float)N;
+            float sq = 0.0f;
+#pragma unroll
+            for (int t = 0; t < Q; ++t) {
+                const f32x4 d = v[t] - mean;
+                sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+            sq += __shfl_xor(sq, 1);
+            sq += __shfl_xor(sq, 2);
+            sq += __shfl_xor(sq, 4);
+            sq += __shfl_xor(sq, 8);
+            const float rstd = 1.0f / sqrtf(sq / (float)N + eps);
+            if (row < M) {
+#pragma unroll
+                for (int t = 0; t < Q; ++t) {
+                    const int col = 4 * (ej + 16 * t);
+                    *(f32x4*)(C + (size_t)row * N + col) = (v[t] - mean) * rstd * *(const f32x4*)(ln_w + col) + *(const f32x4*)(ln_b + col);
+                }
+            }
+        }
+        // the next tile's first operands
+        ag = A + (size_t)min(min(tile + (int)gridDim.x, tiles - 1) * LBM + srow, M - 1) * K + c4 * 4;
+        ra = *(const f32x4*)ag;
+#pragma unroll
+        for (int u = 0; u < 2 * CT; ++u) rw[u] = *(const f32x4*)(wg + (size_t)64 * u * K);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Skinny GEMM for M <= 128 (a single query, a few highlight chunks): the 128x128 tiling would run
 // N/128 workgroups through K/32 barrier-separated steps each (30-115 us per layer GEMM, launch- and
@@ -1631,17 +1769,19 @@ bool launch_gemm_f32_ln(hipStream_t st, const float* A, const float* W, const fl
     if (M <= 128 || (N != 128 && N != 256 && N != 384) || K % BK != 0 || bias == nullptr || resid == nullptr) return false;
     const size_t lds = (size_t)(LBM + N) * LDT * sizeof(float);
     const dim3 grid((M + LBM - 1) / LBM);
+    if (N == 384) {  // persistent eight-wave form: 1 % of a 256 x 256 forward over the four-wave one
+        static bool allowed8 = false;  // 64.5 KB of dynamic LDS
+        if (!allowed8) {
+            PCV_HIP(hipFuncSetAttribute((const void*)gemm_f32_ln8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            allowed8 = true;
+        }
+        const int resident = 2 * 256;  // two workgroups per CU
+        gemm_f32_ln8_kernel<3><<<dim3(std::min<int>(grid.x, resident)), 512, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
+        return true;
+    }
     switch (N / 128) {
         case 1: gemm_f32_ln_kernel<1><<<grid, 256, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K); break;
-        case 2: gemm_f32_ln_kernel<2><<<grid, 256, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K); break;
-        default: {
-            static bool allowed = false;  // 64.5 KB of dynamic LDS
-            if (!allowed) {
-                PCV_HIP(hipFuncSetAttribute((const void*)gemm_f32_ln_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                allowed = true;
-            }
-            gemm_f32_ln_kernel<3><<<grid, 256, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
-        }
+        default: gemm_f32_ln_kernel<2><<<grid, 256, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K); break;
     }
     return true;
 }
