@@ -107,6 +107,15 @@ CLUSTER_ROWS = 20_000         # rows per cluster of the clustered corpus
 CLUSTER_NOISE = 0.004         # cosines inside a cluster spread over ~noise^2 * dim = 0.006: 2e4 rows within 0.01 of a query's top-k
 
 
+WIPE_GBPS = 30.0  # measured 34 GB/s (tools/scratch notes in DESIGN.md §5): the driver clears freed VRAM in the background
+
+
+def settle(freed_bytes):
+    """After `freed_bytes` of device memory went back to the driver, wait until its background clear of them is over:
+    while it runs it takes ~2.6 % of the HBM bandwidth from whatever is being timed."""
+    time.sleep(freed_bytes / (WIPE_GBPS * 1e9))
+
+
 def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, clustered=False, searcher=None, dim=384):
     """One single-GPU scan measurement: `steps` exact top-k searches of `batch` fresh queries over `rows`
     synthetic rows resident in HBM.  Returns the record that goes under `extra` (same fields as the headline)."""
@@ -158,6 +167,7 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
     }
     if own:
         searcher.close()
+        settle(rows * (dim * 4 + dim + 8))
     return rec
 
 
@@ -442,12 +452,26 @@ def main():
             es, ew = max(3, min(args.steps, 20)), max(1, min(args.warmup, 3))
             extra["config5_end_to_end"] = e2e_leg(pa, ctx, searcher, total_rows)
             searcher.set_kernel(args.kernel)
+            if copy is not None:
+                # the same corpus and queries' shape without the int8 copy: the scan streams the f32 rows themselves
+                # (1536 B/vector, the SURVEY §8d figure) or the bf16 copy; results are the same exact top-k
+                held = {"int8": args.dim + 5, "bf16": 2 * args.dim}  # bytes per row of a copy
+                for mode, key in (("off", "f32_rows_b64"), ("bf16", "bf16_copy_b64")):
+                    searcher.set_screening_copy(mode)
+                    searcher.finalize()
+                    if mode == "off":
+                        settle(total_rows * held[copy])
+                    extra[key] = scan_leg(pa, ctx, total_rows, B, k, args.kernel, es, ew, searcher=searcher)
+                searcher.set_screening_copy({"int8": "int8", "bf16": "bf16"}[copy])
+                searcher.finalize()
+                settle(total_rows * held["bf16"])
             extra["config2_10m_b1"] = scan_leg(pa, ctx, 10_000_000, 1, k, "auto", es, ew)
             extra["shard_12p5m_b64"] = scan_leg(pa, ctx, 12_500_000, 64, k, "auto", es, ew)
             extra["encoder_256x256"] = encoder_leg(pa, ctx, "f32")
             extra["encoder_256x256_split_precision"] = [encoder_leg(pa, ctx, "bf16x3"), encoder_leg(pa, ctx, "f16x2")]
             if not args.clustered and args.rows >= 1_000_000:
                 searcher.close()  # two 153.6 GB corpora do not fit: the clustered one replaces the headline one
+                settle(total_rows * (args.dim * 4 + args.dim + 8))
                 extra["clustered_b64"] = scan_leg(pa, ctx, args.rows, B, k, args.kernel, es, ew, clustered=True)
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:

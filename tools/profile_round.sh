@@ -11,6 +11,7 @@ run() {  # run <dir under gpurun_out> <rocprof args...> -- <program...>
   d=$1; shift
   rm -rf $G/$d
   timeout -k 10 400 rocprofv3 "$@" > $G/$d.log 2>&1 || { echo "FAILED: $d"; tail -5 $G/$d.log; exit 1; }
+  sleep 7  # the driver clears the ~190 GB the run gave back at ~34 GB/s in the background: 2.6 % of HBM bandwidth meanwhile
 }
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-extra"
 run prof_default     --kernel-trace --stats --output-format csv -d $G/prof_default     -o p -- $BENCH --steps 10
