@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--kernel", default="auto", choices=["auto", "wave", "mfma"])
+    ap.add_argument("--screen", default="auto", choices=["auto", "int8", "bf16", "off"],
+                    help="resident screening copy of the rows (results do not depend on it): auto = int8; "
+                         "off = the scan streams the f32 rows themselves (1536 B/vector)")
     ap.add_argument("--cpu-rows", type=int, default=int(os.environ.get("PCV_BENCH_CPU_ROWS", 1_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective", default=os.environ.get("PCV_BENCH_COLLECTIVE", "torch"), choices=["torch", "native"],
@@ -295,6 +298,8 @@ def main():
     lo = total_rows * rank // world
     hi = total_rows * (rank + 1) // world
     searcher = pa.Searcher(ctx, args.dim, "cosine")
+    if args.screen != "auto":
+        searcher.set_screening_copy(args.screen)
     t0 = time.time()
     ncl = max(1, total_rows // CLUSTER_ROWS) if args.clustered else 0
     searcher.add_synthetic(1, hi - lo, 0x5EED, first_row=lo, normalize=args.normalized, n_clusters=ncl,
