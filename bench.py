@@ -141,7 +141,7 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
     for i in range(warmup):
         searcher.search_vectors(None, k, queries[i])
     ctx.synchronize()
-    scan_ms, pass_ms, cands, reruns, launches = [], [], [], 0, 0
+    scan_ms, pass_ms, cands, reruns, launches, spec_reruns = [], [], [], 0, 0, 0
     t0 = time.perf_counter()
     for i in range(steps):
         searcher.search_vectors(None, k, queries[warmup + i])
@@ -150,6 +150,7 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
         pass_ms.append(st["total_ms"])
         cands.append(st["candidates"])
         reruns += st["overflow_reruns"]
+        spec_reruns += st["speculation_reruns"]
         launches += st["scan_launches"]
     ctx.synchronize()
     wall = time.perf_counter() - t0
@@ -166,7 +167,8 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
         "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS, "screening_copy": copy,
         "streamed_GBps": streamed_gbps, "streamed_frac_of_8TBps": streamed_gbps / HBM_PEAK_GBPS,
         "vectors_per_s": rows * steps / wall, "queries_per_s": batch * steps / wall,
-        "candidates_per_query": float(np.mean(cands)) / batch, "overflow_reruns": reruns, "steps": steps,
+        "candidates_per_query": float(np.mean(cands)) / batch, "overflow_reruns": reruns, "speculation_reruns": spec_reruns,
+        "steps": steps,
     }
     if own:
         searcher.close()
@@ -342,11 +344,11 @@ def main():
             torch.cuda.synchronize()
         ctx.synchronize()
 
-    scan_ms, pass_ms, host_ms, scan_bytes, streamed_bytes, cands, reruns = [], [], [], [], [], [], 0
+    scan_ms, pass_ms, host_ms, scan_bytes, streamed_bytes, cands, reruns, spec_reruns = [], [], [], [], [], [], 0, 0
     last = None
 
     def step(i, timed):
-        nonlocal last, reruns
+        nonlocal last, reruns, spec_reruns
         q = queries[i]
         if not use_dist:
             last = searcher.search_vectors(None, k, q)
@@ -354,13 +356,15 @@ def main():
             last = sharded.search_vectors(None, k, q)
         if timed:
             st = searcher.last_stats()
-            pass_ms.append(st["total_ms"])
+            nl = max(st["scan_launches"], 1)  # > 1 when a pass had to be repeated: the kernel figures are per launch
+            pass_ms.append(st["total_ms"] / nl)
             host_ms.append((st["host_enqueue_ms"], st["host_wait_ms"]))
-            scan_ms.append(st["scan_ms"])
-            scan_bytes.append(st["bytes_algorithmic"])
-            streamed_bytes.append(st["bytes_streamed"])
+            scan_ms.append(st["scan_ms"] / nl)
+            scan_bytes.append(st["bytes_algorithmic"] / nl)
+            streamed_bytes.append(st["bytes_streamed"] / nl)
             cands.append(st["candidates"])
             reruns += st["overflow_reruns"]
+            spec_reruns += st["speculation_reruns"]
 
     for i in range(args.warmup):
         step(i, False)
@@ -448,6 +452,7 @@ def main():
             },
             "candidates_per_query": float(np.mean(cands)) / B,
             "overflow_reruns": reruns,
+            "speculation_reruns": spec_reruns,  # passes repeated because a speculative start threshold did not hold (scan.h)
             "build_s": t_build,
             "sample_result": {"ids": [int(x) for x in ids[0][:3]], "scores": [float(x) for x in scores[0][:3]]},
         }

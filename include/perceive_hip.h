@@ -280,6 +280,9 @@ typedef struct pcv_scan_stats {
     float host_enqueue_ms;       /* host time spent queueing the passes (copies + launches)      */
     float host_wait_ms;          /* host time blocked until the stream had drained               */
     int64_t bytes_streamed;      /* rows_scanned * dim * (4 f32 rows, 2 bf16 copy, 1 int8 copy)  */
+    int32_t speculation_reruns;  /* passes repeated because a speculative start threshold (a guess taken from the seed
+                                    rows and checked at the end of the pass) did not hold; results are exact either way */
+    int32_t reserved0;
 } pcv_scan_stats;
 pcv_status pcv_searcher_last_stats(pcv_searcher* s, pcv_scan_stats* out);
 

@@ -41,6 +41,8 @@ class ScanStats(C.Structure):
         ("host_enqueue_ms", C.c_float),
         ("host_wait_ms", C.c_float),
         ("bytes_streamed", C.c_int64),
+        ("speculation_reruns", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

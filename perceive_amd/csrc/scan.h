@@ -101,7 +101,28 @@ struct ScanParams {
                              // copy, stream that; bit 6: every segment has its int8 screening copy, stream that; bits 8..15: workgroups per CU override; bits 16..23: seed workgroups; bits 24..27: chunk buffers override (tuning)
     float eps16, eps32;      // |s - c| bounds of the bf16 / f32 screening scores, relative to |q||x|
     float max_norm;          // upper bound of |x| over the corpus (dot metric margins)
+    // Speculative start threshold (int8 scan; 0 = off).  The k slots the seed kernel fills are the best scores of k
+    // disjoint groups of seed rows; min(slots) is a certified k-th best, but a weak one, and every wave screens its
+    // first block against it.  quantize_queries_kernel therefore raises tau to the spec_rank-th LARGEST slot — a guess
+    // that at least k rows of the whole pass score that high — and rescore_select_kernel checks the guess: it counts the
+    // survivors whose f32 score is above it by the fine margin; fewer than k and the query reports 0xffffffff survivors,
+    // the pass is repeated without the guess (searcher.cpp: finish_pass).  A checked guess keeps the result exact:
+    // with k rows at or above it the true k-th best is too, and no screen drops a row at or above tau - its margin.
+    // The host picks spec_rank so that, for rows in an order unrelated to the query, a guess fails with probability
+    // < 1e-6 (C(k-1, j) (seed rows / rows)^j: j of the k-1 best rows of the pass would have to be seed rows).
+    //
+    // On top of that distribution-free guess the searcher learns one from its own passes (spec_gap, NaN = none): how far
+    // the k-th best score of a pass ended up above the MEDIAN seed slot of its query (both come back through pinned
+    // memory: kth_host, spec_base_host); a fraction of the smallest gap of the recent passes is added to the median
+    // slot of the next queries.  Self-calibrating, and checked like the other: a corpus whose queries differ a lot
+    // simply learns a small gap.
+    uint32_t* spec;          // [128] key of the guess per query (kKeyNegInf: none), written by quantize_queries_kernel
+    int spec_rank;
+    float spec_gap;
+    float* spec_base_host;   // [128] pinned: median seed slot per query (NaN: none)
+    float* kth_host;         // [128] pinned: k-th best exact score per query (NaN: fewer than k hits)
 };
+constexpr uint32_t kSpecFailed = 0xffffffffu;  // cnt_host value of a query whose speculative threshold did not hold
 
 // float <-> order-preserving uint32 key (for atomicMax / CAS on scores)
 __host__ __device__ static inline uint32_t f32_key(float f) {

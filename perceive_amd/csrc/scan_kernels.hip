@@ -1159,6 +1159,36 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
         p.q8c[2 * q] = s_q;
         p.q8c[2 * q + 1] = 0.5002f * l1 * s_q + 0.2501f * (float)Dp8 + 4.0f;
     }
+    // the speculative start threshold (scan.h): the spec_rank-th largest seed slot, or the median slot + the learned
+    // gap if that is higher; ranks by counting
+    uint32_t guess = kKeyNegInf, med = kKeyNegInf;
+    const bool learned = p.spec_gap == p.spec_gap;
+    if ((p.spec_rank > 0 || learned) && have) {
+        const uint32_t* sl = p.slots + (size_t)q * kMaxK;
+        const int mid = (p.k - 1) / 2;
+        for (int a = lane; a < p.k; a += 64) {
+            const uint32_t va = ld_relaxed(&sl[a]);
+            int ahead = 0;
+            for (int i = 0; i < p.k; ++i) {
+                const uint32_t vi = ld_relaxed(&sl[i]);
+                ahead += (vi > va || (vi == va && i < a)) ? 1 : 0;
+            }
+            if (ahead == p.spec_rank - 1) guess = va;
+            if (ahead == mid) med = va;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            guess = max(guess, (uint32_t)__shfl_xor(guess, off));
+            med = max(med, (uint32_t)__shfl_xor(med, off));
+        }
+        if (learned && med != kKeyNegInf) {
+            const float g = key_f32(med) + p.spec_gap;
+            if (isfinite(g)) guess = max(guess, f32_key(g));
+        }
+        if (lane == 0 && guess != kKeyNegInf) g_atomic_max(&p.tau[q * kHot], guess);
+    }
+    if (lane == 0 && have && p.spec_base_host) p.spec_base_host[q] = med != kKeyNegInf ? key_f32(med) : __builtin_nanf("");
+    if (lane == 0) p.spec[q] = guess;
 }
 
 template <int NT, bool NTL, int WPB, int NBUF>
@@ -1378,7 +1408,7 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
     __shared__ int64_t k_p[kMaxK];
     __shared__ uint64_t k_e[kMaxK];
     __shared__ uint64_t surv[1024];  // candidates of the current slice that pass the final threshold
-    __shared__ uint32_t nsurv, n_valid;
+    __shared__ uint32_t nsurv, n_valid, n_spec;  // n_spec: survivors certainly at or above the speculative threshold
     __shared__ double s_nq, t_s;  // canonical |q|^2; score of the admission threshold
     __shared__ int64_t t_p;       // ... and its position
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1397,11 +1427,15 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
     if (tid == 0) {
         n_valid = 0;
         nsurv = 0;
+        n_spec = 0;
         t_s = -__builtin_inf();
         t_p = INT64_MAX;
     }
     __syncthreads();
     const float thr_final = key_f32(max(s_tau0, ld_relaxed(&p.tau[q * kHot]))) - p.margin32[q];
+    const uint32_t guess = (p.spec_rank > 0 || p.spec_gap == p.spec_gap) ? ld_relaxed(&p.spec[q]) : kKeyNegInf;
+    const bool guessed = guess != kKeyNegInf;
+    const float thr_spec = guessed ? key_f32(guess) + p.margin32[q] : __builtin_inff();  // f32 score >= this: exact score >= the guess
     if (tid == 255) {  // canonical |q|^2: f64, feature order (the other waves go on to the filter meanwhile)
         double nq = 0.0;
         const float* f = (const float*)sq;
@@ -1463,6 +1497,7 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
             const float sj = cs[j];
             const uint64_t ej = cand[j];  // fetched with the score, not after the test
             if (!(sj < thr_final)) surv[atomicAdd(&nsurv, 1u)] = ej;
+            if (guessed && sj >= thr_spec) atomicAdd(&n_spec, 1u);
         }
         __syncthreads();  // nsurv is final; s_nq is there
         const uint32_t ns = nsurv;
@@ -1555,8 +1590,10 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
             hit.pos = c_p[i];
             hit.id = sg.ids ? sg.ids[row] : sg.id0 + (int64_t)row;
             put(r, hit);
+            if (r == p.k - 1 && p.kth_host) p.kth_host[q] = (float)c_s[i];
         }
     }
+    if (tid == 0 && nv < (uint32_t)p.k && p.kth_host) p.kth_host[q] = __builtin_nanf("");
     pcv_hit_dev none;
     none.score = __builtin_nan("");
     none.pos = -1;
@@ -1564,8 +1601,9 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
     for (int j = (int)nv + tid; j < p.k; j += 256) put(j, none);
     // survivor count (uncapped: the host sizes a rerun from it), overflow record, clean state
     if (tid == 0) {
-        if (p.cnt_host) p.cnt_host[q] = raw_cnt;
-        if (raw_cnt > p.cand_cap && p.flag_rec) p.flag_rec->pos = 1;
+        const bool failed = guessed && n_spec < (uint32_t)p.k;  // (after the last slice's barrier)
+        if (p.cnt_host) p.cnt_host[q] = failed ? kSpecFailed : raw_cnt;
+        if ((raw_cnt > p.cand_cap || failed) && p.flag_rec) p.flag_rec->pos = 1;
         st_relaxed(&p.tau[q * kHot], kKeyNegInf);
         st_relaxed(&p.cand_cnt[q * kHot], 0u);
     }

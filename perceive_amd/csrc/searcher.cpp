@@ -97,6 +97,16 @@ struct pcv_searcher {
     DevBuf<uint16_t> d_qbf16;
     DevBuf<int8_t> d_q8;
     DevBuf<float> d_q8c;
+    DevBuf<uint32_t> d_spec;                 // speculative start thresholds of a pass (scan.h)
+    bool spec_hold = false;                  // a guess failed: the repeat of that pass runs without one
+    // learned part of the guess (scan.h): smallest (k-th best - median seed slot) of each recent pass of one shape
+    static constexpr int kGapPasses = 4;
+    float gap_hist[kGapPasses] = {0, 0, 0, 0};  // each entry: the smallest gap of a group of >= 8 queries
+    int gap_seen = 0;
+    float gap_acc = INFINITY;
+    int gap_acc_n = 0;
+    int64_t gap_rows = -1;
+    int gap_k = 0, gap_nseg = 0;
     DevBuf<float> d_cand_s;
     DevBuf<uint32_t> d_tau, d_slots, d_cnt;
     DevBuf<uint64_t> d_cand;
@@ -109,6 +119,8 @@ struct pcv_searcher {
     // what one pass brings back: written by rescore_select_kernel straight into pinned memory
     struct Pinned {
         uint32_t cnt[kMfmaQueries];
+        float spec_base[kMfmaQueries];  // median seed slot per query, k-th best exact score per query (scan.h: spec_gap)
+        float kth[kMfmaQueries];
         pcv_hit_dev hits[kMfmaQueries * kMaxK];
     };
     Pinned* pin = nullptr;
@@ -429,6 +441,7 @@ void ensure_workspace(pcv_searcher* s) {
     s->d_qbf16.ensure(Q * s->Dp);
     s->d_q8.ensure(Q * (size_t)((s->Dp + 127) & ~127));
     s->d_q8c.ensure(Q * 2);
+    s->d_spec.ensure(Q);
     s->d_margin.ensure(Q);
     s->d_margin32.ensure(Q);
     s->d_tau.ensure(Q * kHot);
@@ -529,6 +542,39 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.seed_blocks = std::min<uint32_t>(std::min<uint32_t>(seed_parts, kSeedParts) * kSeedPartRows / kBlockRows, segs[0].g->nblocks());
     // |s - c| bounds of the screening scores, relative to |q||x| (DESIGN.md §screening error): an f32 FMA
     // chain in any order, and one bf16 rounding per operand on top of it
+    // speculative start threshold (scan.h): the int8 scan only (its queue has the kernel that sets it); j-th largest
+    // seed slot with the smallest j whose guess fails with probability < 1e-6 on rows in an order unrelated to the query
+    p.spec = s->d_spec.p;
+    p.spec_rank = 0;
+    p.spec_gap = NAN;
+    p.spec_base_host = s->pin->spec_base;
+    p.kth_host = s->pin->kth;
+    if (s->gap_rows != rows || s->gap_k != k || s->gap_nseg != nseg) {  // another shape: learn afresh
+        s->gap_rows = rows;
+        s->gap_k = k;
+        s->gap_nseg = nseg;
+        s->gap_seen = s->gap_acc_n = 0;
+        s->gap_acc = INFINITY;
+    }
+    if (kernel == PCV_KERNEL_MFMA && src_kind == 2 && !s->spec_hold && !(s->scan_flags & 32u) && k >= 2) {
+        if (s->gap_seen >= pcv_searcher::kGapPasses && !(s->scan_flags & 128u)) {
+            float g = s->gap_hist[0];
+            for (float h : s->gap_hist) g = std::min(g, h);
+            // 0.7: the median of k group maxima has a long upper tail, so a query's gap can fall well below the
+            // smallest of the ~32+ seen (0.85 failed once in ~1700 queries on Gaussian rows; a failed guess costs a pass)
+            if (g > 0.0f && std::isfinite(g)) p.spec_gap = 0.7f * g;
+        }
+        const double r = (double)std::min<int64_t>(tab[0].nrows, (int64_t)p.seed_blocks * kBlockRows) / (double)std::max<int64_t>(rows, 1);
+        double binom = 1.0, rj = 1.0;
+        for (int j = 1; j < k && r < 0.25; ++j) {
+            binom *= (double)(k - j) / (double)j;  // C(k-1, j)
+            rj *= r;
+            if (binom * rj < 1e-6) {
+                p.spec_rank = j;
+                break;
+            }
+        }
+    }
     p.eps32 = (float)(s->Dp + 16) * 1.2e-7f;
     p.eps16 = 0.0039101f + 2.0f * p.eps32;
     p.max_norm = s->max_norm;
@@ -659,13 +705,40 @@ bool finish_pass(pcv_searcher* s) {
     const uint32_t* cnt = s->pin->cnt;
     uint32_t mx = 0;
     int64_t sum = 0;
+    bool guess_failed = false;
     for (int b = 0; b < B; ++b) {
+        if (cnt[b] == kSpecFailed) {  // fewer than k rows at the speculative threshold (scan.h): repeat without it
+            guess_failed = true;
+            continue;
+        }
         mx = std::max(mx, cnt[b]);
         sum += cnt[b];
     }
-    if (mx <= s->cand_cap) {
+    if (mx <= s->cand_cap && !guess_failed) {
         s->stats.candidates += sum;
+        s->spec_hold = false;
+        if (s->pending.src == 2) {  // what this pass teaches about the gap (scan.h: spec_gap)
+            for (int b = 0; b < B; ++b) {
+                const float d = s->pin->kth[b] - s->pin->spec_base[b];
+                if (d == d) {
+                    s->gap_acc = std::min(s->gap_acc, d);
+                    s->gap_acc_n += 1;
+                }
+            }
+            if (s->gap_acc_n >= 8) {
+                s->gap_hist[s->gap_seen++ % pcv_searcher::kGapPasses] = s->gap_acc;
+                s->gap_acc = INFINITY;
+                s->gap_acc_n = 0;
+            }
+        }
         return false;
+    }
+    if (guess_failed) {
+        s->stats.speculation_reruns += 1;
+        s->spec_hold = true;
+        s->gap_seen = s->gap_acc_n = 0;  // what was learned did not hold: start over
+        s->gap_acc = INFINITY;
+        if (mx <= s->cand_cap) return true;
     }
     s->stats.overflow_reruns += 1;
     uint64_t want = (uint64_t)mx + mx / 4 + 1024;
@@ -682,7 +755,7 @@ void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* s
     for (int attempt = 0;; ++attempt) {
         enqueue_pass(s, attempt == 0 ? queries_host : nullptr, B, segs, nseg, k, kernel, d_out, download, nullptr);
         if (!finish_pass(s)) return;
-        PCV_REQUIRE(attempt < 6, "candidate lists still overflow after %d reruns", attempt + 1);
+        PCV_REQUIRE(attempt < 7, "candidate lists still overflow after %d reruns", attempt + 1);
     }
 }
 
@@ -839,6 +912,7 @@ pcv_status pcv_searcher_destroy(pcv_searcher* s) {
         s->d_qbf16.release();
         s->d_q8.release();
         s->d_q8c.release();
+        s->d_spec.release();
         s->d_cand_s.release();
         s->d_tau.release();
         s->d_slots.release();
@@ -1391,6 +1465,7 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
             total.candidates += s->stats.candidates;
             total.scan_launches += s->stats.scan_launches;
             total.overflow_reruns += s->stats.overflow_reruns;
+            total.speculation_reruns += s->stats.speculation_reruns;
             total.host_enqueue_ms += s->stats.host_enqueue_ms;
             total.host_wait_ms += s->stats.host_wait_ms;
             total.kernel_used = s->stats.kernel_used;
@@ -1418,7 +1493,7 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
                 if (!again) std::memcpy(all.data() + (size_t)q0 * k, c->pin_hits, nb * sizeof(pcv_hit_dev));
                 accumulate();
                 if (!again) break;
-                PCV_REQUIRE(attempt < 6, "search_sharded: candidate lists still overflow after %d reruns", attempt + 1);
+                PCV_REQUIRE(attempt < 7, "search_sharded: candidate lists still overflow after %d reruns", attempt + 1);
             }
         }
         s->stats = total;

@@ -55,6 +55,8 @@ pub struct pcv_scan_stats {
     pub host_enqueue_ms: f32,
     pub host_wait_ms: f32,
     pub bytes_streamed: i64,
+    pub speculation_reruns: i32,
+    pub reserved0: i32,
 }
 
 #[repr(C)]

@@ -1100,3 +1100,42 @@ def test_screens_agree_with_the_oracle_across_shapes(ctx, oracle, D, B, k, metri
         mine = np.array([oracle.canonical_score(q[b], m[pos_of_id[int(i)]], metric=1 if metric == "dot" else 0) for i in got[b] if i >= 0])
         theirs = np.array([oracle.canonical_score(q[b], m[int(p)], metric=1 if metric == "dot" else 0) for p in ref[b] if p >= 0])
         np.testing.assert_array_equal(mine, theirs)
+
+
+def test_speculative_threshold_is_checked_and_repeated_when_it_fails(ctx, oracle, monkeypatch):
+    # The int8 scan starts from a guess taken from the seed rows (the first 16384 of the first segment) and checked at
+    # the end of the pass (scan.h).  Here the guess must fail for query 0: its ten best rows ARE seed rows, so the
+    # seed score the guess is taken from (one of the ten: they sit in ten different seed groups, row mod k) has fewer
+    # than ten rows at or above it; the pass is repeated without the guess and the
+    # answer is the oracle's.  Query 1 has its best rows far from the seed rows: its guess holds.  Afterwards the
+    # same searcher answers unrelated queries without a repeat, and a searcher with the guess switched off
+    # (PCV_SCAN_FLAGS bit 5) returns the same hits.
+    rng = np.random.default_rng(77)
+    N, D, k = 400_000, 128, 10
+    m = rng.standard_normal((N, D)).astype(np.float32)
+    q = rng.standard_normal((2, D)).astype(np.float32)
+    for j in range(k):  # graded near-copies of query 0 among the seed rows, of query 1 in the tail
+        m[37 + 1501 * j] = q[0] + (0.02 + 0.01 * j) * rng.standard_normal(D).astype(np.float32)
+        m[N - 5 - 3000 * j] = q[1] + (0.02 + 0.01 * j) * rng.standard_normal(D).astype(np.float32)
+    s = build(ctx, m, kernel="mfma")
+    ids, scores, counts = s.search_vectors(None, k, q)
+    st = s.last_stats()
+    assert st["screening_copy"] == 2 and st["speculation_reruns"] == 1 and st["scan_launches"] == 2, st
+    opos, osc, _ = oracle.topk(q, m, k)
+    np.testing.assert_array_equal(ids, opos)
+    np.testing.assert_allclose(scores, osc, rtol=0, atol=1e-6)
+    assert set(ids[0]) == {37 + 1501 * j for j in range(k)} and set(ids[1]) == {N - 5 - 3000 * j for j in range(k)}
+    q2 = rng.standard_normal((64, D)).astype(np.float32)
+    for _ in range(6):  # enough passes for the learned part of the guess to come into play
+        ids2, sc2, _ = s.search_vectors(None, k, q2)
+    assert s.last_stats()["speculation_reruns"] == 0
+    opos2, osc2, _ = oracle.topk(q2, m, k)
+    np.testing.assert_array_equal(ids2, opos2)
+    s.close()
+    monkeypatch.setenv("PCV_SCAN_FLAGS", "32")
+    s = build(ctx, m, kernel="mfma")
+    ids3, sc3, _ = s.search_vectors(None, k, q)
+    assert s.last_stats()["speculation_reruns"] == 0 and s.last_stats()["scan_launches"] == 1
+    np.testing.assert_array_equal(ids3, ids)
+    np.testing.assert_array_equal(sc3, scores)
+    s.close()
