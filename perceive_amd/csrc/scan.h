@@ -96,7 +96,9 @@ struct ScanParams {
     uint32_t* cnt_host;      // [B] pinned host: survivors per query, uncapped (the host sizes a rerun from it)
     pcv_hit_dev* flag_rec;   // overflow record behind a shard's hit list (device), or nullptr
     uint32_t cand_cap;
-    uint32_t seed_blocks;    // leading blocks of segment 0 ranked by the seed kernel
+    uint32_t seed_blocks;    // blocks of segment 0 ranked by the seed kernel: blocks i << seed_shift, i < seed_blocks — spread
+    uint32_t seed_shift;     // over the whole segment, so that rows stored in an order that goes with their content (by topic, by
+                             // date) still give a sample of all of it
     uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bit 4: every segment has its bf16 screening
                              // copy, stream that; bit 6: every segment has its int8 screening copy, stream that; bits 8..15: workgroups per CU override; bits 16..23: seed workgroups; bits 24..27: chunk buffers override (tuning)
     float eps16, eps32;      // |s - c| bounds of the bf16 / f32 screening scores, relative to |q||x|

@@ -423,6 +423,11 @@ __global__ __launch_bounds__(256) void reset_scan_state_kernel(uint32_t* __restr
     }
 }
 
+// is block `lb` of segment `si` one the seed kernel ranked?  (its rows are in the slots already: no second offer)
+__device__ __forceinline__ bool is_seed_block(const ScanParams& p, int si, uint32_t lb) {
+    return si == 0 && (lb & ((1u << p.seed_shift) - 1u)) == 0 && (lb >> p.seed_shift) < p.seed_blocks;
+}
+
 // min over the k slots of query q = the threshold the seed rows alone justify.  Four threads per query.
 // Every consumer of a threshold takes max(this, tau): the seed kernel only fills the slots (no hand-off
 // inside a launch), and tau is raised by the scan's offers.
@@ -465,13 +470,15 @@ __global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __rest
     // of them is used: the phase is latency-bound (a workgroup reads 384 KB once), so what counts is bytes
     // in flight — 64 KB per workgroup.  The first step's loads go out before the queries are prepared.
     static_assert(kSeedPartRows == 256, "one seed row per thread");
-    const uint32_t row = part * kSeedPartRows + tid;
-    const uint32_t rowc = min(row, nseed ? nseed - 1 : 0u);
+    const uint32_t sr = part * kSeedPartRows + tid;  // seed row: row sr & 31 of seed block sr >> 5
+    const uint32_t row = (((sr >> 5) << p.seed_shift) << 5) | (sr & 31);
+    const bool valid = (sr >> 5) < p.seed_blocks && row < nseed;
+    const uint32_t rowc = valid ? row : 0u;
     const float4* base = seg0_blk + (size_t)(rowc >> 5) * p.D4 * 32 + (rowc & 31);
     float4 v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = gld4(base + (size_t)j * 32);
-    const float sc = row < nseed ? gld(&seg0_scale[row]) : 0.0f;
+    const float sc = valid ? gld(&seg0_scale[row]) : 0.0f;
     __builtin_amdgcn_sched_barrier(0);
 
     for (int i = tid; i < QG * kMaxK; i += 256) gmax[i] = kKeyNegInf;
@@ -595,8 +602,9 @@ __global__ __launch_bounds__(256) void prep_seed_mfma_kernel(const ScanParams* _
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const bool writer = part == 0;
-    const uint32_t lb = part * 4 + wave;           // this wave's corpus block of segment 0
-    const bool active = lb * 32u < nseed;
+    const uint32_t sb = part * 4 + wave;           // this wave's seed block = corpus block sb << seed_shift of segment 0
+    const uint32_t lb = sb << p.seed_shift;
+    const bool active = sb < p.seed_blocks && lb * 32u < nseed;
     const int P = p.D4 >> 1;                       // pieces per lane
     const float4* base = seg0_blk + (size_t)(active ? lb : 0) * p.D4 * 32 + h * 32 + r;
     float4 va[16], vb[16];
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
                 acc[b] = 0.0f;
             }
             if (__any(any)) {
-                const bool feeds = !(cons.sc.si == 0 && cons.lb < p.seed_blocks);
+                const bool feeds = !is_seed_block(p, cons.sc.si, cons.lb);
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
                     if ((h == 0) && (sc_cur != 0.0f) && !(s[b] < thr[b])) emit_hit(p, b, cons.sc.si, row, s[b], feeds);
@@ -880,7 +888,7 @@ __device__ __forceinline__ void fine_survivors(const ScanParams& p, uint32_t mas
                                                const uint32_t* ltau0, int lane, int D4) {
     unsigned long long ball = __ballot(mask != 0);
     if (!ball) return;
-    const bool feeds = !(esc.si == 0 && elb < p.seed_blocks);
+    const bool feeds = !is_seed_block(p, esc.si, elb);
     const float* scp = esc.scale + (size_t)elb * 32;
     const float4* bbase = esc.blk + (size_t)elb * D4 * 32;
     const int Dp = D4 * 4;
@@ -1161,7 +1169,7 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
     }
     // the speculative start threshold (scan.h): the spec_rank-th largest seed slot, or the median slot + the learned
     // gap if that is higher; ranks by counting
-    uint32_t guess = kKeyNegInf, med = kKeyNegInf;
+    uint32_t guess = kKeyNegInf, med = kKeyNegInf, top = kKeyNegInf;
     const bool learned = p.spec_gap == p.spec_gap;
     if ((p.spec_rank > 0 || learned) && have) {
         const uint32_t* sl = p.slots + (size_t)q * kMaxK;
@@ -1175,14 +1183,19 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
             }
             if (ahead == p.spec_rank - 1) guess = va;
             if (ahead == mid) med = va;
+            if (ahead == 0) top = va;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             guess = max(guess, (uint32_t)__shfl_xor(guess, off));
             med = max(med, (uint32_t)__shfl_xor(med, off));
+            top = max(top, (uint32_t)__shfl_xor(top, off));
         }
         if (learned && med != kKeyNegInf) {
-            const float g = key_f32(med) + p.spec_gap;
+            // never further above the best seed score than that one is above the median seed score: a query whose
+            // seed scores are bunched (its neighbourhood was sampled) is not given the gap of queries whose are not
+            const float fm = key_f32(med), ft = key_f32(top);
+            const float g = fminf(fm + p.spec_gap, ft + (ft - fm));
             if (isfinite(g)) guess = max(guess, f32_key(g));
         }
         if (lane == 0 && guess != kKeyNegInf) g_atomic_max(&p.tau[q * kHot], guess);
@@ -1762,7 +1775,7 @@ void launch_upload(hipStream_t st, const void* src_pinned, void* dst, size_t byt
 
 void launch_prep_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp, const SegDesc& seg0) {
     const int nparts = std::max(1, (int)((p.seed_blocks * 32u + kSeedPartRows - 1) / kSeedPartRows));
-    const uint32_t nseed = std::min<uint32_t>(seg0.nrows, p.seed_blocks * 32u);
+    const uint32_t nseed = seg0.nrows;  // rows of the segment: the seed blocks are spread over it (seed_shift)
     const size_t Dp = (size_t)p.D4 * 4;
     const size_t lds1 = Dp * sizeof(float) + kMaxK * sizeof(uint32_t);
     const size_t lds_mfma = 32 * (Dp + 4) * sizeof(float) + 32 * (size_t)p.k * sizeof(uint32_t);

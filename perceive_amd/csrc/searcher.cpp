@@ -99,12 +99,37 @@ struct pcv_searcher {
     DevBuf<float> d_q8c;
     DevBuf<uint32_t> d_spec;                 // speculative start thresholds of a pass (scan.h)
     bool spec_hold = false;                  // a guess failed: the repeat of that pass runs without one
-    // learned part of the guess (scan.h): smallest (k-th best - median seed slot) of each recent pass of one shape
-    static constexpr int kGapPasses = 4;
-    float gap_hist[kGapPasses] = {0, 0, 0, 0};  // each entry: the smallest gap of a group of >= 8 queries
-    int gap_seen = 0;
-    float gap_acc = INFINITY;
-    int gap_acc_n = 0;
+    int spec_rest = 0;                       // ... and so do the next passes: 16 after a first failure, doubling up to 1024
+    int spec_penalty = 0;                    //     while failures keep coming, forgotten after 4096 passes without one
+    int spec_clean = 0;
+    // learned part of the guess (scan.h): statistics of (k-th best - median seed slot) over the queries of one pass shape
+    struct GapStats {
+        int64_t n = 0;
+        double mean = 0.0, m2 = 0.0;  // Welford
+        float smallest = INFINITY;
+        int holdoff = 0;              // passes still to run without a learned guess after one failed
+        void add(float d) {
+            n += 1;
+            const double dl = d - mean;
+            mean += dl / (double)n;
+            m2 += dl * (d - mean);
+            smallest = std::min(smallest, d);
+        }
+        void reset() {
+            n = 0;
+            mean = m2 = 0.0;
+            smallest = INFINITY;
+        }
+        // used only where the gaps seen are tightly concentrated (queries alike, as far as this statistic goes): then six
+        // standard deviations below their mean, and no more than 0.8 of the smallest seen; otherwise no learned guess
+        float gap() const {
+            if (n < 128 || holdoff > 0) return NAN;
+            const double sd = std::sqrt(m2 / (double)(n - 1));
+            if (!(mean > 0.0) || sd > 0.15 * mean) return NAN;
+            const double g = std::min(mean - 6.0 * sd, 0.8 * (double)smallest);
+            return g > 0.0 ? (float)g : NAN;
+        }
+    } gaps;
     int64_t gap_rows = -1;
     int gap_k = 0, gap_nseg = 0;
     DevBuf<float> d_cand_s;
@@ -159,6 +184,7 @@ struct pcv_searcher {
         int64_t rows = 0;
         int src = 0;  // what the scan streamed: 0 f32 rows, 1 bf16 copies, 2 int8 copies
         bool replayed = false;  // launched as a graph: only the pass as a whole was timed
+        bool learned = false;   // the speculative threshold had a learned part
     } pending;
 
     Source* find_source(int64_t id) {
@@ -540,6 +566,8 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.flags = (s->scan_flags & ~(16u | 64u)) | (src_kind == 1 ? 16u : 0u) | (src_kind == 2 ? 64u : 0u);
     const uint32_t seed_parts = ((s->scan_flags >> 16) & 0xff) ? ((s->scan_flags >> 16) & 0xff) : kSeedParts;  // tuning
     p.seed_blocks = std::min<uint32_t>(std::min<uint32_t>(seed_parts, kSeedParts) * kSeedPartRows / kBlockRows, segs[0].g->nblocks());
+    p.seed_shift = 0;  // the seed blocks are every 2^shift-th block of segment 0, the largest stride that fits
+    while (((uint64_t)p.seed_blocks << (p.seed_shift + 1)) <= segs[0].g->nblocks() && p.seed_shift < 20) ++p.seed_shift;
     // |s - c| bounds of the screening scores, relative to |q||x| (DESIGN.md §screening error): an f32 FMA
     // chain in any order, and one bf16 rounding per operand on top of it
     // speculative start threshold (scan.h): the int8 scan only (its queue has the kernel that sets it); j-th largest
@@ -553,18 +581,11 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
         s->gap_rows = rows;
         s->gap_k = k;
         s->gap_nseg = nseg;
-        s->gap_seen = s->gap_acc_n = 0;
-        s->gap_acc = INFINITY;
+        s->gaps.reset();
     }
-    if (kernel == PCV_KERNEL_MFMA && src_kind == 2 && !s->spec_hold && !(s->scan_flags & 32u) && k >= 2) {
-        if (s->gap_seen >= pcv_searcher::kGapPasses && !(s->scan_flags & 128u)) {
-            float g = s->gap_hist[0];
-            for (float h : s->gap_hist) g = std::min(g, h);
-            // 0.7: the median of k group maxima has a long upper tail, so a query's gap can fall well below the
-            // smallest of the ~32+ seen (0.85 failed once in ~1700 queries on Gaussian rows; a failed guess costs a pass)
-            if (g > 0.0f && std::isfinite(g)) p.spec_gap = 0.7f * g;
-        }
-        const double r = (double)std::min<int64_t>(tab[0].nrows, (int64_t)p.seed_blocks * kBlockRows) / (double)std::max<int64_t>(rows, 1);
+    if (kernel == PCV_KERNEL_MFMA && src_kind == 2 && !s->spec_hold && s->spec_rest == 0 && !(s->scan_flags & 32u) && k >= 2) {
+        if (!(s->scan_flags & 128u)) p.spec_gap = s->gaps.gap();
+        const double r = (double)std::min<int64_t>(tab[0].nrows, (int64_t)p.seed_blocks * kBlockRows) / (double)std::max<int64_t>(rows, 1);  // (seed rows) / rows
         double binom = 1.0, rj = 1.0;
         for (int j = 1; j < k && r < 0.25; ++j) {
             binom *= (double)(k - j) / (double)j;  // C(k-1, j)
@@ -668,6 +689,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     s->pending.B = B;
     s->pending.rows = rows;
     s->pending.src = src_kind;
+    s->pending.learned = p.spec_gap == p.spec_gap;
     s->stats.host_enqueue_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
@@ -717,27 +739,28 @@ bool finish_pass(pcv_searcher* s) {
     if (mx <= s->cand_cap && !guess_failed) {
         s->stats.candidates += sum;
         s->spec_hold = false;
+        if (s->spec_rest > 0) s->spec_rest -= 1;
+        if (s->spec_penalty > 0 && ++s->spec_clean >= 4096) s->spec_penalty = s->spec_clean = 0;
         if (s->pending.src == 2) {  // what this pass teaches about the gap (scan.h: spec_gap)
             for (int b = 0; b < B; ++b) {
                 const float d = s->pin->kth[b] - s->pin->spec_base[b];
-                if (d == d) {
-                    s->gap_acc = std::min(s->gap_acc, d);
-                    s->gap_acc_n += 1;
-                }
+                if (d == d && std::isfinite(d)) s->gaps.add(d);
             }
-            if (s->gap_acc_n >= 8) {
-                s->gap_hist[s->gap_seen++ % pcv_searcher::kGapPasses] = s->gap_acc;
-                s->gap_acc = INFINITY;
-                s->gap_acc_n = 0;
-            }
+            if (s->gaps.holdoff > 0) s->gaps.holdoff -= 1;
         }
         return false;
     }
     if (guess_failed) {
         s->stats.speculation_reruns += 1;
         s->spec_hold = true;
-        s->gap_seen = s->gap_acc_n = 0;  // what was learned did not hold: start over
-        s->gap_acc = INFINITY;
+        if (s->pending.learned) {  // what was learned did not hold: start over, and not before 256 passes have gone by
+            s->gaps.reset();
+            s->gaps.holdoff = 256;
+        } else {  // the seed rows were not a fair sample for this query: no guesses for a while
+            s->spec_penalty = std::min(1024, s->spec_penalty ? 2 * s->spec_penalty : 16);
+            s->spec_rest = s->spec_penalty;
+            s->spec_clean = 0;
+        }
         if (mx <= s->cand_cap) return true;
     }
     s->stats.overflow_reruns += 1;

@@ -1103,20 +1103,26 @@ def test_screens_agree_with_the_oracle_across_shapes(ctx, oracle, D, B, k, metri
 
 
 def test_speculative_threshold_is_checked_and_repeated_when_it_fails(ctx, oracle, monkeypatch):
-    # The int8 scan starts from a guess taken from the seed rows (the first 16384 of the first segment) and checked at
-    # the end of the pass (scan.h).  Here the guess must fail for query 0: its ten best rows ARE seed rows, so the
-    # seed score the guess is taken from (one of the ten: they sit in ten different seed groups, row mod k) has fewer
-    # than ten rows at or above it; the pass is repeated without the guess and the
-    # answer is the oracle's.  Query 1 has its best rows far from the seed rows: its guess holds.  Afterwards the
-    # same searcher answers unrelated queries without a repeat, and a searcher with the guess switched off
-    # (PCV_SCAN_FLAGS bit 5) returns the same hits.
+    # The int8 scan starts from a guess taken from the seed rows (512 blocks of 32 rows spread evenly over the first
+    # segment) and checked at the end of the pass (scan.h).  Here the guess must fail for query 0: its ten best rows
+    # ARE seed rows, one in each of the ten seed groups (row mod k), so the seed score the guess is taken from has
+    # fewer than ten rows at or above it; the pass is repeated without the guess and the answer is the oracle's.
+    # Query 1 has its best rows outside the seed blocks: its guess holds.  Afterwards the same searcher answers
+    # unrelated queries without a repeat, and a searcher with the guess switched off (PCV_SCAN_FLAGS bit 5) returns the
+    # same hits.
     rng = np.random.default_rng(77)
     N, D, k = 400_000, 128, 10
     m = rng.standard_normal((N, D)).astype(np.float32)
     q = rng.standard_normal((2, D)).astype(np.float32)
-    for j in range(k):  # graded near-copies of query 0 among the seed rows, of query 1 in the tail
-        m[37 + 1501 * j] = q[0] + (0.02 + 0.01 * j) * rng.standard_normal(D).astype(np.float32)
-        m[N - 5 - 3000 * j] = q[1] + (0.02 + 0.01 * j) * rng.standard_normal(D).astype(np.float32)
+    nblocks, shift = (N + 31) // 32, 0
+    while (512 << (shift + 1)) <= nblocks:
+        shift += 1
+    seed_rows = [((7 + 31 * j) << shift) * 32 + j for j in range(k)]          # row j of seed block 7 + 31 j: ten residues mod 10
+    other_rows = [(((11 + 29 * j) << shift) + 1) * 32 + 5 for j in range(k)]  # the block after a seed block
+    assert len({r % k for r in seed_rows}) == k and max(seed_rows + other_rows) < N
+    for j in range(k):  # graded near-copies of the queries
+        m[seed_rows[j]] = q[0] + (0.02 + 0.01 * j) * rng.standard_normal(D).astype(np.float32)
+        m[other_rows[j]] = q[1] + (0.02 + 0.01 * j) * rng.standard_normal(D).astype(np.float32)
     s = build(ctx, m, kernel="mfma")
     ids, scores, counts = s.search_vectors(None, k, q)
     st = s.last_stats()
@@ -1124,7 +1130,7 @@ def test_speculative_threshold_is_checked_and_repeated_when_it_fails(ctx, oracle
     opos, osc, _ = oracle.topk(q, m, k)
     np.testing.assert_array_equal(ids, opos)
     np.testing.assert_allclose(scores, osc, rtol=0, atol=1e-6)
-    assert set(ids[0]) == {37 + 1501 * j for j in range(k)} and set(ids[1]) == {N - 5 - 3000 * j for j in range(k)}
+    assert set(ids[0]) == set(seed_rows) and set(ids[1]) == set(other_rows)
     q2 = rng.standard_normal((64, D)).astype(np.float32)
     for _ in range(6):  # enough passes for the learned part of the guess to come into play
         ids2, sc2, _ = s.search_vectors(None, k, q2)
