@@ -121,7 +121,9 @@ struct ScanParams {
     uint32_t* spec;          // [128] key of the guess per query (kKeyNegInf: none), written by quantize_queries_kernel
     int spec_rank;
     float spec_gap;
+    float spec_spread;       // learned: mean (best - median) seed slot; a query takes the learned gap only if its own is within 50 %
     float* spec_base_host;   // [128] pinned: median seed slot per query (NaN: none)
+    float* spec_top_host;    // [128] pinned: best seed slot per query
     float* kth_host;         // [128] pinned: k-th best exact score per query (NaN: fewer than k hits)
 };
 constexpr uint32_t kSpecFailed = 0xffffffffu;  // cnt_host value of a query whose speculative threshold did not hold

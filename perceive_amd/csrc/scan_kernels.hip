@@ -1196,11 +1196,16 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
             // seed scores are bunched (its neighbourhood was sampled) is not given the gap of queries whose are not
             const float fm = key_f32(med), ft = key_f32(top);
             const float g = fminf(fm + p.spec_gap, ft + (ft - fm));
-            if (isfinite(g)) guess = max(guess, f32_key(g));
+            // ... and only a query whose seed scores spread like those the gap was learned from takes it at all
+            const bool alike = fabsf((ft - fm) - p.spec_spread) <= 0.5f * p.spec_spread;
+            if (alike && isfinite(g)) guess = max(guess, f32_key(g));
         }
         if (lane == 0 && guess != kKeyNegInf) g_atomic_max(&p.tau[q * kHot], guess);
     }
-    if (lane == 0 && have && p.spec_base_host) p.spec_base_host[q] = med != kKeyNegInf ? key_f32(med) : __builtin_nanf("");
+    if (lane == 0 && have && p.spec_base_host) {
+        p.spec_base_host[q] = med != kKeyNegInf ? key_f32(med) : __builtin_nanf("");
+        p.spec_top_host[q] = top != kKeyNegInf ? key_f32(top) : __builtin_nanf("");
+    }
     if (lane == 0) p.spec[q] = guess;
 }
 

@@ -106,18 +106,20 @@ struct pcv_searcher {
     struct GapStats {
         int64_t n = 0;
         double mean = 0.0, m2 = 0.0;  // Welford
+        double spread = 0.0;          // mean (best - median) seed slot of the same queries
         float smallest = INFINITY;
         int holdoff = 0;              // passes still to run without a learned guess after one failed
-        void add(float d) {
+        void add(float d, float sp) {
             n += 1;
             const double dl = d - mean;
             mean += dl / (double)n;
             m2 += dl * (d - mean);
+            spread += (sp - spread) / (double)n;
             smallest = std::min(smallest, d);
         }
         void reset() {
             n = 0;
-            mean = m2 = 0.0;
+            mean = m2 = spread = 0.0;
             smallest = INFINITY;
         }
         // used only where the gaps seen are tightly concentrated (queries alike, as far as this statistic goes): then six
@@ -144,7 +146,8 @@ struct pcv_searcher {
     // what one pass brings back: written by rescore_select_kernel straight into pinned memory
     struct Pinned {
         uint32_t cnt[kMfmaQueries];
-        float spec_base[kMfmaQueries];  // median seed slot per query, k-th best exact score per query (scan.h: spec_gap)
+        float spec_base[kMfmaQueries];  // median / best seed slot per query, k-th best exact score per query (scan.h: spec_gap)
+        float spec_top[kMfmaQueries];
         float kth[kMfmaQueries];
         pcv_hit_dev hits[kMfmaQueries * kMaxK];
     };
@@ -575,7 +578,9 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.spec = s->d_spec.p;
     p.spec_rank = 0;
     p.spec_gap = NAN;
+    p.spec_spread = 0.0f;
     p.spec_base_host = s->pin->spec_base;
+    p.spec_top_host = s->pin->spec_top;
     p.kth_host = s->pin->kth;
     if (s->gap_rows != rows || s->gap_k != k || s->gap_nseg != nseg) {  // another shape: learn afresh
         s->gap_rows = rows;
@@ -585,6 +590,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     }
     if (kernel == PCV_KERNEL_MFMA && src_kind == 2 && !s->spec_hold && s->spec_rest == 0 && !(s->scan_flags & 32u) && k >= 2) {
         if (!(s->scan_flags & 128u)) p.spec_gap = s->gaps.gap();
+        p.spec_spread = (float)s->gaps.spread;
         const double r = (double)std::min<int64_t>(tab[0].nrows, (int64_t)p.seed_blocks * kBlockRows) / (double)std::max<int64_t>(rows, 1);  // (seed rows) / rows
         double binom = 1.0, rj = 1.0;
         for (int j = 1; j < k && r < 0.25; ++j) {
@@ -744,7 +750,8 @@ bool finish_pass(pcv_searcher* s) {
         if (s->pending.src == 2) {  // what this pass teaches about the gap (scan.h: spec_gap)
             for (int b = 0; b < B; ++b) {
                 const float d = s->pin->kth[b] - s->pin->spec_base[b];
-                if (d == d && std::isfinite(d)) s->gaps.add(d);
+                const float sp = s->pin->spec_top[b] - s->pin->spec_base[b];
+                if (d == d && std::isfinite(d) && sp == sp && std::isfinite(sp)) s->gaps.add(d, sp);
             }
             if (s->gaps.holdoff > 0) s->gaps.holdoff -= 1;
         }
