@@ -206,7 +206,7 @@ def encoder_leg(pa, ctx, compute, steps=5, warmup=2, batch=256, seq=256):
     }
 
 
-def e2e_leg(pa, ctx, searcher, rows, steps=3, warmup=1, batch=256, seq=256, k=10):
+def e2e_leg(pa, ctx, searcher, rows, steps=5, warmup=2, batch=256, seq=256, k=10):
     """BASELINE configs[4] on one GPU: encode 256 x 256 tokens (f32), then search the 256 embeddings over the
     resident corpus (two passes of 128 queries)."""
     m = pa.Model(ctx, pa.minilm_l6_desc("f32"), synthetic_seed=1)
