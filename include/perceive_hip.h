@@ -210,9 +210,10 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
 
 /* The same per-shard search split in two so that the exchange can be queued behind it without a host
  * round trip.  `begin` queues the whole pass on the context stream and returns at once; `d_out` then
- * holds n_queries*k hits followed by ONE extra pcv_hit whose `pos` is 1 if a candidate list of this
- * pass overflowed (the results are then incomplete and the pass must be repeated), else 0.  `end` waits
- * for the stream, books the statistics and, after an overflow, enlarges the lists for the repeat.
+ * holds n_queries*k hits followed by ONE extra pcv_hit whose `pos` is 1 if the pass must be repeated —
+ * a candidate list overflowed, or a speculative start threshold did not hold (pcv_scan_stats) — and the
+ * hits are then incomplete; else 0.  `end` waits for the stream, books the statistics and prepares the
+ * repeat (larger lists; no guess).
  * No other call may use the searcher between the two.  PCV_ERR_UNSUPPORTED only when n_queries exceeds
  * one pass (use pcv_searcher_search_device then) — a condition every rank of a sharded search evaluates
  * alike, so all ranks exchange the same payload; a shard that holds none of the selected sources delivers

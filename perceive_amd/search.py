@@ -193,7 +193,8 @@ class Searcher:
         )
 
     def search_device_end(self):
-        """Wait for the queued pass and book its statistics; True if a candidate list overflowed."""
+        """Wait for the queued pass and book its statistics; True if the pass has to be repeated (a candidate list
+        overflowed, or a speculative start threshold did not hold)."""
         over = C.c_int()
         _ffi.check(_ffi.lib().pcv_searcher_search_device_end(self._handle, C.byref(over)))
         return bool(over.value)
