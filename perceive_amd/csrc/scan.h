@@ -103,9 +103,9 @@ struct ScanParams {
                              // copy, stream that; bit 6: every segment has its int8 screening copy, stream that; bits 8..15: workgroups per CU override; bits 16..23: seed workgroups; bits 24..27: chunk buffers override (tuning)
     float eps16, eps32;      // |s - c| bounds of the bf16 / f32 screening scores, relative to |q||x|
     float max_norm;          // upper bound of |x| over the corpus (dot metric margins)
-    // Speculative start threshold (int8 scan; 0 = off).  The k slots the seed kernel fills are the best scores of k
+    // Speculative start threshold (MFMA scans; 0 = off).  The k slots the seed kernel fills are the best scores of k
     // disjoint groups of seed rows; min(slots) is a certified k-th best, but a weak one, and every wave screens its
-    // first block against it.  quantize_queries_kernel therefore raises tau to the spec_rank-th LARGEST slot — a guess
+    // first block against it.  set_guess (quantize_queries_kernel / set_guess_kernel) therefore raises tau to the spec_rank-th LARGEST slot — a guess
     // that at least k rows of the whole pass score that high — and rescore_select_kernel checks the guess: it counts the
     // survivors whose f32 score is above it by the fine margin; fewer than k and the query reports 0xffffffff survivors,
     // the pass is repeated without the guess (searcher.cpp: finish_pass).  A checked guess keeps the result exact:
@@ -118,7 +118,7 @@ struct ScanParams {
     // memory: kth_host, spec_base_host); a fraction of the smallest gap of the recent passes is added to the median
     // slot of the next queries.  Self-calibrating, and checked like the other: a corpus whose queries differ a lot
     // simply learns a small gap.
-    uint32_t* spec;          // [128] key of the guess per query (kKeyNegInf: none), written by quantize_queries_kernel
+    uint32_t* spec;          // [128] key of the guess per query (kKeyNegInf: none), written by set_guess
     int spec_rank;
     float spec_gap;
     float spec_spread;       // learned: mean (best - median) seed slot; a query takes the learned gap only if its own is within 50 %

@@ -1129,46 +1129,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-// Queries of the pass -> int8 tile of the int8 screen, one wave per tile row: q^_i = rint(q'_i * s_q), s_q = 127 / max|q'_i|
-// (q' = the scan-side query prep_seed wrote), and the per-query constants of the test (scan_mfma8_kernel).  Tile rows
-// beyond the batch are zeros with s_q = 0.
-__global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams* __restrict__ pp) {
-    const ScanParams& p = *pp;
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int Dp = p.D4 * 4, Dp8 = (Dp + 127) & ~127;
-    const bool have = q < p.B;
-    const float* src = p.qf32 + (size_t)q * Dp;
-    float x[16];  // Dp <= 1024: |acc| <= 1024 * 127^2 < 2^24, so the integer dot product converts to f32 exactly
-    float mx = 0.0f, l1 = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int i = lane + 64 * j;
-        x[j] = (have && i < Dp) ? gld(&src[i]) : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        mx = fmaxf(mx, fabsf(x[j]));
-        l1 += fabsf(x[j]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mx = fmaxf(mx, __shfl_xor(mx, off));
-        l1 += __shfl_xor(l1, off);
-    }
-    const float s_q = (mx > 0.0f && mx < __builtin_inff() && l1 < __builtin_inff()) ? 127.0f / mx : 0.0f;
-    int8_t* row = p.q8 + (size_t)q * Dp8;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int i = lane + 64 * j;
-        if (i < Dp8) row[i] = (int8_t)max(-127, min(127, (int)rintf((s_q != 0.0f ? x[j] : 0.0f) * s_q)));
-    }
-    if (lane == 0) {
-        p.q8c[2 * q] = s_q;
-        p.q8c[2 * q + 1] = 0.5002f * l1 * s_q + 0.2501f * (float)Dp8 + 4.0f;
-    }
-    // the speculative start threshold (scan.h): the spec_rank-th largest seed slot, or the median slot + the learned
-    // gap if that is higher; ranks by counting
+// The speculative start threshold of query q (scan.h), by one wave: the spec_rank-th largest seed slot, or the median
+// slot + the learned gap if that is higher; ranks by counting.  Raises tau, records the guess for the check at the end
+// of the pass and sends the query's median / best seed slot home for the learning.
+__device__ __forceinline__ void set_guess(const ScanParams& p, int q, int lane, bool have) {
     uint32_t guess = kKeyNegInf, med = kKeyNegInf, top = kKeyNegInf;
     const bool learned = p.spec_gap == p.spec_gap;
     if ((p.spec_rank > 0 || learned) && have) {
@@ -1207,6 +1171,54 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
         p.spec_top_host[q] = top != kKeyNegInf ? key_f32(top) : __builtin_nanf("");
     }
     if (lane == 0) p.spec[q] = guess;
+}
+
+// ... as a kernel of its own in front of the scans that have no query-quantisation step (bf16 copy / f32 rows)
+__global__ __launch_bounds__(256) void set_guess_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    set_guess(p, q, threadIdx.x & 63, q < p.B);
+}
+
+// Queries of the pass -> int8 tile of the int8 screen, one wave per tile row: q^_i = rint(q'_i * s_q), s_q = 127 / max|q'_i|
+// (q' = the scan-side query prep_seed wrote), and the per-query constants of the test (scan_mfma8_kernel).  Tile rows
+// beyond the batch are zeros with s_q = 0.
+__global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int Dp = p.D4 * 4, Dp8 = (Dp + 127) & ~127;
+    const bool have = q < p.B;
+    const float* src = p.qf32 + (size_t)q * Dp;
+    float x[16];  // Dp <= 1024: |acc| <= 1024 * 127^2 < 2^24, so the integer dot product converts to f32 exactly
+    float mx = 0.0f, l1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = lane + 64 * j;
+        x[j] = (have && i < Dp) ? gld(&src[i]) : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        mx = fmaxf(mx, fabsf(x[j]));
+        l1 += fabsf(x[j]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+        l1 += __shfl_xor(l1, off);
+    }
+    const float s_q = (mx > 0.0f && mx < __builtin_inff() && l1 < __builtin_inff()) ? 127.0f / mx : 0.0f;
+    int8_t* row = p.q8 + (size_t)q * Dp8;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = lane + 64 * j;
+        if (i < Dp8) row[i] = (int8_t)max(-127, min(127, (int)rintf((s_q != 0.0f ? x[j] : 0.0f) * s_q)));
+    }
+    if (lane == 0) {
+        p.q8c[2 * q] = s_q;
+        p.q8c[2 * q + 1] = 0.5002f * l1 * s_q + 0.2501f * (float)Dp8 + 4.0f;
+    }
+    set_guess(p, q, lane, have);
 }
 
 template <int NT, bool NTL, int WPB, int NBUF>
@@ -1896,6 +1908,10 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
     unsigned grid = (unsigned)num_cus * (gm ? gm : per_cu);
     const unsigned need = (p.total_blocks + wpb - 1) / wpb;
     if (grid > need) grid = need;
+    if (p.spec_rank > 0 || p.spec_gap == p.spec_gap) {
+        set_guess_kernel<<<(p.B + 3) / 4, 256, 0, st>>>(dp);
+        PCV_LAUNCHED();
+    }
     if (NT == 1) {
         if (ntl) launch_mfma_shape<1, true>(st, dp, grid, lds, wide, src16, nbuf, wpb);
         else launch_mfma_shape<1, false>(st, dp, grid, lds, wide, src16, nbuf, wpb);

@@ -163,12 +163,12 @@ struct pcv_searcher {
     // a pass of the same shape comes by, its launch sequence is captured into a hipGraph and replayed from then on (what
     // changes between passes — parameters, segment table, queries — travels in the pinned block the first kernel reads).
     struct PassShape {
-        int B = -1, k = 0, kernel = 0, src_kind = 0, nseg = 0;
+        int B = -1, k = 0, kernel = 0, src_kind = 0, nseg = 0, guess = 0;  // guess: the pass has the kernel that sets a speculative threshold
         uint32_t total_blocks = 0, seed_blocks = 0, flags = 0, seg0_rows = 0;
         size_t bytes = 0;
         const void *pin = nullptr, *dev = nullptr, *seg0_blk = nullptr, *seg0_scale = nullptr;
         bool operator==(const PassShape& o) const {
-            return B == o.B && k == o.k && kernel == o.kernel && src_kind == o.src_kind && nseg == o.nseg && total_blocks == o.total_blocks &&
+            return B == o.B && k == o.k && kernel == o.kernel && src_kind == o.src_kind && nseg == o.nseg && guess == o.guess && total_blocks == o.total_blocks &&
                    seed_blocks == o.seed_blocks && flags == o.flags && seg0_rows == o.seg0_rows && bytes == o.bytes && pin == o.pin &&
                    dev == o.dev && seg0_blk == o.seg0_blk && seg0_scale == o.seg0_scale;
         }
@@ -188,6 +188,7 @@ struct pcv_searcher {
         int src = 0;  // what the scan streamed: 0 f32 rows, 1 bf16 copies, 2 int8 copies
         bool replayed = false;  // launched as a graph: only the pass as a whole was timed
         bool learned = false;   // the speculative threshold had a learned part
+        bool guessing = false;  // the pass ran with a speculative threshold (and sent the seed statistics home)
     } pending;
 
     Source* find_source(int64_t id) {
@@ -588,7 +589,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
         s->gap_nseg = nseg;
         s->gaps.reset();
     }
-    if (kernel == PCV_KERNEL_MFMA && src_kind == 2 && !s->spec_hold && s->spec_rest == 0 && !(s->scan_flags & 32u) && k >= 2) {
+    if (kernel == PCV_KERNEL_MFMA && !s->spec_hold && s->spec_rest == 0 && !(s->scan_flags & 32u) && k >= 2) {
         if (!(s->scan_flags & 128u)) p.spec_gap = s->gaps.gap();
         p.spec_spread = (float)s->gaps.spread;
         const double r = (double)std::min<int64_t>(tab[0].nrows, (int64_t)p.seed_blocks * kBlockRows) / (double)std::max<int64_t>(rows, 1);  // (seed rows) / rows
@@ -635,6 +636,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     shape.k = k;
     shape.kernel = kernel;
     shape.src_kind = src_kind;
+    shape.guess = (p.spec_rank > 0 || p.spec_gap == p.spec_gap) ? 1 : 0;
     shape.nseg = nseg;
     shape.total_blocks = blk0;
     shape.seed_blocks = p.seed_blocks;
@@ -696,6 +698,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     s->pending.rows = rows;
     s->pending.src = src_kind;
     s->pending.learned = p.spec_gap == p.spec_gap;
+    s->pending.guessing = p.spec_rank > 0 || s->pending.learned;
     s->stats.host_enqueue_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 }
 
@@ -747,7 +750,7 @@ bool finish_pass(pcv_searcher* s) {
         s->spec_hold = false;
         if (s->spec_rest > 0) s->spec_rest -= 1;
         if (s->spec_penalty > 0 && ++s->spec_clean >= 4096) s->spec_penalty = s->spec_clean = 0;
-        if (s->pending.src == 2) {  // what this pass teaches about the gap (scan.h: spec_gap)
+        if (s->pending.guessing) {  // what this pass teaches about the gap (scan.h: spec_gap)
             for (int b = 0; b < B; ++b) {
                 const float d = s->pin->kth[b] - s->pin->spec_base[b];
                 const float sp = s->pin->spec_top[b] - s->pin->spec_base[b];
