@@ -110,6 +110,10 @@ struct pcv_searcher {
         float smallest = INFINITY;
         int holdoff = 0;              // passes still to run without a learned guess after one failed
         void add(float d, float sp) {
+            if (n >= 8192) {  // keep following the queries: older ones count half
+                n /= 2;
+                m2 /= 2.0;
+            }
             n += 1;
             const double dl = d - mean;
             mean += dl / (double)n;
