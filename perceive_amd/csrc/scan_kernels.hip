@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void upload_kernel(const uint4* __restrict__ s
 // (x / |x| for cosine; |q|^2 by a lane-parallel f64 sum — the canonical feature-order sum is only needed
 // for the exact scores and is made by rescore_select_kernel) — the `part == 0` workgroups also publish
 // them (f32, bf16, raw, margins) for the scan — then ranks rows [part*256, +256) of segment 0 against
-// them with f32 FMA chains.  Seed rows are split in k disjoint groups (row mod k); the best score of
+// them with f32 FMA chains.  Seed rows are split in k disjoint groups (position in the sample mod k); the best score of
 // each group goes to slot j: k distinct rows, so min(slots) is a valid running k-th best, without any
 // selection step and without any hand-off between workgroups (the atomics are fire-and-forget).  The
 // streaming kernels thus start with a useful threshold: with W waves in flight the first round screens
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __rest
             }
     }
     {
-        const uint32_t grp = row % (uint32_t)p.k;
+        const uint32_t grp = sr % (uint32_t)p.k;  // groups by position in the sample: every group gets rows whatever the stride
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             const float s = acc[g] * sc;
@@ -712,9 +712,9 @@ __global__ __launch_bounds__(256) void prep_seed_mfma_kernel(const ScanParams* _
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const uint32_t row = lb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
             const float s = acc[i] * sc[i];
-            if (sc[i] != 0.0f && isfinite(s)) atomicMax(&gmax[r * p.k + row % (uint32_t)p.k], f32_key(s));
+            const uint32_t sr = sb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // position in the sample: its group (every group gets rows whatever the stride)
+            if (sc[i] != 0.0f && isfinite(s)) atomicMax(&gmax[r * p.k + sr % (uint32_t)p.k], f32_key(s));
         }
     }
     __syncthreads();

@@ -1105,7 +1105,7 @@ def test_screens_agree_with_the_oracle_across_shapes(ctx, oracle, D, B, k, metri
 def test_speculative_threshold_is_checked_and_repeated_when_it_fails(ctx, oracle, monkeypatch):
     # The int8 scan starts from a guess taken from the seed rows (512 blocks of 32 rows spread evenly over the first
     # segment) and checked at the end of the pass (scan.h).  Here the guess must fail for query 0: its ten best rows
-    # ARE seed rows, one in each of the ten seed groups (row mod k), so the seed score the guess is taken from has
+    # ARE seed rows, one in each of the ten seed groups (position in the sample mod k), so the seed score the guess is taken from has
     # fewer than ten rows at or above it; the pass is repeated without the guess and the answer is the oracle's.
     # Query 1 has its best rows outside the seed blocks: its guess holds.  Afterwards the same searcher answers
     # unrelated queries without a repeat, and a searcher with the guess switched off (PCV_SCAN_FLAGS bit 5) returns the
@@ -1117,9 +1117,9 @@ def test_speculative_threshold_is_checked_and_repeated_when_it_fails(ctx, oracle
     nblocks, shift = (N + 31) // 32, 0
     while (512 << (shift + 1)) <= nblocks:
         shift += 1
-    seed_rows = [((7 + 31 * j) << shift) * 32 + j for j in range(k)]          # row j of seed block 7 + 31 j: ten residues mod 10
+    seed_rows = [((7 + 31 * j) << shift) * 32 + j for j in range(k)]          # row j of seed block 7 + 31 j: ten seed groups
     other_rows = [(((11 + 29 * j) << shift) + 1) * 32 + 5 for j in range(k)]  # the block after a seed block
-    assert len({r % k for r in seed_rows}) == k and max(seed_rows + other_rows) < N
+    assert len({((7 + 31 * j) * 32 + j) % k for j in range(k)}) == k and max(seed_rows + other_rows) < N  # (position in the sample) mod k
     for j in range(k):  # graded near-copies of the queries
         m[seed_rows[j]] = q[0] + (0.02 + 0.01 * j) * rng.standard_normal(D).astype(np.float32)
         m[other_rows[j]] = q[1] + (0.02 + 0.01 * j) * rng.standard_normal(D).astype(np.float32)
@@ -1145,3 +1145,30 @@ def test_speculative_threshold_is_checked_and_repeated_when_it_fails(ctx, oracle
     np.testing.assert_array_equal(ids3, ids)
     np.testing.assert_array_equal(sc3, scores)
     s.close()
+
+
+@pytest.mark.parametrize("metric,k", [("cosine", 10), ("dot", 2), ("cosine", 128)])
+def test_speculative_threshold_on_rows_sorted_by_similarity(ctx, oracle, metric, k):
+    # Rows stored best first: block 0 — a seed block — holds the 32 best rows for the query, so every guess taken from
+    # the seed rows is too high; and the reverse order, where the seed rows say nothing about the end of the corpus.
+    # Both must come out exact, whatever the number of repeated passes.
+    rng = np.random.default_rng(5)
+    N, D = 300_000, 96
+    q = rng.standard_normal((1, D)).astype(np.float32)
+    qh = (q / np.linalg.norm(q)).astype(np.float64)
+    u = rng.standard_normal((N, D))
+    u -= (u @ qh.T) * qh  # orthogonal to the query, unit length: similarity is a function of t alone
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    t = np.linspace(1.0, -1.0, N)[:, None]
+    m = (t * qh + 0.5 * u).astype(np.float32)
+    for order in (m, m[::-1].copy()):
+        s = build(ctx, order, metric=metric, kernel="mfma")
+        s.set_candidate_capacity(1 << 16)
+        ids, scores, counts = s.search_vectors(None, k, q)
+        st = s.last_stats()
+        opos, osc, _ = oracle.topk(q, order, k, metric=1 if metric == "dot" else 0)
+        np.testing.assert_array_equal(ids, opos)
+        assert st["screening_copy"] == 2 and st["scan_launches"] == 1 + st["overflow_reruns"] + st["speculation_reruns"], st
+        if order is m and k >= 10:  # (k = 2: no seed slot is a safe enough guess on 300 000 rows, none is made)
+            assert st["speculation_reruns"] == 1, st
+        s.close()
