@@ -760,8 +760,8 @@ bool finish_pass(pcv_searcher* s) {
                 const float sp = s->pin->spec_top[b] - s->pin->spec_base[b];
                 if (d == d && std::isfinite(d) && sp == sp && std::isfinite(sp)) s->gaps.add(d, sp);
             }
-            if (s->gaps.holdoff > 0) s->gaps.holdoff -= 1;
         }
+        if (s->gaps.holdoff > 0) s->gaps.holdoff -= 1;
         return false;
     }
     if (guess_failed) {
