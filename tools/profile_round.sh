@@ -35,4 +35,4 @@ done
 # keep only the summaries (the traces themselves are large)
 find $G/prof_* $G/pmc_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete 2>/dev/null
 find $G/prof_* $G/pmc_* -name "*.csv" | head -40
-tail -1 $G/prof_default.log | cut -c1-300
+echo done
