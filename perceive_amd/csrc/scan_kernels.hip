@@ -1406,6 +1406,154 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 #undef PCV_STEP
 }
 
+// 65..128 queries over rows of at most 384 features: the 128-query tile above needs 232 registers (64 accumulators, four
+// chunk buffers) and runs at 2 waves per SIMD.  Here a wave HOLDS a block (NCH chunks = all its 12 KB, in the registers the
+// chunk buffers took) and multiplies it with the two 64-query halves of the tile one after the other, so only 32
+// accumulators are live: the register footprint of the 64-query form, 3 waves per SIMD, three 51 KB tiles per CU.  In the
+// second half every chunk of the next block is requested as soon as the MFMAs of the chunk it replaces are out; the
+// latency is covered by the rest of that half, its epilogue and the other eleven waves of the CU.
+template <bool NTL, int NCH>
+__global__ __launch_bounds__(256, 3) void scan_mfma8_hold_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
+    extern __shared__ uint4 lq8[];  // [128][LDQ] pieces of 16 int8
+    constexpr int P16 = NCH * 8;    // pieces per row
+    constexpr int LDQ = P16 + 1;    // odd
+    const int D4 = p.D4;
+    __shared__ uint32_t ltau0[128];
+    __shared__ float lsq[128], lvq[128], le32[128];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 128 * P16; i += 256) {  // the tile quantize_queries_kernel prepared
+        const int q = i / P16, pc = i - q * P16;
+        lq8[(size_t)q * LDQ + pc] = __builtin_bit_cast(uint4, gld4((const float4*)p.q8 + i));
+    }
+    for (int q = threadIdx.x; q < 128; q += 256) {
+        lsq[q] = gld(&p.q8c[2 * q]);
+        lvq[q] = gld(&p.q8c[2 * q + 1]);
+        le32[q] = q < p.B ? 0.5f * gld(&p.margin32[q]) : 0.0f;
+    }
+    for (int q = threadIdx.x >> 2; q < 128; q += 64) {
+        const uint32_t key = seed_threshold_key(p, q, threadIdx.x & 3);
+        if ((threadIdx.x & 3) == 0) ltau0[q] = key;
+    }
+    __syncthreads();
+    const int c = lane & 31, h = lane >> 5;
+    const float nrm = (p.metric == PCV_METRIC_DOT) ? p.max_norm : 1.0f;
+    const float c1 = 0.5002f * sqrtf((float)(NCH * 128)) * nrm;
+    const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
+
+    const uint32_t total_waves = gridDim.x * 4;
+    struct Cur {
+        uint32_t gb;
+        SegCursor sc;
+        uint32_t lb;
+    } cur;
+    cur.gb = blockIdx.x * 4 + wave;
+    if (cur.gb >= p.total_blocks) return;
+
+    float4 buf[NCH][4];
+    float srv = 0.0f;
+    float2 smm = make_float2(0.0f, 0.0f);
+    const float4* base = nullptr;
+    auto enter = [&]() {  // the block `cur` points at
+        seek_seg(p, cur.sc, cur.gb);
+        cur.lb = cur.gb - cur.sc.begin;
+        base = (const float4*)cur.sc.blk8 + (size_t)cur.lb * P16 * 32 + h * 32 + c;
+    };
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) buf[ch][i] = ld_row<NTL>(base + (size_t)(ch * 8 + i * 2) * 32);
+    };
+    auto load_scales = [&]() {  // of the block's rows (see scan_mfma8_kernel)
+        const float* s8 = cur.sc.scale8 + (size_t)cur.lb * kScale8Stride;
+        srv = gld(s8 + 16 * h + (lane & 15));
+        smm.x = gld(s8 + 32 + 2 * h);
+        smm.y = gld(s8 + 33 + 2 * h);
+    };
+    enter();
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) load_chunk(ch);
+    load_scales();
+
+    while (true) {
+        SegCursor esc = cur.sc;
+        uint32_t elb = cur.lb;
+        float srv_e = 0.0f;
+        float2 smm_e = make_float2(0.0f, 0.0f);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int q0 = 64 * half + c;  // this lane's queries: q0, q0 + 32
+            uint32_t tauk[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) tauk[t] = (q0 + 32 * t < p.B) ? max(ltau0[q0 + 32 * t], ld_relaxed(&p.tau[(q0 + 32 * t) * kHot])) : 0u;
+            i32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = 0;
+            bool more = false;
+            if (half == 0) {
+                srv_e = srv;
+                smm_e = smm;
+            } else {  // second half: every chunk's registers are free once its MFMAs are out: the next block's chunk follows at once
+                cur.gb += total_waves;
+                more = cur.gb < p.total_blocks;
+                if (more) enter();
+            }
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const i32x4 a = __builtin_bit_cast(i32x4, buf[ch][ks]);
+                    const int pc = 2 * (ch * 4 + ks) + h;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const i32x4 q8 = *(const i32x4*)&lq8[(size_t)(q0 + 32 * t) * LDQ + pc];
+                        acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
+                    }
+                }
+                if (half == 1 && more) load_chunk(ch);
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler would fetch all 2 * 4 * NCH query pieces first: 190 registers)
+            }
+            if (half == 1 && more) load_scales();
+            // epilogue of this half (scan_mfma8_kernel has the derivation)
+            float U[2], vq[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int q = q0 + 32 * t;
+                const float sq = lsq[q];
+                vq[t] = lvq[q];
+                const float T = (key_f32(tauk[t]) - le32[q]) * sq;
+                U[t] = (q < p.B) ? (sq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
+            }
+            bool hot = false;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                int m = acc[t][0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
+                hot |= (float)m >= fmaf(U[t] >= 0.0f ? smm_e.x : smm_e.y, U[t], -vq[t]);
+            }
+            if (__any(hot)) {
+                uint32_t mask[2] = {0u, 0u};
+#define PCV_TEST(I)                                                                                                            \
+    {                                                                                                                          \
+        const float s_row = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, srv_e), 0x150 + I, 0xf, 0xf, false)); \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) mask[t] |= ((float)acc[t][I] >= fmaf(s_row, U[t], -vq[t])) ? (1u << I) : 0u;  \
+    }
+                PCV_TEST(0) PCV_TEST(1) PCV_TEST(2) PCV_TEST(3) PCV_TEST(4) PCV_TEST(5) PCV_TEST(6) PCV_TEST(7)
+                PCV_TEST(8) PCV_TEST(9) PCV_TEST(10) PCV_TEST(11) PCV_TEST(12) PCV_TEST(13) PCV_TEST(14) PCV_TEST(15)
+#undef PCV_TEST
+                if (__any((mask[0] | mask[1]) != 0)) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) fine_survivors(p, mask[t], 2 * half + t, esc, elb, ltau0, lane, D4);
+                }
+            }
+        }
+        if (cur.gb >= p.total_blocks) return;
+    }
+}
+
 __device__ __forceinline__ bool better(double sa, int64_t pa, double sb, int64_t pb) {
     return sa > sb || (sa == sb && pa < pb);
 }
@@ -1957,6 +2105,28 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
     if (p.D4 * 4 > 1024) PCV_FAIL(PCV_ERR_UNSUPPORTED, "int8 screen: dimension %d is too large", p.D);
     quantize_queries_kernel<<<NT * 32 / 4, 256, 0, st>>>(dp);
     PCV_LAUNCHED();
+    const int nch = ((p.D4 * 4 + 127) & ~127) >> 7;
+    if (NT == 4 && nch <= 3 && !(p.flags & 8u)) {  // (flag bit 3: the 128-query tile, for comparison)
+        const unsigned g3 = std::min<unsigned>((unsigned)num_cus * (gm ? gm : 3u), need);
+        static bool allowed = false;
+        if (!allowed) {  // three of them are the same tile size or smaller
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_hold_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(4, 384)));
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_hold_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(4, 384)));
+            allowed = true;
+        }
+        if (nch == 3) {
+            if (ntl) scan_mfma8_hold_kernel<true, 3><<<g3, 256, lds, st>>>(dp);
+            else scan_mfma8_hold_kernel<false, 3><<<g3, 256, lds, st>>>(dp);
+        } else if (nch == 2) {
+            if (ntl) scan_mfma8_hold_kernel<true, 2><<<g3, 256, lds, st>>>(dp);
+            else scan_mfma8_hold_kernel<false, 2><<<g3, 256, lds, st>>>(dp);
+        } else {
+            if (ntl) scan_mfma8_hold_kernel<true, 1><<<g3, 256, lds, st>>>(dp);
+            else scan_mfma8_hold_kernel<false, 1><<<g3, 256, lds, st>>>(dp);
+        }
+        PCV_LAUNCHED();
+        return;
+    }
     if (NT == 1) {
         if (ntl) launch_mfma8_variant<1, true>(st, dp, grid, lds);
         else launch_mfma8_variant<1, false>(st, dp, grid, lds);

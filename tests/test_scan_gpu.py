@@ -1054,7 +1054,8 @@ def test_screening_copy_gives_way_when_memory_is_short(ctx, oracle, monkeypatch)
     e.close()
 
 
-@pytest.mark.parametrize("D,B,k", [(64, 1, 1), (100, 7, 10), (256, 33, 128), (512, 65, 10), (768, 128, 10), (1000, 5, 3), (1024, 64, 10), (384, 128, 128)])
+@pytest.mark.parametrize("D,B,k", [(64, 1, 1), (100, 7, 10), (256, 33, 128), (512, 65, 10), (768, 128, 10), (1000, 5, 3), (1024, 64, 10), (384, 128, 128),
+                                   (96, 100, 10), (256, 128, 10), (320, 65, 5)])  # the last three: the block-holding form for 65..128 queries
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
 def test_screens_agree_with_the_oracle_across_shapes(ctx, oracle, D, B, k, metric):
     """int8 / bf16 / no screening copy over widths, batch sizes and k that exercise every query-tile shape, three sources in
