@@ -148,7 +148,8 @@ pcv_status pcv_searcher_get_rows(pcv_searcher* s, const int64_t* positions, int6
                                  int64_t* out_ids);
 
 /* Which scan kernel pcv_searcher_search uses. AUTO: wave-reduction kernel for n_queries <= 4,
- * MFMA tile kernel otherwise (up to 128 queries per corpus pass at dim <= 640). */
+ * MFMA tile kernel otherwise (up to 128 queries per corpus pass at dim <= 640; 256 with the int8 screening copy at
+ * dim <= 384).  More queries than one pass takes are searched in several passes. */
 enum { PCV_KERNEL_AUTO = 0, PCV_KERNEL_WAVE = 1, PCV_KERNEL_MFMA = 2 };
 pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel);
 

@@ -36,7 +36,7 @@ constexpr int kSeedParts = 64;       // seed workgroups per query group -> up to
 constexpr int kMaxWaveQueries = 4;  // wave-reduction kernel handles 1..4 queries per pass
 constexpr int kHot = 256;            // uint32 words between per-query hot words (tau, cand_cnt): 1 KB apart,
                                      // so the device-wide atomics on them do not queue on one HBM channel
-constexpr int kMfmaQueries = 128;   // MFMA kernel handles up to 128 queries per pass
+constexpr int kMfmaQueries = 256;   // most queries of one pass (the int8 scan up to 384-d: 256; the other MFMA scans 128)
 constexpr int kScale8Stride = 36;   // floats per block in SegDesc::scale8: 32 row scales + (min, max) of its two 16-row sets
 
 // One corpus segment as a scan launch sees it.  A launch walks any number of them: the table lives in

@@ -1412,27 +1412,31 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 // accumulators are live: the register footprint of the 64-query form, 3 waves per SIMD, three 51 KB tiles per CU.  In the
 // second half every chunk of the next block is requested as soon as the MFMAs of the chunk it replaces are out; the
 // latency is covered by the rest of that half, its epilogue and the other eleven waves of the CU.
-template <bool NTL, int NCH>
-__global__ __launch_bounds__(256, 3) void scan_mfma8_hold_kernel(const ScanParams* __restrict__ pp) {
+// NH halves of 64 queries: 2 (up to 128 queries: 256-thread workgroups, three 51 KB tiles per CU) or 4 (up to 256 queries:
+// one 768-thread workgroup and one 102 KB tile per CU, the same 3 waves per SIMD) — one pass over the rows for 256 queries.
+template <bool NTL, int NCH, int NH>
+__global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
-    extern __shared__ uint4 lq8[];  // [128][LDQ] pieces of 16 int8
+    constexpr int TQ = NH * 64;       // queries of the tile
+    constexpr int WPB = NH == 2 ? 4 : 12;
+    extern __shared__ uint4 lq8[];  // [TQ][LDQ] pieces of 16 int8
     constexpr int P16 = NCH * 8;    // pieces per row
     constexpr int LDQ = P16 + 1;    // odd
     const int D4 = p.D4;
-    __shared__ uint32_t ltau0[128];
-    __shared__ float lsq[128], lvq[128], le32[128];
+    __shared__ uint32_t ltau0[TQ];
+    __shared__ float lsq[TQ], lvq[TQ], le32[TQ];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < 128 * P16; i += 256) {  // the tile quantize_queries_kernel prepared
+    for (int i = threadIdx.x; i < TQ * P16; i += WPB * 64) {  // the tile quantize_queries_kernel prepared
         const int q = i / P16, pc = i - q * P16;
         lq8[(size_t)q * LDQ + pc] = __builtin_bit_cast(uint4, gld4((const float4*)p.q8 + i));
     }
-    for (int q = threadIdx.x; q < 128; q += 256) {
+    for (int q = threadIdx.x; q < TQ; q += WPB * 64) {
         lsq[q] = gld(&p.q8c[2 * q]);
         lvq[q] = gld(&p.q8c[2 * q + 1]);
         le32[q] = q < p.B ? 0.5f * gld(&p.margin32[q]) : 0.0f;
     }
-    for (int q = threadIdx.x >> 2; q < 128; q += 64) {
+    for (int q = threadIdx.x >> 2; q < TQ; q += WPB * 16) {
         const uint32_t key = seed_threshold_key(p, q, threadIdx.x & 3);
         if ((threadIdx.x & 3) == 0) ltau0[q] = key;
     }
@@ -1442,13 +1446,13 @@ __global__ __launch_bounds__(256, 3) void scan_mfma8_hold_kernel(const ScanParam
     const float c1 = 0.5002f * sqrtf((float)(NCH * 128)) * nrm;
     const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
 
-    const uint32_t total_waves = gridDim.x * 4;
+    const uint32_t total_waves = gridDim.x * WPB;
     struct Cur {
         uint32_t gb;
         SegCursor sc;
         uint32_t lb;
     } cur;
-    cur.gb = blockIdx.x * 4 + wave;
+    cur.gb = blockIdx.x * WPB + wave;
     if (cur.gb >= p.total_blocks) return;
 
     float4 buf[NCH][4];
@@ -1481,7 +1485,7 @@ __global__ __launch_bounds__(256, 3) void scan_mfma8_hold_kernel(const ScanParam
         float srv_e = 0.0f;
         float2 smm_e = make_float2(0.0f, 0.0f);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NH; ++half) {
             const int q0 = 64 * half + c;  // this lane's queries: q0, q0 + 32
             uint32_t tauk[2];
 #pragma unroll
@@ -1495,7 +1499,7 @@ __global__ __launch_bounds__(256, 3) void scan_mfma8_hold_kernel(const ScanParam
             if (half == 0) {
                 srv_e = srv;
                 smm_e = smm;
-            } else {  // second half: every chunk's registers are free once its MFMAs are out: the next block's chunk follows at once
+            } else if (half == NH - 1) {  // last half: every chunk's registers are free once its MFMAs are out: the next block's chunk follows at once
                 cur.gb += total_waves;
                 more = cur.gb < p.total_blocks;
                 if (more) enter();
@@ -1512,10 +1516,10 @@ __global__ __launch_bounds__(256, 3) void scan_mfma8_hold_kernel(const ScanParam
                         acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
                     }
                 }
-                if (half == 1 && more) load_chunk(ch);
+                if (half == NH - 1 && more) load_chunk(ch);
                 __builtin_amdgcn_sched_barrier(0);  // (the scheduler would fetch all 2 * 4 * NCH query pieces first: 190 registers)
             }
-            if (half == 1 && more) load_scales();
+            if (half == NH - 1 && more) load_scales();
             // epilogue of this half (scan_mfma8_kernel has the derivation)
             float U[2], vq[2];
 #pragma unroll
@@ -2076,6 +2080,7 @@ void launch_scan_mfma(hipStream_t st, const ScanParams& p, const ScanParams* dp,
 // (32*NT rows x (P16+1) pieces) of int8 query tile per workgroup
 static size_t mfma8_lds(int nt, int Dp) { return (size_t)nt * 32 * ((((Dp + 127) & ~127) >> 4) + 1) * 16; }
 int mfma8_pass_queries(int Dp) {
+    if (((Dp + 127) & ~127) <= 384) return 256;  // the block-holding form, four halves of 64 queries
     for (int nt : {4, 2, 1})
         if (mfma8_lds(nt, Dp) <= 156 * 1024) return nt * 32;
     return 0;
@@ -2093,7 +2098,7 @@ static void launch_mfma8_variant(hipStream_t st, const ScanParams* dp, unsigned 
 
 void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
     if (p.total_blocks == 0) return;
-    const int NT = p.B <= 32 ? 1 : (p.B <= 64 ? 2 : 4);
+    const int NT = p.B <= 32 ? 1 : (p.B <= 64 ? 2 : (p.B <= 128 ? 4 : 8));  // 8: the 256-query tile of the block-holding form
     const size_t lds = mfma8_lds(NT, p.D4 * 4);
     const unsigned gm = (p.flags >> 8) & 0xff;
     const bool ntl = (p.flags & 1) == 0;
@@ -2106,27 +2111,35 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
     quantize_queries_kernel<<<NT * 32 / 4, 256, 0, st>>>(dp);
     PCV_LAUNCHED();
     const int nch = ((p.D4 * 4 + 127) & ~127) >> 7;
-    if (NT == 4 && nch <= 3 && !(p.flags & 8u)) {  // (flag bit 3: the 128-query tile, for comparison)
-        const unsigned g3 = std::min<unsigned>((unsigned)num_cus * (gm ? gm : 3u), need);
+    if (p.B > 64 && nch <= 3 && (p.B > 128 || !(p.flags & 8u))) {  // (flag bit 3: the 128-query tile, for comparison)
+        const bool four = p.B > 128;
+        const unsigned wpb = four ? 12 : 4;
+        const unsigned g3 = std::min<unsigned>((unsigned)num_cus * (gm ? gm : (four ? 1u : 3u)), (p.total_blocks + wpb - 1) / wpb);
+        const size_t ldsh = mfma8_lds(four ? 8 : 4, p.D4 * 4);
         static bool allowed = false;
-        if (!allowed) {  // three of them are the same tile size or smaller
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_hold_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(4, 384)));
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_hold_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(4, 384)));
+        if (!allowed) {
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_hold_kernel<true, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(4, 384)));
+            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_hold_kernel<false, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(4, 384)));
+            for (const void* f : {(const void*)scan_mfma8_hold_kernel<true, 3, 4>, (const void*)scan_mfma8_hold_kernel<false, 3, 4>,
+                                  (const void*)scan_mfma8_hold_kernel<true, 2, 4>, (const void*)scan_mfma8_hold_kernel<false, 2, 4>})
+                PCV_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(8, 384)));
             allowed = true;
         }
-        if (nch == 3) {
-            if (ntl) scan_mfma8_hold_kernel<true, 3><<<g3, 256, lds, st>>>(dp);
-            else scan_mfma8_hold_kernel<false, 3><<<g3, 256, lds, st>>>(dp);
-        } else if (nch == 2) {
-            if (ntl) scan_mfma8_hold_kernel<true, 2><<<g3, 256, lds, st>>>(dp);
-            else scan_mfma8_hold_kernel<false, 2><<<g3, 256, lds, st>>>(dp);
+#define PCV_HOLD(NCHV, NHV)                                                                           \
+    {                                                                                                 \
+        if (ntl) scan_mfma8_hold_kernel<true, NCHV, NHV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp); \
+        else scan_mfma8_hold_kernel<false, NCHV, NHV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp);    \
+    }
+        if (four) {
+            if (nch == 3) PCV_HOLD(3, 4) else if (nch == 2) PCV_HOLD(2, 4) else PCV_HOLD(1, 4)
         } else {
-            if (ntl) scan_mfma8_hold_kernel<true, 1><<<g3, 256, lds, st>>>(dp);
-            else scan_mfma8_hold_kernel<false, 1><<<g3, 256, lds, st>>>(dp);
+            if (nch == 3) PCV_HOLD(3, 2) else if (nch == 2) PCV_HOLD(2, 2) else PCV_HOLD(1, 2)
         }
+#undef PCV_HOLD
         PCV_LAUNCHED();
         return;
     }
+    if (NT == 8) PCV_FAIL(PCV_ERR_UNSUPPORTED, "int8 screen: %d queries in one pass need rows of at most 384 features", p.B);
     if (NT == 1) {
         if (ntl) launch_mfma8_variant<1, true>(st, dp, grid, lds);
         else launch_mfma8_variant<1, false>(st, dp, grid, lds);

@@ -536,6 +536,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     // stream the screening copies iff every selected segment has one of the kind the searcher keeps
     int src_kind = (kernel == PCV_KERNEL_MFMA) ? copy_kind_wanted(s) : 0;
     if (src_kind == 2 && (mfma8_pass_queries(s->Dp) < B || s->Dp > 1024)) src_kind = 0;
+    const int src_wanted = src_kind;
     for (int i = 0; i < nseg; ++i) {
         const Segment& g = *segs[i].g;
         tab[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), blk0, 0, g.blk16, g.blk8, g.scale8};
@@ -544,6 +545,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
         blk0 += g.nblocks();
         rows += g.nrows;
     }
+    PCV_REQUIRE(B <= 128 || (kernel == PCV_KERNEL_MFMA && src_kind == 2 && src_wanted == 2), "search: %d queries in one pass without int8 copies of every selected row", B);
     p.seg = reinterpret_cast<const SegDesc*>(s->d_pass + L.off_seg);
     p.nseg = nseg;
     p.total_blocks = blk0;
@@ -812,7 +814,10 @@ int pick_kernel(const pcv_searcher* s, int B) {
 }
 
 int pass_queries(const pcv_searcher* s, int kernel) {
-    return kernel == PCV_KERNEL_WAVE ? kMaxWaveQueries : mfma_pass_queries(s->Dp);
+    if (kernel == PCV_KERNEL_WAVE) return kMaxWaveQueries;
+    // every row has its int8 copy: the int8 scan's pass (256 queries up to 384-d); else what the bf16 / f32-row scans take
+    if (s->copies_kind == 2 && s->Dp <= 1024) return std::min(kMfmaQueries, std::max(mfma8_pass_queries(s->Dp), mfma_pass_queries(s->Dp)));
+    return mfma_pass_queries(s->Dp);
 }
 
 void check_search_args(const pcv_searcher* s, const float* queries, int n_queries, int k, const char* who) {

@@ -505,7 +505,7 @@ def test_begin_end_protocol_two_shards(ctx, oracle):
     np.testing.assert_allclose(scores, osc.astype(np.float32), atol=1e-7)
     assert attempts == 0 and (counts == k).all()
     # protocol errors: a second begin without end, an end without begin, more queries than one pass holds
-    d = ctx.alloc((200 * k + 1) * 24)
+    d = ctx.alloc((300 * k + 1) * 24)
     shards[0].search_device_begin(None, k, q, d)
     with pytest.raises(pa.PcvError):
         shards[0].search_device_begin(None, k, q, d)
@@ -513,7 +513,7 @@ def test_begin_end_protocol_two_shards(ctx, oracle):
     with pytest.raises(pa.PcvError):
         shards[0].search_device_end()
     with pytest.raises(pa.PcvError) as ei:
-        shards[0].search_device_begin(None, k, oracle.synth_rows(5, 0, 200, 384), d)
+        shards[0].search_device_begin(None, k, oracle.synth_rows(5, 0, 300, 384), d)  # (one pass: 256 queries at 384-d with int8 copies)
     assert ei.value.status == 3
     ctx.free(d)
     for s in shards:
@@ -1055,7 +1055,8 @@ def test_screening_copy_gives_way_when_memory_is_short(ctx, oracle, monkeypatch)
 
 
 @pytest.mark.parametrize("D,B,k", [(64, 1, 1), (100, 7, 10), (256, 33, 128), (512, 65, 10), (768, 128, 10), (1000, 5, 3), (1024, 64, 10), (384, 128, 128),
-                                   (96, 100, 10), (256, 128, 10), (320, 65, 5)])  # the last three: the block-holding form for 65..128 queries
+                                   (96, 100, 10), (256, 128, 10), (320, 65, 5),   # the block-holding form for 65..128 queries
+                                   (384, 256, 10), (200, 130, 7), (96, 300, 3)])   # ... and for 129..256 in one pass
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
 def test_screens_agree_with_the_oracle_across_shapes(ctx, oracle, D, B, k, metric):
     """int8 / bf16 / no screening copy over widths, batch sizes and k that exercise every query-tile shape, three sources in
