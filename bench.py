@@ -208,7 +208,7 @@ def encoder_leg(pa, ctx, compute, steps=5, warmup=2, batch=256, seq=256):
 
 def e2e_leg(pa, ctx, searcher, rows, steps=5, warmup=2, batch=256, seq=256, k=10):
     """BASELINE configs[4] on one GPU: encode 256 x 256 tokens (f32), then search the 256 embeddings over the
-    resident corpus (two passes of 128 queries)."""
+    resident corpus (one pass of 256 queries with the int8 copy at 384-d)."""
     m = pa.Model(ctx, pa.minilm_l6_desc("f32"), synthetic_seed=1)
     rng = np.random.default_rng(1)
     ids = rng.integers(1000, 30000, (batch, seq)).astype(np.int64)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End to end (BASELINE configs[4]): encode a batch of token sequences with the all-MiniLM-L6-v2-shaped
 encoder (seq_len 256, batch 256, seeded synthetic weights), then use the 256 embeddings as queries of an
-exact top-10 scan over the synthetic corpus (two passes of 128 queries).  Prints one JSON line.
+exact top-10 scan over the synthetic corpus (one pass of 256 queries with the int8 copy).  Prints one JSON line.
 
     python tools/bench_e2e.py                                            # one GPU
     python -m torch.distributed.run --nproc-per-node N tools/bench_e2e.py --gpus N
