@@ -119,6 +119,15 @@ def settle(freed_bytes):
     time.sleep(freed_bytes / (WIPE_GBPS * 1e9))
 
 
+def scan_kernel_name(stats, batch, dim):
+    """The dominant kernel of a pass, as rocprofv3 lists it (perceive_amd/csrc/scan_kernels.hip: launch_scan_*)."""
+    if stats["kernel_used"] != 2:
+        return "scan_wave_kernel"
+    if stats["screening_copy"] != 2:
+        return "scan_mfma_kernel"
+    return "scan_mfma8_hold_kernel" if batch > 64 and dim <= 384 else "scan_mfma8_kernel"
+
+
 def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, clustered=False, searcher=None, dim=384):
     """One single-GPU scan measurement: `steps` exact top-k searches of `batch` fresh queries over `rows`
     synthetic rows resident in HBM.  Returns the record that goes under `extra` (same fields as the headline)."""
@@ -154,7 +163,7 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
         launches += st["scan_launches"]
     ctx.synchronize()
     wall = time.perf_counter() - t0
-    kname = ("scan_mfma8_kernel" if searcher.last_stats()["screening_copy"] == 2 else "scan_mfma_kernel") if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel"
+    kname = scan_kernel_name(searcher.last_stats(), batch, dim)
     kernel_ms = float(np.sum(scan_ms)) / max(launches, 1)
     gbps = rows * dim * 4 / (kernel_ms * 1e-3) / 1e9
     copy = {0: None, 1: "bf16", 2: "int8"}[searcher.last_stats()["screening_copy"]]
@@ -394,7 +403,7 @@ def main():
         copy = {0: None, 1: "bf16", 2: "int8"}[searcher.last_stats()["screening_copy"]]
         streamed = float(np.mean(streamed_bytes)) / (mean_scan_ms * 1e-3) / 1e9  # what the scan kernel actually pulls from HBM
         ids, scores, counts = last
-        kname = ("scan_mfma8_kernel" if copy == "int8" else "scan_mfma_kernel") if searcher.last_stats()["kernel_used"] == 2 else "scan_wave_kernel"
+        kname = scan_kernel_name(searcher.last_stats(), B, args.dim)
         traffic, traffic_src = measured_traffic(kname, (hi - lo), args.dim, float(np.mean(streamed_bytes)) / max(1, hi - lo))
         out = {
             "metric": f"vectors scanned/sec (exact cosine top-{k}, {args.dim}-d f32, batch={B})",
