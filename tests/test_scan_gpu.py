@@ -1174,3 +1174,34 @@ def test_speculative_threshold_on_rows_sorted_by_similarity(ctx, oracle, metric,
         if order is m and k >= 10:  # (k = 2: no seed slot is a safe enough guess on 300 000 rows, none is made)
             assert st["speculation_reruns"] == 1, st
         s.close()
+
+
+@pytest.mark.parametrize("kind", ["gauss", "clustered", "heavy_tails", "duplicates"])
+def test_guess_on_and_off_give_the_same_hits(ctx, monkeypatch, kind):
+    # the speculative start threshold changes which rows are screened out early, never the answer: the same queries on
+    # the same rows with it (default) and without it (PCV_SCAN_FLAGS bit 5) — Gaussian rows, clusters, heavy-tailed
+    # features and a corpus of 50-fold duplicates, cosine and dot, 1..200 queries, k from 1 to 100
+    rng = np.random.default_rng({"gauss": 1, "clustered": 2, "heavy_tails": 3, "duplicates": 4}[kind])
+    n, d = 300_000, 96
+    if kind == "gauss":
+        m = rng.standard_normal((n, d)).astype(np.float32)
+    elif kind == "clustered":
+        c = rng.standard_normal((n // 5000, d)).astype(np.float32)
+        m = (c[rng.integers(0, len(c), n)] + 0.05 * rng.standard_normal((n, d))).astype(np.float32)
+    elif kind == "heavy_tails":
+        m = rng.standard_t(2.5, (n, d)).astype(np.float32)
+    else:
+        base = rng.standard_normal((n // 50, d)).astype(np.float32)
+        m = base[rng.integers(0, len(base), n)].copy()
+    shapes = ((1, 10), (7, 1), (64, 10), (128, 100), (64, 10), (64, 10), (200, 2))
+    queries = [(m[rng.integers(0, n, B)] + 0.3 * rng.standard_normal((B, d))).astype(np.float32) for B, _ in shapes]
+    for metric in ("cosine", "dot"):
+        hits = {}
+        for flags in ("0", "32"):
+            monkeypatch.setenv("PCV_SCAN_FLAGS", flags)
+            s = build(ctx, m, metric=metric, kernel="mfma")
+            hits[flags] = [s.search_vectors(None, k, q)[:2] for (B, k), q in zip(shapes, queries)]
+            s.close()
+        for (ia, sa), (ib, sb) in zip(hits["0"], hits["32"]):
+            np.testing.assert_array_equal(ia, ib)
+            np.testing.assert_array_equal(sa, sb)
