@@ -149,7 +149,8 @@ pcv_status pcv_searcher_get_rows(pcv_searcher* s, const int64_t* positions, int6
 
 /* Which scan kernel pcv_searcher_search uses. AUTO: wave-reduction kernel for n_queries <= 4,
  * MFMA tile kernel otherwise (up to 128 queries per corpus pass at dim <= 640; 256 with the int8 screening copy at
- * dim <= 384).  More queries than one pass takes are searched in several passes. */
+ * dim <= 384; among the ranks of a sharded search a pass is 128 queries on every rank, whatever copies each holds).
+ * More queries than one pass takes are searched in several passes. */
 enum { PCV_KERNEL_AUTO = 0, PCV_KERNEL_WAVE = 1, PCV_KERNEL_MFMA = 2 };
 pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel);
 

@@ -813,10 +813,12 @@ int pick_kernel(const pcv_searcher* s, int B) {
     return (B <= kMaxWaveQueries || !mfma_ok) ? PCV_KERNEL_WAVE : PCV_KERNEL_MFMA;
 }
 
-int pass_queries(const pcv_searcher* s, int kernel) {
+// `among_ranks`: the split must be the same on every rank of a sharded search, whatever copies each of them holds
+int pass_queries(const pcv_searcher* s, int kernel, bool among_ranks = false) {
     if (kernel == PCV_KERNEL_WAVE) return kMaxWaveQueries;
     // every row has its int8 copy: the int8 scan's pass (256 queries up to 384-d); else what the bf16 / f32-row scans take
-    if (s->copies_kind == 2 && s->Dp <= 1024) return std::min(kMfmaQueries, std::max(mfma8_pass_queries(s->Dp), mfma_pass_queries(s->Dp)));
+    if (!among_ranks && s->copies_kind == 2 && s->Dp <= 1024)
+        return std::min(kMfmaQueries, std::max(mfma8_pass_queries(s->Dp), mfma_pass_queries(s->Dp)));
     return mfma_pass_queries(s->Dp);
 }
 
@@ -883,7 +885,7 @@ void device_begin(pcv_searcher* s, const float* queries, int n_queries, const in
     const int kernel = pick_kernel(s, n_queries);
     // Only a condition every rank evaluates alike may refuse: the ranks of a sharded search must all
     // take the same protocol (the exchanged payload differs by the overflow record).
-    if (n_queries > pass_queries(s, kernel))
+    if (n_queries > pass_queries(s, kernel, true))
         PCV_FAIL(PCV_ERR_UNSUPPORTED, "search_device_begin: %d queries need more than one pass", n_queries);
     const size_t n = (size_t)n_queries * k;
     s->stats = pcv_scan_stats{};
@@ -1496,7 +1498,7 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
             launch_merge(st, c->d_gathered.p, c->world, (int)nq, k, c->d_merged.p, flagged);
             PCV_HIP(hipMemcpyAsync(c->pin_hits, c->d_merged.p, rec * sizeof(pcv_hit_dev), hipMemcpyDeviceToHost, st));
         };
-        const int qstep = pass_queries(s, pick_kernel(s, n_queries));  // every rank computes the same split
+        const int qstep = pass_queries(s, pick_kernel(s, n_queries), true);  // every rank computes the same split
         std::vector<pcv_hit_dev> all(n);
         pcv_scan_stats total{};
         auto accumulate = [&] {  // every attempt starts its own statistics (device_begin)

@@ -505,7 +505,7 @@ def test_begin_end_protocol_two_shards(ctx, oracle):
     np.testing.assert_allclose(scores, osc.astype(np.float32), atol=1e-7)
     assert attempts == 0 and (counts == k).all()
     # protocol errors: a second begin without end, an end without begin, more queries than one pass holds
-    d = ctx.alloc((300 * k + 1) * 24)
+    d = ctx.alloc((200 * k + 1) * 24)
     shards[0].search_device_begin(None, k, q, d)
     with pytest.raises(pa.PcvError):
         shards[0].search_device_begin(None, k, q, d)
@@ -513,7 +513,7 @@ def test_begin_end_protocol_two_shards(ctx, oracle):
     with pytest.raises(pa.PcvError):
         shards[0].search_device_end()
     with pytest.raises(pa.PcvError) as ei:
-        shards[0].search_device_begin(None, k, oracle.synth_rows(5, 0, 300, 384), d)  # (one pass: 256 queries at 384-d with int8 copies)
+        shards[0].search_device_begin(None, k, oracle.synth_rows(5, 0, 200, 384), d)  # (among ranks a pass is 128 queries, whatever copies a rank holds)
     assert ei.value.status == 3
     ctx.free(d)
     for s in shards:
