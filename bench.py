@@ -471,6 +471,10 @@ def main():
             es, ew = max(3, min(args.steps, 20)), max(1, min(args.warmup, 3))
             extra["config5_end_to_end"] = e2e_leg(pa, ctx, searcher, total_rows)
             searcher.set_kernel(args.kernel)
+            if copy == "int8" and args.dim <= 384:
+                # larger batches on the same corpus: the block-holding form of the int8 scan (128 queries; 256 in one pass)
+                for nq in (128, 256):
+                    extra[f"batch{nq}"] = scan_leg(pa, ctx, total_rows, nq, k, args.kernel, max(3, es // 2), ew, searcher=searcher)
             if copy is not None:
                 # the same corpus and queries' shape without the int8 copy: the scan streams the f32 rows themselves
                 # (1536 B/vector, the SURVEY §8d figure) or the bf16 copy; results are the same exact top-k
