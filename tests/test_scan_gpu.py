@@ -989,12 +989,14 @@ def test_int8_screen_on_rows_that_quantise_badly(ctx, oracle, D, metric):
     corpus = corpus[rng.permutation(corpus.shape[0])]
     queries = np.concatenate([q0[None, :], rng.standard_normal((5, D)).astype(np.float32), rng.standard_cauchy((3, D)).astype(np.float32),
                               np.eye(D, dtype=np.float32)[:2], corpus[:3]])
+    # the same queries, perturbed, as batches of 100 and 256: the block-holding forms of the int8 scan
+    many = (queries[np.arange(256) % len(queries)] * (1.0 + 0.05 * rng.standard_normal((256, D)))).astype(np.float32)
     for mode, code in (("int8", 2), ("bf16", 1), ("off", 0)):
         s = build(ctx, corpus, metric=metric, screen=mode, kernel="mfma")
-        for lo, hi in ((0, 1), (0, len(queries))):
-            ids, scores, counts = s.search_vectors(None, 10, queries[lo:hi])
+        for qs in (queries[:1], queries) + ((many[:100], many) if mode == "int8" else ()):
+            ids, scores, counts = s.search_vectors(None, 10, qs)
             assert s.last_stats()["screening_copy"] == code
-            opos, osc, _ = oracle.topk(queries[lo:hi], corpus, 10, metric=1 if metric == "dot" else 0)
+            opos, osc, _ = oracle.topk(qs, corpus, 10, metric=1 if metric == "dot" else 0)
             np.testing.assert_array_equal(ids, opos)
         s.close()
 
