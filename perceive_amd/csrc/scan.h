@@ -99,8 +99,12 @@ struct ScanParams {
     uint32_t seed_blocks;    // blocks of segment 0 ranked by the seed kernel: blocks i << seed_shift, i < seed_blocks — spread
     uint32_t seed_shift;     // over the whole segment, so that rows stored in an order that goes with their content (by topic, by
                              // date) still give a sample of all of it
-    uint32_t flags;          // bit 0: plain (temporal) corpus loads instead of nt; bit 4: every segment has its bf16 screening
-                             // copy, stream that; bit 6: every segment has its int8 screening copy, stream that; bits 8..15: workgroups per CU override; bits 16..23: seed workgroups; bits 24..27: chunk buffers override (tuning)
+    uint32_t flags;          // set by the searcher: bit 4: every segment has its bf16 screening copy, stream that; bit 6: every segment
+                             // has its int8 screening copy, stream that.  Tuning / comparison (PCV_SCAN_FLAGS at searcher creation):
+                             // bit 0: plain (temporal) corpus loads instead of nt; bit 1: 16 queries per seed workgroup (VALU seed);
+                             // bit 2: the VALU seed kernel; bit 3: the 128-query tile instead of the block-holding int8 scan;
+                             // bit 5: no speculative start threshold; bit 7: no learned part of it; bits 8..15: workgroups per CU;
+                             // bits 16..23: seed workgroups; bits 24..27: chunk buffers
     float eps16, eps32;      // |s - c| bounds of the bf16 / f32 screening scores, relative to |q||x|
     float max_norm;          // upper bound of |x| over the corpus (dot metric margins)
     // Speculative start threshold (MFMA scans; 0 = off).  The k slots the seed kernel fills are the best scores of k
