@@ -158,6 +158,15 @@ pcv_status pcv_searcher_set_kernel(pcv_searcher* s, int kernel);
  * lists).  A pass that needs more repeats itself with larger lists (pcv_scan_stats.overflow_reruns). */
 pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candidates);
 
+/* Diagnostic / comparison switches of one searcher; results never depend on them.  `flags` replaces what the
+ * environment variable PCV_SCAN_FLAGS gave the searcher at creation (bit meanings: csrc/scan.h, ScanParams::flags —
+ * bit 0 plain instead of non-temporal corpus loads, bit 3 the 128-query tile instead of the block-holding int8 scan,
+ * bit 5 no speculative start threshold, bit 7 no learned part of it, bits 8..15 workgroups per CU, ...), plus
+ *   PCV_TUNE_FAIL_COPY_ALLOC : while set, every allocation of a screening copy is treated as failed (how the tests
+ *                              reach the out-of-memory branches of pcv_searcher_finalize). */
+enum { PCV_TUNE_FAIL_COPY_ALLOC = 1073741824 }; /* bit 30 */
+pcv_status pcv_searcher_set_tuning(pcv_searcher* s, uint32_t flags);
+
 /* Screening copy: next to the f32 rows a segment can hold the same rows, already scaled, in a narrow form that
  * only the coarse screen reads; the f32 rows are then read for the rows that pass it (fine screen) and for the
  * finalists (exact ranking), so results are identical — the screens are certified bounds, not approximations.

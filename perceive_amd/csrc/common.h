@@ -38,6 +38,15 @@ struct Error {
         if (!(cond)) PCV_FAIL(PCV_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// Kernels that need more than 64 KB of dynamic LDS have to be allowed that once — per DEVICE (the runtime keeps one
+// function object per device) — before their first launch there.  One registry for the whole library, keyed by (current
+// device, kernel) under a mutex: two handles on two host threads may launch the same kernel for the first time at once, and
+// a process may hold contexts on several devices (pcv_init per device).  Raises the limit only when `bytes` is above what
+// this (device, kernel) already has; cheap otherwise.
+void allow_dynamic_lds(const void* kernel, size_t bytes);
+// compute units of the current device (cached per device)
+int current_device_cus();
+
 // Wrap a C-ABI entry point: nothing may escape as an exception.
 template <class F>
 static inline pcv_status guarded(F&& f) {

@@ -1,5 +1,7 @@
 // context.cpp — device context, error plumbing and the embedding blob codec of the C ABI.
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -17,6 +19,35 @@ void set_error(const char* fmt, ...) {
     g_last_error = buf;
 }
 const char* last_error() { return g_last_error.c_str(); }
+
+namespace {
+std::mutex g_attr_mu;
+std::map<std::pair<int, const void*>, size_t> g_lds_allowed;  // (device, kernel) -> dynamic LDS bytes allowed so far
+std::map<int, int> g_device_cus;
+}  // namespace
+
+void allow_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return;  // every kernel may have that much without asking
+    int dev = 0;
+    PCV_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    size_t& have = g_lds_allowed[{dev, kernel}];
+    if (bytes <= have) return;
+    PCV_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+}
+
+int current_device_cus() {
+    int dev = 0;
+    PCV_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    int& n = g_device_cus[dev];
+    if (n <= 0) {
+        PCV_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
 
 }  // namespace pcv
 

@@ -1770,11 +1770,7 @@ bool launch_gemm_f32_ln(hipStream_t st, const float* A, const float* W, const fl
     const size_t lds = (size_t)(LBM + N) * LDT * sizeof(float);
     const dim3 grid((M + LBM - 1) / LBM);
     if (N == 384) {  // persistent eight-wave form: 1 % of a 256 x 256 forward over the four-wave one
-        static bool allowed8 = false;  // 64.5 KB of dynamic LDS
-        if (!allowed8) {
-            PCV_HIP(hipFuncSetAttribute((const void*)gemm_f32_ln8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            allowed8 = true;
-        }
+        allow_dynamic_lds((const void*)gemm_f32_ln8_kernel<3>, lds);  // 64.5 KB of dynamic LDS
         const int resident = 2 * 256;  // two workgroups per CU
         gemm_f32_ln8_kernel<3><<<dim3(std::min<int>(grid.x, resident)), 512, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
         return true;
@@ -1812,17 +1808,8 @@ void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float
 template <int EPI>
 static void launch_gemm_bf16x3_ws(hipStream_t st, const float* A, const uint16_t* Wh, const uint16_t* Wm,
                                   const uint16_t* Wl, const float* bias, const float* resid, float* C, int M, int N, int K) {
-    static bool configured = false;  // > 64 KB of dynamic LDS has to be allowed once per kernel
-    static int num_cus = 0;
-    if (!configured) {
-        PCV_HIP(hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)kGemmWsLdsBytes));
-        int dev = 0;
-        PCV_HIP(hipGetDevice(&dev));
-        PCV_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (num_cus <= 0) num_cus = 256;
-        configured = true;
-    }
+    allow_dynamic_lds((const void*)gemm_bf16x3_ws_kernel<EPI>, kGemmWsLdsBytes);
+    const int num_cus = current_device_cus();
     const unsigned ntiles = (unsigned)(N / BN) * (unsigned)((M + BM - 1) / BM);
     const unsigned grid = ntiles < (unsigned)num_cus ? ntiles : (unsigned)num_cus;  // one workgroup per CU (120 KB of LDS each)
     gemm_bf16x3_ws_kernel<EPI><<<grid, 512, kGemmWsLdsBytes, st>>>(A, Wh, Wm, Wl, bias, resid, C, M, N, K);
@@ -1914,11 +1901,7 @@ void launch_layer_norm(hipStream_t st, float* x, int T, int H, const float* w, c
 template <int HD, int NW, int TPC>
 static void launch_attention_f16_v(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int Lp, int H,
                                    int heads, size_t lds) {
-    static size_t allowed = 64 * 1024;  // per instantiation: dynamic LDS beyond 64 KB has to be allowed (static LDS comes on top)
-    if (lds > allowed) {
-        PCV_HIP(hipFuncSetAttribute((const void*)attention_f16_kernel<HD, NW, TPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        allowed = lds;
-    }
+    allow_dynamic_lds((const void*)attention_f16_kernel<HD, NW, TPC>, lds);  // (static LDS comes on top)
     dim3 grid((Lp / 32 + NW - 1) / NW, heads, B);
     attention_f16_kernel<HD, NW, TPC><<<grid, NW * 64, lds, st>>>(qkv, mask_add, ctx, B, L, Lp, H);
 }
@@ -1947,11 +1930,7 @@ bool launch_attention_f16(hipStream_t st, const float* qkv, const float* mask_ad
 template <int HD, int NW, int TPC>
 static void launch_attention_staged(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int Lp,
                                     int H, int heads, size_t lds) {
-    static size_t allowed = 64 * 1024;
-    if (lds > allowed) {
-        PCV_HIP(hipFuncSetAttribute((const void*)attention_kernel<HD, true, NW, TPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        allowed = lds;
-    }
+    allow_dynamic_lds((const void*)attention_kernel<HD, true, NW, TPC>, lds);
     dim3 grid((Lp / 32 + NW - 1) / NW, heads, B);
     attention_kernel<HD, true, NW, TPC><<<grid, NW * 64, lds, st>>>(qkv, mask_add, ctx, B, L, Lp, H);
 }

@@ -1949,11 +1949,7 @@ void launch_prep_seed(hipStream_t st, const ScanParams& p, const ScanParams* dp,
     const size_t lds1 = Dp * sizeof(float) + kMaxK * sizeof(uint32_t);
     const size_t lds_mfma = 32 * (Dp + 4) * sizeof(float) + 32 * (size_t)p.k * sizeof(uint32_t);
     if (lds_mfma <= 156 * 1024 && !(p.flags & 4)) {  // flag bit 2: the VALU form (tuning / comparison)
-        static size_t lds_allowed = 64 * 1024;
-        if (lds_mfma > lds_allowed) {
-            PCV_HIP(hipFuncSetAttribute((const void*)prep_seed_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
-            lds_allowed = lds_mfma;
-        }
+        allow_dynamic_lds((const void*)prep_seed_mfma_kernel, lds_mfma);
         const unsigned parts = (p.seed_blocks + 3) / 4;
         prep_seed_mfma_kernel<<<dim3(parts ? parts : 1, (p.B + 31) / 32), 256, lds_mfma, st>>>(dp, seg0.blk, seg0.scale, nseed);
     } else if (p.B <= 2 || 8 * lds1 > 64 * 1024) {  // few queries, or very wide rows: one query per workgroup
@@ -1974,20 +1970,10 @@ void launch_scan_wave(hipStream_t st, const ScanParams& p, const ScanParams* dp,
     const unsigned need = (p.total_blocks + 3) / 4;
     if (grid > need) grid = need;
     const bool ntl = (p.flags & 1) == 0;  // non-temporal corpus loads unless flag bit 0 is set
-    if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_wave_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-    }
+    for (const void* f : {(const void*)scan_wave_kernel<1, true>, (const void*)scan_wave_kernel<2, true>, (const void*)scan_wave_kernel<3, true>,
+                          (const void*)scan_wave_kernel<4, true>, (const void*)scan_wave_kernel<1, false>, (const void*)scan_wave_kernel<2, false>,
+                          (const void*)scan_wave_kernel<3, false>, (const void*)scan_wave_kernel<4, false>})
+        allow_dynamic_lds(f, lds);
 #define PCV_WAVE(NB)                                                   \
     if (ntl)                                                           \
         scan_wave_kernel<NB, true><<<grid, 256, lds, st>>>(dp);         \
@@ -2015,12 +2001,7 @@ uint32_t mfma_tile_rows(int B) { return B <= 32 ? 32u : (B <= 64 ? 64u : 128u); 
 
 template <int NT, bool NTL, int WPB, int NBUF, bool SRC16>
 static void launch_mfma_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
-    static size_t lds_allowed = 64 * 1024;  // one per instantiation; the static LDS of the kernel comes on top
-    if (lds > lds_allowed) {
-        PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma_kernel<NT, NTL, WPB, NBUF, SRC16>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_allowed = lds;
-    }
+    allow_dynamic_lds((const void*)scan_mfma_kernel<NT, NTL, WPB, NBUF, SRC16>, lds);  // (the static LDS of the kernel comes on top)
     scan_mfma_kernel<NT, NTL, WPB, NBUF, SRC16><<<grid, WPB * 64, lds, st>>>(dp);
 }
 
@@ -2088,11 +2069,7 @@ int mfma8_pass_queries(int Dp) {
 
 template <int NT, bool NTL, int NBUF = (NT == 2 ? 3 : 4)>  // 64 queries: three chunk buffers leave the registers the block pre-test needs
 static void launch_mfma8_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
-    static size_t lds_allowed = 64 * 1024;
-    if (lds > lds_allowed) {
-        PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_kernel<NT, NTL, 4, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_allowed = lds;
-    }
+    allow_dynamic_lds((const void*)scan_mfma8_kernel<NT, NTL, 4, NBUF>, lds);
     scan_mfma8_kernel<NT, NTL, 4, NBUF><<<grid, 256, lds, st>>>(dp);
 }
 
@@ -2116,17 +2093,9 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
         const unsigned wpb = four ? 12 : 4;
         const unsigned g3 = std::min<unsigned>((unsigned)num_cus * (gm ? gm : (four ? 1u : 3u)), (p.total_blocks + wpb - 1) / wpb);
         const size_t ldsh = mfma8_lds(four ? 8 : 4, p.D4 * 4);
-        static bool allowed = false;
-        if (!allowed) {
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_hold_kernel<true, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(4, 384)));
-            PCV_HIP(hipFuncSetAttribute((const void*)scan_mfma8_hold_kernel<false, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(4, 384)));
-            for (const void* f : {(const void*)scan_mfma8_hold_kernel<true, 3, 4>, (const void*)scan_mfma8_hold_kernel<false, 3, 4>,
-                                  (const void*)scan_mfma8_hold_kernel<true, 2, 4>, (const void*)scan_mfma8_hold_kernel<false, 2, 4>})
-                PCV_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma8_lds(8, 384)));
-            allowed = true;
-        }
 #define PCV_HOLD(NCHV, NHV)                                                                           \
     {                                                                                                 \
+        allow_dynamic_lds(ntl ? (const void*)scan_mfma8_hold_kernel<true, NCHV, NHV> : (const void*)scan_mfma8_hold_kernel<false, NCHV, NHV>, ldsh); \
         if (ntl) scan_mfma8_hold_kernel<true, NCHV, NHV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp); \
         else scan_mfma8_hold_kernel<false, NCHV, NHV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp);    \
     }
@@ -2173,11 +2142,7 @@ void launch_coarse_pack(hipStream_t st, const float4* blk, const float* scale, u
 void launch_rescore_select(hipStream_t st, const ScanParams& p, const ScanParams* dp) {
     if (p.D4 <= kCoopMaxD4) {
         const size_t lds = ((size_t)p.D4 + 4 * 8 * ((size_t)p.D4 + 1)) * sizeof(float4);
-        static bool attr_set = false;
-        if (!attr_set) {  // static LDS (28 KB) + dynamic may pass 64 KB
-            PCV_HIP(hipFuncSetAttribute((const void*)rescore_select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-            attr_set = true;
-        }
+        allow_dynamic_lds((const void*)rescore_select_kernel<true>, 100 * 1024);  // static LDS (28 KB) + dynamic may pass 64 KB
         rescore_select_kernel<true><<<p.B, 256, lds, st>>>(dp);
     } else {
         const size_t lds = (size_t)p.D4 * sizeof(float4);

@@ -158,7 +158,8 @@ struct pcv_searcher {
     Pinned* pin = nullptr;
     bool state_clean = false;  // tau / slots / counters are in the state a pass starts from
     uint32_t cand_cap = 8192;
-    uint32_t scan_flags = 0;  // tuning knobs, PCV_SCAN_FLAGS
+    uint32_t scan_flags = 0;  // tuning knobs: PCV_SCAN_FLAGS at creation, pcv_searcher_set_tuning
+    bool fail_copy_alloc = false;  // PCV_TUNE_FAIL_COPY_ALLOC
     int screen_copy = PCV_SCREEN_COPY_AUTO;  // pcv_searcher_set_screening_copy
     bool screen_copy_gave_way = false;       // AUTO: the copies were dropped to make room for rows
     int copies_kind = 0;                     // 0: not every row of every segment is covered by a screening copy; 1 bf16; 2 int8
@@ -382,9 +383,8 @@ void build_screening_copies(pcv_searcher* s, Source& src) {
             g.copied_rows = 0;
             const size_t nblk = g.cap_rows / kBlockRows;
             const size_t bytes = kind == 1 ? nblk * (s->D4 / 2) * 32 * sizeof(uint4) : nblk * (size_t)(((s->Dp + 127) & ~127) / 16) * 32 * sizeof(uint4);
-            // (PCV_TEST_FAIL_COPY_ALLOC: the tests' way to reach the out-of-memory branch)
-            hipError_t e = getenv("PCV_TEST_FAIL_COPY_ALLOC") ? hipErrorOutOfMemory
-                                                              : hipMalloc(kind == 1 ? (void**)&g.blk16 : (void**)&g.blk8, bytes);
+            hipError_t e = s->fail_copy_alloc ? hipErrorOutOfMemory  // (PCV_TUNE_FAIL_COPY_ALLOC)
+                                              : hipMalloc(kind == 1 ? (void**)&g.blk16 : (void**)&g.blk8, bytes);
             if (e == hipSuccess && kind == 2) {
                 e = hipMalloc((void**)&g.scale8, (size_t)(g.cap_rows / kBlockRows) * kScale8Stride * sizeof(float));
                 if (e != hipSuccess) {
@@ -1217,6 +1217,16 @@ pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candi
     });
 }
 
+pcv_status pcv_searcher_set_tuning(pcv_searcher* s, uint32_t flags) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "set_tuning: searcher is NULL");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->pending.active, "set_tuning: a queued pass has not been collected");
+        s->fail_copy_alloc = (flags & (uint32_t)PCV_TUNE_FAIL_COPY_ALLOC) != 0;
+        s->scan_flags = flags & 0x0fffffffu;
+    });
+}
+
 pcv_status pcv_searcher_set_shard_offset(pcv_searcher* s, int64_t first_global_pos) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr, "set_shard_offset: searcher is NULL");
@@ -1377,9 +1387,8 @@ struct Rccl {
 };
 Rccl& rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;  // first use may come from two contexts' threads at once
+    std::call_once(once, [] {
         // RCCL must sit on the HIP runtime this library is bound to.  A process may hold a second
         // runtime + RCCL pair (PyTorch bundles its own, with the same sonames), so RCCL is looked up by
         // path next to our libamdhip64 first and by soname only after that.
@@ -1404,7 +1413,7 @@ Rccl& rccl() {
             r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
             r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy;
         }
-    }
+    });
     return r;
 }
 void rccl_check(int rc, const char* what) {

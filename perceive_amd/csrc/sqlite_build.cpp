@@ -6,6 +6,8 @@
 // every system that has Python; its header is not needed: the handful of prototypes used are declared here).
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include <cstring>
 #include <map>
 #include <memory>
@@ -35,9 +37,8 @@ struct Sqlite {
 
 Sqlite& sqlite() {
     static Sqlite q;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;  // first use may come from two searchers on two threads
+    std::call_once(once, [] {
         void* h = nullptr;
         for (const char* name : {"libsqlite3.so.0", "libsqlite3.so"})
             if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
@@ -58,7 +59,7 @@ Sqlite& sqlite() {
             q.ok = q.open_v2 && q.close && q.prepare_v2 && q.bind_int64 && q.step && q.column_int64 && q.column_blob &&
                    q.column_bytes && q.column_type && q.finalize && q.errmsg;
         }
-    }
+    });
     return q;
 }
 

@@ -368,10 +368,15 @@ void read_safetensors(const std::string& path, const WantFn& want, const TensorF
         out.dtype_name = dtype;
         out.shape.clear();
         out.numel = 1;
-        for (const JVal& d : shape->a) {
+        for (const JVal& d : shape->a) {  // JSON numbers are doubles: whole, in range, and every product checked
+            if (d.t != JVal::Num || !(d.n >= 0.0) || d.n > 1099511627776.0 /* 2^40 */ || d.n != std::floor(d.n) ||
+                __builtin_mul_overflow(out.numel, (int64_t)d.n, &out.numel) || out.numel > (int64_t)1 << 40)
+                PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has an implausible shape", path.c_str(), kv.first.c_str());
             out.shape.push_back((int64_t)d.n);
-            out.numel *= (int64_t)d.n;
         }
+        for (const JVal& o : offs->a)
+            if (o.t != JVal::Num || !(o.n >= 0.0) || o.n > 9007199254740992.0 /* 2^53 */ || o.n != std::floor(o.n))
+                PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has inconsistent offsets", path.c_str(), kv.first.c_str());
         const uint64_t a = (uint64_t)offs->a[0].n, b = (uint64_t)offs->a[1].n;
         const uint64_t esize = dtype == "F32" ? 4 : (dtype == "F16" || dtype == "BF16") ? 2 : dtype == "F64" ? 8 : 0;
         out.dtype = dtype == "F32" ? AR_F32 : dtype == "F16" ? AR_F16 : dtype == "BF16" ? AR_BF16 : dtype == "F64" ? AR_F64 : AR_OTHER;

@@ -455,27 +455,34 @@ void read_torch_archive(const std::string& path, const std::function<bool(const 
         out.dtype_name = st.s2;
         out.shape = val->shape;
         out.numel = 1;
-        for (int64_t d : val->shape) {
-            if (d < 0 || (d > 0 && out.numel > (int64_t)1 << 40)) PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has an implausible shape", path.c_str(), key->s.c_str());
-            out.numel *= d;
+        for (int64_t d : val->shape) {  // (values straight out of the pickle: every product is checked)
+            if (d < 0 || d > (int64_t)1 << 40 || __builtin_mul_overflow(out.numel, d, &out.numel) || out.numel > (int64_t)1 << 40)
+                PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has an implausible shape", path.c_str(), key->s.c_str());
         }
+        if (val->stride.size() != val->shape.size()) PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has %zu strides for %zu dimensions", path.c_str(), key->s.c_str(), val->stride.size(), val->shape.size());
         out.values.clear();
         if (sk.dtype != AR_OTHER && out.numel > 0) {
             auto e = dir.find(root + "data/" + st.s);
             if (e == dir.end()) PCV_FAIL(PCV_ERR_IO, "%s: storage %s of tensor %s is missing", path.c_str(), st.s.c_str(), key->s.c_str());
             if (!e->second.stored) PCV_FAIL(PCV_ERR_UNSUPPORTED, "%s: storage %s is compressed; libtorch stores tensors uncompressed", path.c_str(), st.s.c_str());
             const int64_t avail = (int64_t)(e->second.size / (uint64_t)sk.esize);
-            // furthest element the view touches
+            // A weight is a view INTO its storage: no more elements than the storage holds (a broadcast view — stride 0
+            // over a long dimension — would have this reader allocate what the file never contained), offset and every
+            // stride inside it, and the furthest element the view touches — summed with overflow checks — as well.
+            if (out.numel > avail) PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has more elements than its storage", path.c_str(), key->s.c_str());
+            if (val->offset < 0 || val->offset >= avail) PCV_FAIL(PCV_ERR_IO, "%s: tensor %s starts outside its storage", path.c_str(), key->s.c_str());
             int64_t last = val->offset;
             bool contiguous = true;
             int64_t expect = 1;
             for (size_t d = val->shape.size(); d-- > 0;) {
-                if (val->stride[d] < 0 || val->offset < 0) PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has a negative stride or offset", path.c_str(), key->s.c_str());
-                last += (val->shape[d] - 1) * val->stride[d];
-                if (val->shape[d] != 1 && val->stride[d] != expect) contiguous = false;
-                expect *= val->shape[d];
+                const int64_t st_d = val->stride[d], n_d = val->shape[d];  // n_d >= 1: numel > 0
+                if (st_d < 0 || st_d > avail) PCV_FAIL(PCV_ERR_IO, "%s: tensor %s has a stride outside its storage", path.c_str(), key->s.c_str());
+                int64_t reach = 0;
+                if (__builtin_mul_overflow(n_d - 1, st_d, &reach) || __builtin_add_overflow(last, reach, &last) || last >= avail)
+                    PCV_FAIL(PCV_ERR_IO, "%s: tensor %s reaches past its storage", path.c_str(), key->s.c_str());
+                if (n_d != 1 && st_d != expect) contiguous = false;
+                expect *= n_d;  // <= numel
             }
-            if (last >= avail) PCV_FAIL(PCV_ERR_IO, "%s: tensor %s reaches past its storage", path.c_str(), key->s.c_str());
             out.values.resize((size_t)out.numel);
             const uint8_t* base = e->second.data;
             if (contiguous) {

@@ -224,6 +224,11 @@ class Searcher:
         """Initial rows per query of a pass's candidate lists (tuning; a pass that needs more repeats itself)."""
         _ffi.check(_ffi.lib().pcv_searcher_set_candidate_capacity(self._handle, int(n_candidates)))
 
+    def set_tuning(self, flags=0, fail_copy_alloc=False):
+        """Diagnostic / comparison switches (pcv_searcher_set_tuning): `flags` as PCV_SCAN_FLAGS (csrc/scan.h), e.g. 32 = no
+        speculative start threshold; fail_copy_alloc: screening-copy allocations fail while set (tests)."""
+        _ffi.check(_ffi.lib().pcv_searcher_set_tuning(self._handle, (int(flags) & 0x0FFFFFFF) | ((1 << 30) if fail_copy_alloc else 0)))
+
     def set_screening_copy(self, mode="auto"):
         """"off" | "bf16" | "int8" | "auto" (= int8): keep a narrow copy of the scaled rows next to the f32 rows so that
         the coarse screen streams a half / a quarter of the bytes (pcv_searcher_set_screening_copy); built at the next

@@ -101,6 +101,7 @@ pub const PCV_METRIC_DOT: c_int = 1;
 pub const PCV_KERNEL_AUTO: c_int = 0;
 pub const PCV_KERNEL_WAVE: c_int = 1;
 pub const PCV_KERNEL_MFMA: c_int = 2;
+pub const PCV_TUNE_FAIL_COPY_ALLOC: c_int = 1073741824;
 pub const PCV_SCREEN_COPY_OFF: c_int = 0;
 pub const PCV_SCREEN_COPY_BF16: c_int = 1;
 pub const PCV_SCREEN_COPY_AUTO: c_int = 2;
@@ -159,6 +160,7 @@ extern "C" {
     pub fn pcv_searcher_get_rows(s: *mut pcv_searcher, positions: *const i64, n: i64, out_rows: *mut f32, out_ids: *mut i64) -> c_int;
     pub fn pcv_searcher_set_kernel(s: *mut pcv_searcher, kernel: c_int) -> c_int;
     pub fn pcv_searcher_set_candidate_capacity(s: *mut pcv_searcher, n_candidates: u32) -> c_int;
+    pub fn pcv_searcher_set_tuning(s: *mut pcv_searcher, flags: u32) -> c_int;
     pub fn pcv_searcher_set_screening_copy(s: *mut pcv_searcher, mode: c_int) -> c_int;
     pub fn pcv_searcher_search(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;
     pub fn pcv_searcher_set_shard_offset(s: *mut pcv_searcher, first_global_pos: i64) -> c_int;

@@ -105,6 +105,56 @@ def test_archive_reader_refuses_what_it_does_not_know(tmp_path, ot_dir):
         pa.checkpoint_tensors(tmp_path / "does-not-exist.ot")
 
 
+def _patched_state_dict(tmp_path, name, size, stride):
+    """torch.save of {"w": 16 f32} with the (size, stride) tuples of its view record — pickled `K\x10\x85 q<memo> K\x01\x85` —
+    replaced by the given pickle bytes (views no tensor API would make)."""
+    import re
+
+    import torch
+
+    torch.save({"w": torch.arange(16, dtype=torch.float32)}, tmp_path / "plain.bin")
+    with zipfile.ZipFile(tmp_path / "plain.bin") as src, zipfile.ZipFile(tmp_path / name, "w", zipfile.ZIP_STORED) as dst:
+        for info in src.infolist():
+            data = src.read(info.filename)
+            if info.filename.endswith("data.pkl"):
+                pat = re.compile(rb"K\x10\x85(q.)K\x01\x85", re.S)
+                assert len(pat.findall(data)) == 1, data
+                data = pat.sub(lambda m: size + m.group(1) + stride, data)
+            dst.writestr(info.filename, data)
+    return tmp_path / name
+
+
+def test_archive_reader_refuses_views_that_leave_their_storage(tmp_path):
+    """Shapes, strides and offsets come straight out of the pickle / the JSON header: sums and products that wrap around
+    int64 (stride 2^62 + 2^24 over three elements wraps `last` negative and walked far outside the mapping),
+    broadcast views that would allocate what the file never held, and safetensors shapes that are not whole numbers."""
+    tup1 = lambda v: (b"K" + bytes([v]) if 0 <= v < 256 else b"\x8a\x08" + int(v).to_bytes(8, "little", signed=True)) + b"\x85"
+    assert pa.checkpoint_tensors(_patched_state_dict(tmp_path, "same.bin", tup1(16), tup1(1)))["w"].tolist() == list(range(16))
+    assert pa.checkpoint_tensors(_patched_state_dict(tmp_path, "strided.bin", tup1(4), tup1(5)))["w"].tolist() == [0, 5, 10, 15]
+    for name, size, stride in [("wrap.bin", 3, 2**62 + 2**24),  # `last` wraps negative
+                               ("bcast.bin", 2**40, 0),         # 4 TB of values out of 64 bytes
+                               ("huge.bin", 2**62, 0),
+                               ("past.bin", 2, 16),             # second element is one past the end
+                               ("neg.bin", 4, -1)]:
+        with pytest.raises(pa.ModelError):
+            pa.checkpoint_tensors(_patched_state_dict(tmp_path, name, tup1(size), tup1(stride)))
+    # safetensors: header numbers are JSON doubles
+    import json
+    import struct
+
+    def st_file(name, shape, offsets, nbytes=64):
+        hdr = json.dumps({"w": {"dtype": "F32", "shape": shape, "data_offsets": offsets}}).encode()
+        (tmp_path / name).write_bytes(struct.pack("<Q", len(hdr)) + hdr + b"\0" * nbytes)
+        return tmp_path / name
+
+    assert pa.checkpoint_tensors(st_file("ok.safetensors", [4, 4], [0, 64]))["w"].shape == (4, 4)
+    for name, shape, offs in [("frac.safetensors", [2.5, 4], [0, 40]), ("neg.safetensors", [-1, 4], [0, 64]),
+                              ("wrap.safetensors", [2**31, 2**31, 4], [0, 64]), ("big.safetensors", [1e300], [0, 64]),
+                              ("offs.safetensors", [16], [1e300, 64]), ("past.safetensors", [32], [0, 128])]:
+        with pytest.raises(pa.ModelError):
+            pa.checkpoint_tensors(st_file(name, shape, offs))
+
+
 @pytest.mark.gpu
 def test_new_pretrained_from_rust_model_ot(ctx, ot_dir, expected):
     """The reference's layout end to end: JSON configs + vocab.txt + rust_model.ot (+ 2_Dense/rust_model.ot) -> text in,

@@ -1033,12 +1033,12 @@ def test_screening_copy_gives_way_when_memory_is_short(ctx, oracle, monkeypatch)
     s.finalize()
     np.testing.assert_array_equal(s.search_vectors(None, 10, q)[0], oracle.topk(q, m[:2000], 10)[0])
     assert s.last_stats()["screening_copy"] == 2
-    monkeypatch.setenv("PCV_TEST_FAIL_COPY_ALLOC", "1")
+    s.set_tuning(fail_copy_alloc=True)
     s.add_rows(2, m[2000:], 2000 + np.arange(1000))  # a second source = a new segment, whose copy cannot be allocated
     s.finalize()
     np.testing.assert_array_equal(s.search_vectors(None, 10, q)[0], ref)
     assert s.last_stats()["screening_copy"] == 0 and s.last_stats()["kernel_used"] == 2  # every copy was given back
-    monkeypatch.delenv("PCV_TEST_FAIL_COPY_ALLOC")
+    s.set_tuning()
     s.finalize()  # still off for this searcher: it gave way for good
     np.testing.assert_array_equal(s.search_vectors(None, 10, q)[0], ref)
     assert s.last_stats()["screening_copy"] == 0
@@ -1047,8 +1047,8 @@ def test_screening_copy_gives_way_when_memory_is_short(ctx, oracle, monkeypatch)
     np.testing.assert_array_equal(s.search_vectors(None, 10, q)[0], ref)
     assert s.last_stats()["screening_copy"] == 2
     s.close()
-    monkeypatch.setenv("PCV_TEST_FAIL_COPY_ALLOC", "1")
     e = pa.Searcher(ctx, 128, "cosine")
+    e.set_tuning(fail_copy_alloc=True)
     e.set_screening_copy("int8")
     e.add_rows(1, m)
     with pytest.raises(pa.PcvError):
