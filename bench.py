@@ -125,19 +125,40 @@ def scan_kernel_name(stats, batch, dim):
         return "scan_wave_kernel"
     if stats["screening_copy"] != 2:
         return "scan_mfma_kernel"
-    return "scan_mfma8_hold_kernel" if batch > 64 and dim <= 384 else "scan_mfma8_kernel"
+    return "scan_mfma8_hold_kernel" if batch > 64 and (dim + 127) // 128 * 128 <= HOLD_MAX_DIM else "scan_mfma8_kernel"
 
 
-def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, clustered=False, searcher=None, dim=384):
+HOLD_MAX_DIM = 384  # widest rows the block-holding int8 scan takes (csrc/scan_kernels.hip: launch_scan_mfma8)
+
+
+def roofline_of(st, launches, kernel_ms, rows, dim):
+    """Roofline record of one scan leg.  `achieved` = the bytes the selected scan kernel HAS TO move per launch (the
+    library's pcv_scan_stats.bytes_streamed: int8 copy + scales, or bf16 copy, or f32 rows + scales) / its hipEvent time;
+    `frac` = that / 8 TB/s, <= 1 by construction.  The N*D*4-equivalent rate of the reference formulation (one
+    f32 pass, which a scan over a narrow copy does not make) is kept under its own name and is not a fraction of anything."""
+    per_launch = st["bytes_streamed"] / max(launches, 1)
+    achieved = per_launch / (kernel_ms * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        "bytes_per_launch": per_launch, "kernel_ms": kernel_ms,
+        "effective_f32_pass_GBps": rows * dim * 4 / (kernel_ms * 1e-3) / 1e9,
+    }
+
+
+def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, clustered=False, searcher=None, dim=384, metric="cosine",
+             amplitude=None, tuning=0, keep=False):
     """One single-GPU scan measurement: `steps` exact top-k searches of `batch` fresh queries over `rows`
     synthetic rows resident in HBM.  Returns the record that goes under `extra` (same fields as the headline)."""
     own = searcher is None
     if own:
-        searcher = pa.Searcher(ctx, dim, "cosine")
+        searcher = pa.Searcher(ctx, dim, metric)
         ncl = max(1, rows // CLUSTER_ROWS) if clustered else 0
-        searcher.add_synthetic(1, rows, seed, n_clusters=ncl, noise=CLUSTER_NOISE if clustered else 0.0)
+        searcher.add_synthetic(1, rows, seed, n_clusters=ncl, noise=CLUSTER_NOISE if clustered else 0.0, amplitude=amplitude)
         searcher.finalize()
     searcher.set_kernel(kernel)
+    env_flags = int(os.environ.get("PCV_SCAN_FLAGS", "0"), 0)
+    if tuning:
+        searcher.set_tuning(env_flags | tuning)
     rng = np.random.default_rng(seed + 17)
     if clustered:
         # queries = unseen members of the corpus' clusters (the oracle's twin generator is test infrastructure;
@@ -150,7 +171,7 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
     for i in range(warmup):
         searcher.search_vectors(None, k, queries[i])
     ctx.synchronize()
-    scan_ms, pass_ms, cands, reruns, launches, spec_reruns = [], [], [], 0, 0, 0
+    scan_ms, pass_ms, cands, coarse, reruns, launches, spec_reruns, streamed = [], [], [], [], 0, 0, 0, 0
     t0 = time.perf_counter()
     for i in range(steps):
         searcher.search_vectors(None, k, queries[warmup + i])
@@ -158,36 +179,46 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
         scan_ms.append(st["scan_ms"])
         pass_ms.append(st["total_ms"])
         cands.append(st["candidates"])
+        coarse.append(st["coarse_survivors"])
         reruns += st["overflow_reruns"]
         spec_reruns += st["speculation_reruns"]
         launches += st["scan_launches"]
+        streamed += st["bytes_streamed"]
     ctx.synchronize()
     wall = time.perf_counter() - t0
-    kname = scan_kernel_name(searcher.last_stats(), batch, dim)
+    st = searcher.last_stats()
+    kname = scan_kernel_name(st, batch, dim)
     kernel_ms = float(np.sum(scan_ms)) / max(launches, 1)
-    gbps = rows * dim * 4 / (kernel_ms * 1e-3) / 1e9
-    copy = {0: None, 1: "bf16", 2: "int8"}[searcher.last_stats()["screening_copy"]]
-    streamed_gbps = gbps / {None: 1, "bf16": 2, "int8": 4}[copy]  # bytes per feature of what the scan streams: 4, 2, 1
+    copy = {0: None, 1: "bf16", 2: "int8"}[st["screening_copy"]]
     rec = {
-        "workload": f"{rows} x {dim} f32 synthetic" + (" clustered" if clustered else "") + f" corpus, batch={batch}, top-{k}, 1 MI355X",
-        "kernel": kname, "ms_per_step": 1e3 * wall / steps, "kernel_ms": kernel_ms,
+        "workload": f"{rows} x {dim} f32 synthetic" + (" clustered" if clustered else "") +
+                    (f" rows x U[{amplitude[0]},{amplitude[1]})" if amplitude else "") + f" corpus, {metric}, batch={batch}, top-{k}, 1 MI355X",
+        "kernel": kname, "screening_copy": copy, "ms_per_step": 1e3 * wall / steps, "kernel_ms": kernel_ms,
         "pass_ms": float(np.sum(pass_ms)) / max(launches, 1),
         "fixed_cost_us": 1e3 * (float(np.sum(pass_ms)) - float(np.sum(scan_ms))) / max(launches, 1),
-        "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS, "screening_copy": copy,
-        "streamed_GBps": streamed_gbps, "streamed_frac_of_8TBps": streamed_gbps / HBM_PEAK_GBPS,
+        "roofline": roofline_of({"bytes_streamed": streamed}, launches, kernel_ms, rows, dim),
         "vectors_per_s": rows * steps / wall, "queries_per_s": batch * steps / wall,
-        "candidates_per_query": float(np.mean(cands)) / batch, "overflow_reruns": reruns, "speculation_reruns": spec_reruns,
-        "steps": steps,
+        "candidates_per_query": float(np.mean(cands)) / batch, "coarse_survivors_per_query": float(np.mean(coarse)) / batch,
+        "overflow_reruns": reruns, "speculation_reruns": spec_reruns, "steps": steps,
     }
-    if own:
+    if tuning:
+        searcher.set_tuning(env_flags)
+    if own and not keep:
         searcher.close()
         settle(rows * (dim * 4 + dim + 8))
-    return rec
+    return (rec, searcher) if keep else rec
 
 
-def encoder_leg(pa, ctx, compute, steps=5, warmup=2, batch=256, seq=256):
-    """BASELINE configs[4]'s encoder: all-MiniLM-L6-v2 shape, 256 documents x 256 tokens, seeded synthetic weights."""
-    m = pa.Model(ctx, pa.minilm_l6_desc(compute), synthetic_seed=1)
+def encoder_leg(pa, ctx, compute, steps=5, warmup=2, batch=256, seq=256, shape="minilm_l6"):
+    """BASELINE configs[4]'s encoder (all-MiniLM-L6-v2 shape, 256 documents x 256 tokens), or the shape of the reference's
+    default model (MsMarcoBertBaseDotV5 = BERT-base: 12 x 768, 12 heads x 64, FFN 3072; pipeline.rs:76 batches 64 documents);
+    seeded synthetic weights."""
+    if shape == "minilm_l6":
+        desc, label = pa.minilm_l6_desc(compute), "all-MiniLM-L6-v2 shape"
+    else:
+        desc = pa.make_desc(30522, 768, 12, 12, 3072, 512, pooling="cls", normalize=False, compute=compute)
+        label = "BERT-base shape (msmarco-bert-base-dot-v5: 12 x 768, cls pooling, not normalised)"
+    m = pa.Model(ctx, desc, synthetic_seed=1)
     rng = np.random.default_rng(0)
     ids = rng.integers(1000, 30000, (batch, seq)).astype(np.int64)
     mask = np.ones((batch, seq), np.int64)
@@ -204,7 +235,7 @@ def encoder_leg(pa, ctx, compute, steps=5, warmup=2, batch=256, seq=256):
     dev_ms = float(np.mean(ms))
     tf = flops / (dev_ms * 1e-3) / 1e12
     return {
-        "workload": f"encode batch={batch} x seq_len={seq}, all-MiniLM-L6-v2 shape, synthetic weights",
+        "workload": f"encode batch={batch} x seq_len={seq}, {label}, synthetic weights",
         "compute": {"f32": "f32 (exact-f32 MFMA; the reference's dtype)",
                     "bf16x3": "split precision: 3 bf16 terms per f32 operand, 6 bf16 MFMAs per product, f32 accumulate",
                     "f16x2": "split precision: 2 f16 terms per f32 operand, 3 f16 MFMAs per product, f32 accumulate"}[compute],
@@ -353,7 +384,7 @@ def main():
             torch.cuda.synchronize()
         ctx.synchronize()
 
-    scan_ms, pass_ms, host_ms, scan_bytes, streamed_bytes, cands, reruns, spec_reruns = [], [], [], [], [], [], 0, 0
+    scan_ms, pass_ms, host_ms, scan_bytes, streamed_bytes, cands, coarse, reruns, spec_reruns = [], [], [], [], [], [], [], 0, 0
     last = None
 
     def step(i, timed):
@@ -372,6 +403,7 @@ def main():
             scan_bytes.append(st["bytes_algorithmic"] / nl)
             streamed_bytes.append(st["bytes_streamed"] / nl)
             cands.append(st["candidates"])
+            coarse.append(st["coarse_survivors"])
             reruns += st["overflow_reruns"]
             spec_reruns += st["speculation_reruns"]
 
@@ -398,13 +430,23 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         vectors_per_s = total_rows * args.steps / elapsed
-        per_launch_bytes = float(np.mean(scan_bytes))  # this rank's shard: rows * dim * 4
-        achieved = per_launch_bytes / (mean_scan_ms * 1e-3) / 1e9
-        copy = {0: None, 1: "bf16", 2: "int8"}[searcher.last_stats()["screening_copy"]]
-        streamed = float(np.mean(streamed_bytes)) / (mean_scan_ms * 1e-3) / 1e9  # what the scan kernel actually pulls from HBM
+        st_last = searcher.last_stats()
+        copy = {0: None, 1: "bf16", 2: "int8"}[st_last["screening_copy"]]
+        per_launch_streamed = float(np.mean(streamed_bytes))  # what this rank's scan kernel has to read per launch
         ids, scores, counts = last
-        kname = scan_kernel_name(searcher.last_stats(), B, args.dim)
-        traffic, traffic_src = measured_traffic(kname, (hi - lo), args.dim, float(np.mean(streamed_bytes)) / max(1, hi - lo))
+        kname = scan_kernel_name(st_last, B, args.dim)
+        roof = roofline_of({"bytes_streamed": per_launch_streamed}, 1, mean_scan_ms, hi - lo, args.dim)
+        traffic, traffic_src = measured_traffic(kname, (hi - lo), args.dim, per_launch_streamed / max(1, hi - lo))
+        roof.update({
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "streams": {None: "f32 rows + row scales", "bf16": "bf16 screening copy",
+                                                                                          "int8": "int8 screening copy + row scales"}[copy],
+            "algorithmic_f32_bytes_per_launch": float(np.mean(scan_bytes)),  # N*D*4 of SURVEY 8d: what `effective_f32_pass_GBps` prices
+            "kernel_ms_median": float(np.median(scan_ms)), "kernel_ms_min": float(np.min(scan_ms)),
+            "read_ceiling_measured": measured_read_ceiling(),  # GB/s, profiles/r01_ubench_hbm_read*.txt
+            "pass_ms": float(np.mean(pass_ms)),  # upload + prep_seed + scan + rescore_select on the device
+            "fixed_cost_us": 1e3 * (float(np.mean(pass_ms)) - mean_scan_ms),
+            "host_enqueue_ms": float(np.mean([h[0] for h in host_ms])), "host_wait_ms": float(np.mean([h[1] for h in host_ms])),
+        })
         out = {
             "metric": f"vectors scanned/sec (exact cosine top-{k}, {args.dim}-d f32, batch={B})",
             "value": vectors_per_s,
@@ -418,48 +460,25 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "screen": ({"int8": "coarse screen = exact integer dot product of per-row int8-quantised rows (resident screening copy, 384 B/vector "
-                                "+ 4 B scale) and the int8-quantised query on v_mfma_i32_32x32x32_i8, with a certified quantisation margin; ",
+                                "+ 4.5 B of scales) and the int8-quantised query on v_mfma_i32_32x32x32_i8, with a certified quantisation margin; ",
                         "bf16": "coarse screen = bf16 MFMA over the resident bf16 screening copy of the rows (768 B/vector); ",
                         None: "rows are read as f32 (1536 B/vector), bf16 MFMA coarse screen; "}[copy]
                        + "the f32 rows are read for the coarse survivors only: exact-f32 fine screen with certified margins, survivors "
-                         "ranked in f64: exact top-k") if searcher.last_stats()["kernel_used"] == 2 else
+                         "ranked in f64: exact top-k") if st_last["kernel_used"] == 2 else
                       "f32 FMA screen with a certified margin, survivors ranked in f64: exact top-k",
             "data": "synthetic clustered" if args.clustered else "synthetic",
             "config": {
                 "workload": f"{total_rows} x {args.dim} f32 synthetic corpus, batch={B} queries, top-{k}, "
                             f"{world} MI355X" + (" (rows sharded, RCCL all-gather of per-shard top-k)" if world > 1 else ""),
                 "rows": total_rows, "dim": args.dim, "batch": B, "k": k,
-                "kernel": {1: "wave", 2: "mfma"}[searcher.last_stats()["kernel_used"]], "screening_copy": copy,
+                "kernel": {1: "wave", 2: "mfma"}[st_last["kernel_used"]], "screening_copy": copy,
                 "rows_normalized": bool(args.normalized), "clustered": bool(args.clustered),
                 "collective": (args.collective if use_dist else None),
             },
             "queries_per_s": B * args.steps / elapsed,
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel": kname,
-                "bytes_per_launch": per_launch_bytes,
-                # `achieved` / `frac` price the launch at the ALGORITHMIC bytes of the reference formulation (one f32 pass,
-                # SURVEY §8d); with the screening copy the kernel streams half of them, so frac can pass 1.  The kernel's
-                # own efficiency against the HBM roofline is streamed / peak:
-                "streamed_bytes_per_launch": float(np.mean(streamed_bytes)),
-                "streamed": streamed,
-                "frac_streamed": streamed / HBM_PEAK_GBPS,
-                "kernel_ms": mean_scan_ms,
-                "kernel_ms_median": float(np.median(scan_ms)),
-                "kernel_ms_min": float(np.min(scan_ms)),
-                "read_ceiling_measured": measured_read_ceiling(),  # GB/s, profiles/r01_ubench_hbm_read*.txt
-                "pass_ms": float(np.mean(pass_ms)),  # H2D + prep_seed + scan + rescore_select on the device
-                "fixed_cost_us": 1e3 * (float(np.mean(pass_ms)) - mean_scan_ms),
-                "host_enqueue_ms": float(np.mean([h[0] for h in host_ms])),
-                "host_wait_ms": float(np.mean([h[1] for h in host_ms])),
-            },
+            "roofline": roof,
             "candidates_per_query": float(np.mean(cands)) / B,
+            "coarse_survivors_per_query": float(np.mean(coarse)) / B,
             "overflow_reruns": reruns,
             "speculation_reruns": spec_reruns,  # passes repeated because a speculative start threshold did not hold (scan.h)
             "build_s": t_build,
@@ -469,33 +488,50 @@ def main():
             # the other legs BASELINE.json names, measured in the same run (single GPU only)
             extra = {}
             es, ew = max(3, min(args.steps, 20)), max(1, min(args.warmup, 3))
-            extra["config5_end_to_end"] = e2e_leg(pa, ctx, searcher, total_rows)
+            # the same workload without the speculative start threshold (scan.h; PCV_SCAN_FLAGS bit 5): the headline's kernel
+            # time includes a guess learned from the bench's own i.i.d. queries — this is the figure without it
+            ng = scan_leg(pa, ctx, total_rows, B, k, args.kernel, max(3, es // 2), ew, searcher=searcher, dim=args.dim, tuning=32)
+            out["roofline"]["no_guess"] = {"kernel_ms": ng["kernel_ms"], "frac": ng["roofline"]["frac"], "candidates_per_query": ng["candidates_per_query"]}
+            if args.dim == 384:
+                extra["config5_end_to_end"] = e2e_leg(pa, ctx, searcher, total_rows)
             searcher.set_kernel(args.kernel)
-            if copy == "int8" and args.dim <= 384:
-                # larger batches on the same corpus: the block-holding form of the int8 scan (128 queries; 256 in one pass)
+            if copy == "int8":
+                # larger batches on the same corpus (the block-holding form of the int8 scan up to 384-d: 128 queries; 256 in one pass)
                 for nq in (128, 256):
-                    extra[f"batch{nq}"] = scan_leg(pa, ctx, total_rows, nq, k, args.kernel, max(3, es // 2), ew, searcher=searcher)
+                    extra[f"batch{nq}"] = scan_leg(pa, ctx, total_rows, nq, k, args.kernel, max(3, es // 2), ew, searcher=searcher, dim=args.dim)
             if copy is not None:
                 # the same corpus and queries' shape without the int8 copy: the scan streams the f32 rows themselves
-                # (1536 B/vector, the SURVEY §8d figure) or the bf16 copy; results are the same exact top-k
+                # (1536 B/vector, the SURVEY 8d / north_star workload) or the bf16 copy; results are the same exact top-k
                 held = {"int8": args.dim + 5, "bf16": 2 * args.dim}  # bytes per row of a copy
                 for mode, key in (("off", "f32_rows_b64"), ("bf16", "bf16_copy_b64")):
                     searcher.set_screening_copy(mode)
                     searcher.finalize()
                     if mode == "off":
                         settle(total_rows * held[copy])
-                    extra[key] = scan_leg(pa, ctx, total_rows, B, k, args.kernel, es, ew, searcher=searcher)
-                searcher.set_screening_copy({"int8": "int8", "bf16": "bf16"}[copy])
-                searcher.finalize()
-                settle(total_rows * held["bf16"])
-            extra["config2_10m_b1"] = scan_leg(pa, ctx, 10_000_000, 1, k, "auto", es, ew)
-            extra["shard_12p5m_b64"] = scan_leg(pa, ctx, 12_500_000, 64, k, "auto", es, ew)
-            extra["encoder_256x256"] = encoder_leg(pa, ctx, "f32")
-            extra["encoder_256x256_split_precision"] = [encoder_leg(pa, ctx, "bf16x3"), encoder_leg(pa, ctx, "f16x2")]
+                    extra[key] = scan_leg(pa, ctx, total_rows, B, k, args.kernel, es, ew, searcher=searcher, dim=args.dim)
+                # the north_star's own workload ("coalesced HBM reads of the corpus f32 rows", >= 70 % of the HBM roofline): beside the headline
+                f = extra["f32_rows_b64"]
+                out["roofline"]["f32_rows"] = {"kernel": f["kernel"], "kernel_ms": f["kernel_ms"], "achieved": f["roofline"]["achieved"],
+                                               "frac": f["roofline"]["frac"], "vectors_per_s": f["vectors_per_s"]}
             if not args.clustered and args.rows >= 1_000_000:
                 searcher.close()  # two 153.6 GB corpora do not fit: the clustered one replaces the headline one
-                settle(total_rows * (args.dim * 4 + args.dim + 8))
-                extra["clustered_b64"] = scan_leg(pa, ctx, args.rows, B, k, args.kernel, es, ew, clustered=True)
+                searcher = None
+                settle(total_rows * (args.dim * 4 + 2 * args.dim + 8))
+                extra["clustered_b64"] = scan_leg(pa, ctx, args.rows, B, k, args.kernel, es, ew, clustered=True, dim=args.dim)
+                # the reference's default model (MsMarcoBertBaseDotV5, perceive-cli/state.rs:24): 768-d, dot metric
+                # (search.rs:266-279), rows not normalised — norms spread over x[0.5, 2)
+                big = max(1_000_000, args.rows // 2)  # as many bytes of rows as the headline corpus
+                rec, s768 = scan_leg(pa, ctx, big, 64, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0), keep=True)
+                extra["d768_dot_b64"] = rec
+                extra["d768_dot_b128"] = scan_leg(pa, ctx, big, 128, k, "auto", max(3, es // 2), ew, searcher=s768, dim=768, metric="dot", amplitude=(0.5, 2.0))
+                s768.close()
+                settle(big * (768 * 4 + 768 + 8))
+                extra["d768_dot_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0))
+            extra["config2_10m_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew)
+            extra["shard_12p5m_b64"] = scan_leg(pa, ctx, max(100_000, args.rows // 8), 64, k, "auto", es, ew)
+            extra["encoder_256x256"] = encoder_leg(pa, ctx, "f32")
+            extra["encoder_256x256_split_precision"] = [encoder_leg(pa, ctx, "bf16x3"), encoder_leg(pa, ctx, "f16x2")]
+            extra["encoder_bertbase_64x256"] = encoder_leg(pa, ctx, "f32", batch=64, seq=256, shape="bert_base")
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
@@ -503,7 +539,8 @@ def main():
 
     if use_dist and comm is not None:
         comm.close()
-    searcher.close()
+    if searcher is not None:
+        searcher.close()
     ctx.close()
     if use_dist:
         dist.destroy_process_group()

@@ -124,9 +124,19 @@ public:
     // Searcher::rebuild_source (search.rs:58-79)
     template <class Rows>
     void rebuild_source(const Rows& rows, int64_t source_id) {
-        check(pcv_searcher_clear_source(h_, source_id));
-        for (const EmbeddingRow& r : rows)
-            if (r.source_id == source_id) insert(r);  // search.rs:106-109
+        // the new index is built first and swapped in only once it exists (search.rs:57-79): staged under
+        // PCV_STAGING_SOURCE, so a bad row leaves the source's old rows in place
+        check(pcv_searcher_clear_source(h_, PCV_STAGING_SOURCE));
+        try {
+            for (const EmbeddingRow& r : rows)
+                if (r.source_id == source_id) insert(r, PCV_STAGING_SOURCE);  // search.rs:106-109
+            check(pcv_searcher_finalize(h_));
+        } catch (...) {
+            pcv_searcher_clear_source(h_, PCV_STAGING_SOURCE);
+            pcv_searcher_finalize(h_);
+            throw;
+        }
+        check(pcv_searcher_replace_source(h_, PCV_STAGING_SOURCE, source_id));
         check(pcv_searcher_finalize(h_));
     }
     // Searcher::search_vector (search.rs:157-182)
@@ -184,10 +194,11 @@ public:
     pcv_searcher* handle() const { return h_; }
 
 private:
-    void insert(const EmbeddingRow& r) {
+    void insert(const EmbeddingRow& r) { insert(r, r.source_id); }
+    void insert(const EmbeddingRow& r, int64_t into_source) {
         if ((int)r.embedding.size() != dim_ * 4)
             throw Error(PCV_ERR_INVALID, "embedding blob of item " + std::to_string(r.item_id) + " has the wrong size");
-        check(pcv_searcher_add_blobs(h_, r.source_id, &r.item_id, r.embedding.data(), 1));
+        check(pcv_searcher_add_blobs(h_, into_source, &r.item_id, r.embedding.data(), 1));
     }
     pcv_searcher* h_ = nullptr;
     int dim_;

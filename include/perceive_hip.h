@@ -114,6 +114,11 @@ pcv_status pcv_searcher_add_synthetic(pcv_searcher* s, int64_t source_id, int64_
  * n_clusters seeded centroids; the cosines inside a cluster spread over ~noise^2 * dim.  n_clusters = 0: plain rows. */
 pcv_status pcv_searcher_add_synthetic_clustered(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
                                                 int64_t first_row, int normalize, int n_clusters, float noise);
+/* Un-normalised synthetic rows whose norms spread — what a dot-product model (the reference's default
+ * MsMarcoBertBaseDotV5, perceive-cli/state.rs:24) stores: row = a(row) * synth_row(seed, row), a(row) uniform in
+ * [amp_lo, amp_hi) from a hash of the row number; 0 < amp_lo < amp_hi.  Bit-identical CPU twin: oracle/synth.c. */
+pcv_status pcv_searcher_add_synthetic_scaled(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
+                                             int64_t first_row, float amp_lo, float amp_hi);
 /* Capacity hint (search.rs:138-140 sizes each source's index from its row count before inserting): the
  * host is about to add `n_rows` more rows to `source_id`, e.g. the COUNT(*) of the build query.  The rows
  * then land in one device segment instead of a chain of growing ones.  Optional; no-op for n_rows = 0. */
@@ -121,6 +126,13 @@ pcv_status pcv_searcher_reserve(pcv_searcher* s, int64_t source_id, int64_t n_ro
 /* Searcher::rebuild_source (search.rs:58-79): drop every row of `source_id`; follow with
  * add_* + finalize to install the replacement.  Unknown source: no-op. */
 pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id);
+/* The swap of Searcher::rebuild_source (search.rs:57-79: the new SourceSearch is built first and takes the old one's
+ * place only once it exists): the rows of source `from_source_id` become the rows of `to_source_id`, whose old rows
+ * are dropped; `from_source_id` disappears.  `from` unknown or empty: `to` is left absent (search.rs:67-69).  Build
+ * the replacement under a staging id (add_* + finalize: a failure on the way leaves `to` untouched — clear the
+ * staging id then), swap, finalize.  PCV_STAGING_SOURCE is the id this library's own loaders stage under. */
+#define PCV_STAGING_SOURCE INT64_MIN
+pcv_status pcv_searcher_replace_source(pcv_searcher* s, int64_t from_source_id, int64_t to_source_id);
 /* Pack pending rows into the HBM layout, compute row norms (set_searching_mode, search.rs:150). */
 pcv_status pcv_searcher_finalize(pcv_searcher* s);
 
@@ -128,7 +140,10 @@ pcv_status pcv_searcher_finalize(pcv_searcher* s);
  * file: runs `SELECT id FROM sources` and the items / item_embeddings join of search.rs:87-93 for
  * (model_id, model_version) — rows with `skipped` or `hidden_at` set never enter the index — streams the
  * embedding blobs into the device (one segment per source, sized from a COUNT), and finalizes.
- *   only_source   NULL: every source of the database; else that source is cleared and reloaded
+ *   only_source   NULL: every source of the database; else that source is reloaded: its new rows are read, checked and
+ *                 packed under PCV_STAGING_SOURCE first and replace the old ones only when all of them are in
+ *                 (search.rs:57-79) — after a failure (a blob of the wrong size, an SQLite error) the old rows are
+ *                 still there and searchable
  *   out_rows      rows loaded (may be NULL)
  * SQLite is bound at run time (libsqlite3.so.0); PCV_ERR_UNSUPPORTED if it is not installed. */
 pcv_status pcv_searcher_load_sqlite(pcv_searcher* s, const char* db_path, uint32_t model_id, uint32_t model_version,
@@ -184,6 +199,9 @@ pcv_status pcv_searcher_set_tuning(pcv_searcher* s, uint32_t flags);
 enum { PCV_SCREEN_COPY_OFF = 0, PCV_SCREEN_COPY_BF16 = 1, PCV_SCREEN_COPY_AUTO = 2, PCV_SCREEN_COPY_INT8 = 3 };
 pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode);
 
+/* Most hits one search call ranks per query (num_results of search.rs:160; the reference's callers ask for 10 and 20). */
+enum { PCV_MAX_RESULTS = 128 };
+
 /* Searcher::search_vector (search.rs:157-182), batched over `n_queries` query vectors.
  *   queries      [n_queries][dim] f32
  *   source_ids   sources to search (search.rs:166 filter): NULL = all sources (n_sources ignored);
@@ -234,6 +252,11 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
 pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* queries, int n_queries,
                                             const int64_t* source_ids, int n_sources, int k, void* d_out);
 pcv_status pcv_searcher_search_device_end(pcv_searcher* s, int* out_overflowed);
+/* A step of a sharded search is about to be repeated because SOME rank's pass was incomplete (any_overflow of
+ * pcv_merge_topk_flagged): the repeat on THIS rank runs without a speculative start threshold as well.  Every rank
+ * keeps its own guess statistics; without this call guesses could fail on different ranks in different attempts and
+ * every such failure would make all ranks repeat.  Call it on every rank between `end` and the next `begin`. */
+pcv_status pcv_searcher_repeat_without_guess(pcv_searcher* s);
 
 /* Cross-shard merge (replaces the rayon flat_map + sort + truncate of search.rs:163-181):
  * `d_lists` is a DEVICE pointer to [n_shards][n_queries][k] pcv_hit (the all-gather result),
@@ -291,10 +314,13 @@ typedef struct pcv_scan_stats {
     int32_t screening_copy;      /* what the scan streamed (last pass): 0 f32 rows, 1 bf16 copy, 2 int8 copy */
     float host_enqueue_ms;       /* host time spent queueing the passes (copies + launches)      */
     float host_wait_ms;          /* host time blocked until the stream had drained               */
-    int64_t bytes_streamed;      /* rows_scanned * dim * (4 f32 rows, 2 bf16 copy, 1 int8 copy)  */
+    int64_t bytes_streamed;      /* bytes the scan kernel(s) had to read from HBM, layout padding included: per 32-row block
+                                    the f32 pieces + 32 row scales, or the bf16 pieces, or the int8 pieces + 36 scale floats */
     int32_t speculation_reruns;  /* passes repeated because a speculative start threshold (a guess taken from the seed
                                     rows and checked at the end of the pass) did not hold; results are exact either way */
     int32_t reserved0;
+    int64_t coarse_survivors;    /* MFMA scans: (row, query) pairs that passed the coarse screen and had their f32 row read
+                                    by the fine screen, summed over queries and launches */
 } pcv_scan_stats;
 pcv_status pcv_searcher_last_stats(pcv_searcher* s, pcv_scan_stats* out);
 

@@ -62,6 +62,8 @@ void orc_synth_rows(uint64_t seed, int64_t first_row, int64_t n, int D, int norm
 /* Clustered rows: centroid(cluster(row))/sqrt(D) + noise * u(row) * synth_row(seed,row), u in [0.5,1.5) (bench.py --clustered). */
 void orc_synth_rows_clustered(uint64_t seed, int64_t first_row, int64_t n, int D, int normalize, int n_clusters,
                               float noise, float* out);
+/* Scaled rows: a(row) * synth_row(seed,row), a uniform in [amp_lo, amp_hi) (bench.py's 768-d dot-metric legs). */
+void orc_synth_rows_scaled(uint64_t seed, int64_t first_row, int64_t n, int D, float amp_lo, float amp_hi, float* out);
 
 /* ---- timed CPU baseline (bench.py cpu_baseline leg) ----------------------------------------- */
 /* Fused single pass of lib.rs:67-77 + top-k over rows [0,N) of `m` for B queries on `threads`

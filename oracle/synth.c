@@ -97,3 +97,18 @@ void orc_synth_rows_clustered(uint64_t seed, int64_t first_row, int64_t n, int D
         }
     }
 }
+
+/* Scaled rows (twin of synth_piece_scaled): row = a(row) * synth_row, a uniform in [lo, hi) from the amplitude hash. */
+void orc_synth_rows_scaled(uint64_t seed, int64_t first_row, int64_t n, int D, float amp_lo, float amp_hi, float* out) {
+    const float span = amp_hi - amp_lo;
+    for (int64_t r = 0; r < n; ++r) {
+        float* o = out + (size_t)r * D;
+        const int64_t row = first_row + r;
+        const float a = fmaf(span, (float)(uint32_t)((((uint64_t)row * 0xD6E8FEB86659FD93ull) >> 40) & 0xffffffu) * (1.0f / 16777216.0f), amp_lo);
+        for (int f4 = 0; f4 < D / 4; ++f4) {
+            float v[4];
+            synth_piece(seed, row, (uint32_t)f4, v);
+            for (int j = 0; j < 4; ++j) o[4 * f4 + j] = a * v[j];
+        }
+    }
+}

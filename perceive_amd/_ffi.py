@@ -43,6 +43,7 @@ class ScanStats(C.Structure):
         ("bytes_streamed", C.c_int64),
         ("speculation_reruns", C.c_int32),
         ("reserved0", C.c_int32),
+        ("coarse_survivors", C.c_int64),
     ]
 
 
@@ -106,7 +107,9 @@ SYMBOLS = {
     "pcv_searcher_add_blobs": (C.c_int, [_P, C.c_int64, _I64P, _U8P, C.c_int64]),
     "pcv_searcher_add_synthetic": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int]),
     "pcv_searcher_add_synthetic_clustered": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_float]),
+    "pcv_searcher_add_synthetic_scaled": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_float, C.c_float]),
     "pcv_searcher_clear_source": (C.c_int, [_P, C.c_int64]),
+    "pcv_searcher_replace_source": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "pcv_searcher_finalize": (C.c_int, [_P]),
     "pcv_searcher_load_sqlite": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint32, _I64P, _I64P]),
     "pcv_searcher_dim": (C.c_int, [_P, _INTP]),
@@ -124,6 +127,7 @@ SYMBOLS = {
     "pcv_searcher_search_device": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _P, C.c_int]),
     "pcv_searcher_search_device_begin": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _P]),
     "pcv_searcher_search_device_end": (C.c_int, [_P, _INTP]),
+    "pcv_searcher_repeat_without_guess": (C.c_int, [_P]),
     "pcv_merge_topk_flagged": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP, _INTP]),
     "pcv_merge_topk": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
     "pcv_merge_topk_host": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP]),

@@ -30,7 +30,7 @@
 namespace pcv {
 
 constexpr int kBlockRows = 32;      // rows per corpus block
-constexpr int kMaxK = 128;          // largest num_results the running top-k slots hold
+constexpr int kMaxK = PCV_MAX_RESULTS;  // largest num_results the running top-k slots hold (128)
 constexpr int kSeedPartRows = 256;   // rows one seed workgroup ranks (one per thread)
 constexpr int kSeedParts = 64;       // seed workgroups per query group -> up to 16384 seed rows
 constexpr int kMaxWaveQueries = 4;  // wave-reduction kernel handles 1..4 queries per pass
@@ -88,12 +88,14 @@ struct ScanParams {
     float* margin32;         // [B]  fine screen:   rows with s32 < tau - margin32 are dropped     (2 * eps32)
     uint32_t* tau;           // [B*kHot]  ordered key of the running k-th best f32 score (word q*kHot)
     uint32_t* slots;         // [B][kMaxK] ordered keys of k distinct rows' f32 scores
-    uint32_t* cand_cnt;      // [B*kHot]  survivors emitted per query (word q*kHot)
+    uint32_t* cand_cnt;      // [B*kHot]  survivors emitted per query (word q*kHot); word q*kHot + 32: rows that passed the COARSE screen
+                             //           (statistics only: pcv_scan_stats.coarse_survivors)
     uint64_t* cand;          // [B][cand_cap]  (segment index << 32) | row
     float* cand_s;           // [B][cand_cap]  f32 screening score the row was emitted with
     pcv_hit_dev* out;        // [B][k] device results
     pcv_hit_dev* out_host;   // pinned host mirror of `out`, or nullptr
     uint32_t* cnt_host;      // [B] pinned host: survivors per query, uncapped (the host sizes a rerun from it)
+    uint32_t* coarse_host;   // [B] pinned host: coarse survivors per query (MFMA scans)
     pcv_hit_dev* flag_rec;   // overflow record behind a shard's hit list (device), or nullptr
     uint32_t cand_cap;
     uint32_t seed_blocks;    // blocks of segment 0 ranked by the seed kernel: blocks i << seed_shift, i < seed_blocks — spread
@@ -158,7 +160,7 @@ void launch_coarse_pack8(hipStream_t st, const float4* blk, const float* scale, 
 void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);  // quantises the queries first
 int mfma8_pass_queries(int Dp);  // queries one int8 MFMA pass can take (LDS-limited)
 void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nrows, uint32_t row0, int D, int D4, uint64_t seed,
-                       int64_t first_row, int normalize, uint32_t n_clusters, float noise);
+                       int64_t first_row, int normalize, uint32_t n_clusters, float noise, float amp_lo = 0.0f, float amp_hi = 0.0f);
 void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const int64_t* d_pos, int64_t n, int D,
                         int D4, float* out_rows, int64_t* out_ids);
 // `p` is the host copy (shapes for the launch geometry), `dp` the same struct resident in device memory.

@@ -331,13 +331,14 @@ __global__ __launch_bounds__(256) void coarse_pack8_kernel(const float4* __restr
 }
 
 
-struct SynthShape {  // n_clusters == 0: plain i.i.d. rows
+struct SynthShape {  // n_clusters == 0: plain i.i.d. rows, times a per-row amplitude in [amp_lo, amp_lo + amp_span) if amp_span >= 0
     uint32_t n_clusters;
     float noise, inv_sqrt_d;
+    float amp_lo, amp_span;  // amp_span < 0: no amplitude
 };
 __device__ __forceinline__ float4 synth_value(uint64_t seed, int64_t row, uint32_t f4, const SynthShape& sh) {
-    return sh.n_clusters ? synth_piece_clustered(seed, row, f4, sh.n_clusters, sh.noise, sh.inv_sqrt_d)
-                         : synth_piece(seed, row, f4);
+    if (sh.n_clusters) return synth_piece_clustered(seed, row, f4, sh.n_clusters, sh.noise, sh.inv_sqrt_d);
+    return sh.amp_span >= 0.0f ? synth_piece_scaled(seed, row, f4, sh.amp_lo, sh.amp_span) : synth_piece(seed, row, f4);
 }
 
 __global__ __launch_bounds__(256) void synth_inv_kernel(uint32_t nrows, int D4src, uint64_t seed, int64_t first_row,
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(256) void reset_scan_state_kernel(uint32_t* __restr
     if (t < kMfmaQueries) {
         tau[t * kHot] = kKeyNegInf;
         cand_cnt[t * kHot] = 0;
+        cand_cnt[t * kHot + 32] = 0;
     }
 }
 
@@ -898,6 +900,7 @@ __device__ __forceinline__ void fine_survivors(const ScanParams& p, uint32_t mas
         uint32_t m = __builtin_amdgcn_readlane(mask, src);
         const int q = 32 * t + (src & 31), hh = src >> 5;
         const float m32 = gld(&p.margin32[q]);
+        if (lane == 0) g_atomic_add(&p.cand_cnt[q * kHot + 32], (uint32_t)__builtin_popcount(m));  // statistics (no return value is used)
         while (m) {
             const int i = __builtin_ctz(m);
             m &= m - 1;
@@ -1785,6 +1788,8 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
     if (tid == 0) {
         const bool failed = guessed && n_spec < (uint32_t)p.k;  // (after the last slice's barrier)
         if (p.cnt_host) p.cnt_host[q] = failed ? kSpecFailed : raw_cnt;
+        if (p.coarse_host) p.coarse_host[q] = ld_relaxed(&p.cand_cnt[q * kHot + 32]);
+        st_relaxed(&p.cand_cnt[q * kHot + 32], 0u);
         if ((raw_cnt > p.cand_cap || failed) && p.flag_rec) p.flag_rec->pos = 1;
         st_relaxed(&p.tau[q * kHot], kKeyNegInf);
         st_relaxed(&p.cand_cnt[q * kHot], 0u);
@@ -1903,10 +1908,10 @@ void launch_row_scales(hipStream_t st, const float4* blk, uint32_t first_block, 
 }
 
 void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nrows, uint32_t row0, int D, int D4, uint64_t seed,
-                       int64_t first_row, int normalize, uint32_t n_clusters, float noise) {
+                       int64_t first_row, int normalize, uint32_t n_clusters, float noise, float amp_lo, float amp_hi) {
     if (nrows == 0) return;
     const int D4src = D / 4;
-    const SynthShape sh{n_clusters, noise, 1.0f / sqrtf((float)D)};
+    const SynthShape sh{n_clusters, noise, 1.0f / sqrtf((float)D), amp_lo, amp_hi > amp_lo ? amp_hi - amp_lo : (amp_hi == amp_lo && amp_lo > 0.0f ? 0.0f : -1.0f)};
     float* inv = nullptr;
     if (normalize) {
         PCV_HIP(hipMallocAsync((void**)&inv, (size_t)nrows * sizeof(float), st));

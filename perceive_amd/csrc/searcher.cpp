@@ -150,6 +150,7 @@ struct pcv_searcher {
     // what one pass brings back: written by rescore_select_kernel straight into pinned memory
     struct Pinned {
         uint32_t cnt[kMfmaQueries];
+        uint32_t coarse[kMfmaQueries];  // rows per query that passed the coarse screen (statistics)
         float spec_base[kMfmaQueries];  // median / best seed slot per query, k-th best exact score per query (scan.h: spec_gap)
         float spec_top[kMfmaQueries];
         float kth[kMfmaQueries];
@@ -191,6 +192,7 @@ struct pcv_searcher {
         int B = 0;
         int64_t rows = 0;
         int src = 0;  // what the scan streamed: 0 f32 rows, 1 bf16 copies, 2 int8 copies
+        int64_t stream_bytes = 0;  // ... and how many bytes of it the scan kernel has to read, padding included
         bool replayed = false;  // launched as a graph: only the pass as a whole was timed
         bool learned = false;   // the speculative threshold had a learned part
         bool guessing = false;  // the pass ran with a speculative threshold (and sent the seed statistics home)
@@ -571,6 +573,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.out = d_out ? d_out : s->d_hits.p;
     p.out_host = download ? s->pin->hits : nullptr;
     p.cnt_host = s->pin->cnt;
+    p.coarse_host = s->pin->coarse;
     p.flag_rec = d_flag;
     p.cand_cap = s->cand_cap;
     p.flags = (s->scan_flags & ~(16u | 64u)) | (src_kind == 1 ? 16u : 0u) | (src_kind == 2 ? 64u : 0u);
@@ -703,6 +706,12 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     s->pending.B = B;
     s->pending.rows = rows;
     s->pending.src = src_kind;
+    // what the scan kernel of this pass must pull from HBM, per 32-row block: the int8 pieces + the 36 floats of scales and
+    // set extremes; the bf16 pieces; or the f32 pieces + the 32 row scales
+    const int64_t Dp8 = (s->Dp + 127) & ~127;
+    s->pending.stream_bytes = (int64_t)blk0 * (src_kind == 2 ? Dp8 * kBlockRows + (int64_t)kScale8Stride * 4
+                                               : src_kind == 1 ? (int64_t)s->Dp * 2 * kBlockRows
+                                                               : (int64_t)s->Dp * 4 * kBlockRows + kBlockRows * 4);
     s->pending.learned = p.spec_gap == p.spec_gap;
     s->pending.guessing = p.spec_rank > 0 || s->pending.learned;
     s->stats.host_enqueue_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -736,7 +745,7 @@ bool finish_pass(pcv_searcher* s) {
     s->stats.scan_launches += 1;
     s->stats.rows_scanned += rows;
     s->stats.bytes_algorithmic += rows * (int64_t)s->D * 4;
-    s->stats.bytes_streamed += rows * (int64_t)s->D * (s->pending.src == 2 ? 1 : (s->pending.src == 1 ? 2 : 4));
+    s->stats.bytes_streamed += s->pending.stream_bytes;
     s->stats.screening_copy = s->pending.src;
 
     const uint32_t* cnt = s->pin->cnt;
@@ -751,6 +760,7 @@ bool finish_pass(pcv_searcher* s) {
         mx = std::max(mx, cnt[b]);
         sum += cnt[b];
     }
+    for (int b = 0; b < B; ++b) s->stats.coarse_survivors += s->pin->coarse[b];
     if (mx <= s->cand_cap && !guess_failed) {
         s->stats.candidates += sum;
         s->spec_hold = false;
@@ -1015,11 +1025,12 @@ pcv_status pcv_searcher_add_blobs(pcv_searcher* s, int64_t source_id, const int6
 }
 
 static pcv_status add_synthetic(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed, int64_t first_row,
-                                int normalize, int n_clusters, float noise) {
+                                int normalize, int n_clusters, float noise, float amp_lo = 0.0f, float amp_hi = 0.0f) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr, "add_synthetic: searcher is NULL");
         PCV_REQUIRE(n >= 0, "add_synthetic: negative row count");
         PCV_REQUIRE(n_clusters >= 0 && noise >= 0.0f && std::isfinite(noise), "add_synthetic: bad cluster shape");
+        PCV_REQUIRE(std::isfinite(amp_lo) && std::isfinite(amp_hi) && amp_lo >= 0.0f && amp_hi >= amp_lo, "add_synthetic: bad amplitude range");
         PCV_REQUIRE(s->D % 4 == 0, "add_synthetic: dim %d is not a multiple of 4", s->D);
         std::lock_guard<std::mutex> lk(s->mu);
         Source& src = s->get_or_add_source(source_id);
@@ -1034,7 +1045,7 @@ static pcv_status add_synthetic(pcv_searcher* s, int64_t source_id, int64_t n, u
             g.id0 = first_row + r0;
             try {
                 launch_synth_fill(st, g.blk, (uint32_t)m, 0, s->D, s->D4, seed, first_row + r0, normalize,
-                                  (uint32_t)n_clusters, noise);
+                                  (uint32_t)n_clusters, noise, amp_lo, amp_hi);
                 PCV_HIP(hipStreamSynchronize(st));
                 PCV_HIP(hipGetLastError());
             } catch (...) {
@@ -1058,6 +1069,15 @@ pcv_status pcv_searcher_add_synthetic_clustered(pcv_searcher* s, int64_t source_
     return add_synthetic(s, source_id, n, seed, first_row, normalize, n_clusters, noise);
 }
 
+pcv_status pcv_searcher_add_synthetic_scaled(pcv_searcher* s, int64_t source_id, int64_t n, uint64_t seed,
+                                             int64_t first_row, float amp_lo, float amp_hi) {
+    if (!(amp_hi > amp_lo) || !(amp_lo > 0.0f)) {
+        set_error("add_synthetic_scaled: amplitudes must satisfy 0 < amp_lo < amp_hi");
+        return PCV_ERR_INVALID;
+    }
+    return add_synthetic(s, source_id, n, seed, first_row, 0, 0, 0.0f, amp_lo, amp_hi);
+}
+
 pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr, "clear_source: searcher is NULL");
@@ -1071,6 +1091,35 @@ pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id) {
         src->next_implicit_id = 0;
         src->reserve = 0;
         s->dirty = true;
+    });
+}
+
+pcv_status pcv_searcher_replace_source(pcv_searcher* s, int64_t from_source_id, int64_t to_source_id) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "replace_source: searcher is NULL");
+        PCV_REQUIRE(from_source_id != to_source_id, "replace_source: a source cannot replace itself");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->pending.active, "replace_source: a queued pass has not been collected");
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+        std::vector<Segment> fresh;
+        int64_t next_id = 0;
+        for (size_t i = 0; i < s->sources.size(); ++i)
+            if (s->sources[i].id == from_source_id) {
+                fresh = std::move(s->sources[i].segs);
+                next_id = s->sources[i].next_implicit_id;
+                s->sources.erase(s->sources.begin() + (std::ptrdiff_t)i);
+                break;
+            }
+        Source* to = s->find_source(to_source_id);
+        if (!to && !fresh.empty()) to = &s->get_or_add_source(to_source_id);
+        if (to) {  // (the old rows keep their place among the sources: positions of the others do not move)
+            for (auto& g : to->segs) free_segment(g);
+            to->segs = std::move(fresh);
+            to->next_implicit_id = next_id;
+            to->reserve = 0;
+        }
+        s->dirty = true;  // positions are handed out again by finalize (an emptied source disappears there)
     });
 }
 
@@ -1294,6 +1343,14 @@ pcv_status pcv_searcher_search_device_end(pcv_searcher* s, int* out_overflowed) 
         PCV_HIP(hipSetDevice(s->ctx->device));
         const bool over = finish_pass(s);
         if (out_overflowed) *out_overflowed = over ? 1 : 0;
+    });
+}
+
+pcv_status pcv_searcher_repeat_without_guess(pcv_searcher* s) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "repeat_without_guess: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->spec_hold = true;  // cleared by the next pass that completes (finish_pass)
     });
 }
 
@@ -1523,6 +1580,7 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
             total.host_wait_ms += s->stats.host_wait_ms;
             total.kernel_used = s->stats.kernel_used;
             total.bytes_streamed += s->stats.bytes_streamed;
+            total.coarse_survivors += s->stats.coarse_survivors;
             total.screening_copy = s->stats.screening_copy;
         };
         for (int q0 = 0; q0 < n_queries; q0 += qstep) {
@@ -1546,7 +1604,15 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
                 if (!again) std::memcpy(all.data() + (size_t)q0 * k, c->pin_hits, nb * sizeof(pcv_hit_dev));
                 accumulate();
                 if (!again) break;
-                PCV_REQUIRE(attempt < 7, "search_sharded: candidate lists still overflow after %d reruns", attempt + 1);
+                // Some rank's pass was incomplete (a list overflowed, or a speculative threshold did not hold — one flag
+                // covers both): the repeat runs without a guess on EVERY rank, so that guesses failing on different ranks
+                // in different attempts cannot use up the limit; what is left to repeat for are overflows, and each of
+                // those grows the lists of the rank it happened on.
+                s->spec_hold = true;
+                PCV_REQUIRE(attempt < 7,
+                            "search_sharded: the step is still incomplete on some rank after %d repeats (on this rank: %d candidate-list "
+                            "overflows, %d speculative thresholds that did not hold)",
+                            attempt + 1, total.overflow_reruns, total.speculation_reruns);
             }
         }
         s->stats = total;

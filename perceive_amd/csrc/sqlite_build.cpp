@@ -102,10 +102,13 @@ pcv_status pcv_searcher_load_sqlite(pcv_searcher* s, const char* db_path, uint32
         if (sqlite().open_v2(db_path, &db.h, kSqliteOpenReadonly, nullptr) != 0)
             PCV_FAIL(PCV_ERR_IO, "sqlite: cannot open %s: %s", db_path, db.h ? sqlite().errmsg(db.h) : "out of memory");
         // the sources to (re)build: all of them (Searcher::build, search.rs:45-48) or one (rebuild_source)
+        // One source: its new rows are staged under PCV_STAGING_SOURCE and take the old rows' place only once every one
+        // of them has been read, checked and packed (search.rs:57-79 builds the new SourceSearch before it swaps).
         std::vector<int64_t> sources;
         if (only_source) {
+            PCV_REQUIRE(*only_source != PCV_STAGING_SOURCE, "searcher_load_sqlite: source id %lld is reserved", (long long)*only_source);
             sources.push_back(*only_source);
-            check(pcv_searcher_clear_source(s, *only_source));  // search.rs:58-79: the source is replaced
+            check(pcv_searcher_clear_source(s, PCV_STAGING_SOURCE));  // (left over from a failed call, if anything)
         } else {
             Stmt st;
             prepare(db, st, "SELECT id FROM sources");
@@ -126,7 +129,7 @@ pcv_status pcv_searcher_load_sqlite(pcv_searcher* s, const char* db_path, uint32
             int rc;
             while ((rc = sqlite().step(st.h)) == kSqliteRow) {
                 const int64_t src = (int64_t)sqlite().column_int64(st.h, 0);
-                if (index.count(src)) check(pcv_searcher_reserve(s, src, (int64_t)sqlite().column_int64(st.h, 1)));
+                if (index.count(src)) check(pcv_searcher_reserve(s, only_source ? PCV_STAGING_SOURCE : src, (int64_t)sqlite().column_int64(st.h, 1)));
             }
             if (rc != kSqliteDone) PCV_FAIL(PCV_ERR_IO, "sqlite: %s", sqlite().errmsg(db.h));
         }
@@ -142,12 +145,12 @@ pcv_status pcv_searcher_load_sqlite(pcv_searcher* s, const char* db_path, uint32
         auto flush = [&](size_t i) {
             Pending& p = pend[i];
             if (p.ids.empty()) return;
-            check(pcv_searcher_add_blobs(s, sources[i], p.ids.data(), p.blobs.data(), (int64_t)p.ids.size()));
+            check(pcv_searcher_add_blobs(s, only_source ? PCV_STAGING_SOURCE : sources[i], p.ids.data(), p.blobs.data(), (int64_t)p.ids.size()));
             total += (int64_t)p.ids.size();
             p.ids.clear();
             p.blobs.clear();
         };
-        {
+        try {
             Stmt st;
             prepare(db, st,
                     "SELECT items.id, source_id, embedding FROM items JOIN item_embeddings ie ON model_id=? AND model_version=? "
@@ -172,8 +175,20 @@ pcv_status pcv_searcher_load_sqlite(pcv_searcher* s, const char* db_path, uint32
                 if (p.ids.size() >= kChunkRows) flush(it->second);
             }
             if (rc != kSqliteDone) PCV_FAIL(PCV_ERR_IO, "sqlite: %s", sqlite().errmsg(db.h));
+            for (size_t i = 0; i < pend.size(); ++i) flush(i);
+            if (only_source) {
+                check(pcv_searcher_finalize(s));  // the staged rows are complete (scales, screening copies): now the swap
+                check(pcv_searcher_replace_source(s, PCV_STAGING_SOURCE, *only_source));
+            }
+        } catch (...) {
+            if (only_source) {  // the old rows of the source stay what they were: drop the half-built replacement
+                const std::string why = pcv::last_error();
+                (void)pcv_searcher_clear_source(s, PCV_STAGING_SOURCE);
+                (void)pcv_searcher_finalize(s);
+                pcv::set_error("%s", why.c_str());
+            }
+            throw;
         }
-        for (size_t i = 0; i < pend.size(); ++i) flush(i);
         check(pcv_searcher_finalize(s));  // set_searching_mode, search.rs:150-152
         if (out_rows) *out_rows = total;
     });

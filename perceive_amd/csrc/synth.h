@@ -59,6 +59,16 @@ __host__ __device__ static inline uint32_t synth_cluster_of(int64_t row, uint32_
 __host__ __device__ static inline float synth_amplitude_of(int64_t row) {  // uniform in [0.5, 1.5), 24 bits
     return 0.5f + (float)(uint32_t)((((uint64_t)row * 0xD6E8FEB86659FD93ull) >> 40) & 0xffffffu) * (1.0f / 16777216.0f);
 }
+// Scaled variant (bench.py's 768-d dot-metric legs): row = a(row) * synth_row(seed, row), a(row) uniform in [lo, hi) from
+// the same hash — un-normalised rows whose norms spread, what a dot-product model (MsMarcoBertBaseDotV5) stores.
+__host__ __device__ static inline float synth_scale_of(int64_t row, float lo, float span) {
+    return fmaf(span, (float)(uint32_t)((((uint64_t)row * 0xD6E8FEB86659FD93ull) >> 40) & 0xffffffu) * (1.0f / 16777216.0f), lo);
+}
+__device__ static inline float4 synth_piece_scaled(uint64_t seed, int64_t row, uint32_t f4, float lo, float span) {
+    const float4 n = synth_piece(seed, row, f4);
+    const float a = synth_scale_of(row, lo, span);
+    return make_float4(a * n.x, a * n.y, a * n.z, a * n.w);
+}
 __device__ static inline float4 synth_piece_clustered(uint64_t seed, int64_t row, uint32_t f4, uint32_t n_clusters,
                                                       float noise, float inv_sqrt_d) {
     const float4 c = synth_piece(seed ^ kClusterSeedXor, (int64_t)synth_cluster_of(row, n_clusters), f4);

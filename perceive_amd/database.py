@@ -125,9 +125,8 @@ def rebuild_source(searcher, database, source_id, model_id, model_version):
     if database.path is not None:
         _load_sqlite(searcher, database.path, model_id, model_version, int(source_id))
         return
-    _ffi.check(_ffi.lib().pcv_searcher_clear_source(searcher._handle, int(source_id)))
-    _load(searcher, database.conn, model_id, model_version, [source_id])
-    searcher.finalize()
+    # in-memory database: the same staging as Searcher.rebuild_source (search.rs:57-79: build first, swap on success)
+    searcher.rebuild_source(database.conn.execute(_ROWS_SQL, (model_id, model_version)), source_id)
 
 
 def search_vector_and_retrieve(searcher, database, sources, num_results, vector):

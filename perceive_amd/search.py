@@ -13,6 +13,7 @@ from .context import Context
 
 _METRICS = {"cosine": _ffi.METRIC_COSINE, "dot": _ffi.METRIC_DOT}
 _KERNELS = {"auto": _ffi.KERNEL_AUTO, "wave": _ffi.KERNEL_WAVE, "mfma": _ffi.KERNEL_MFMA}
+STAGING_SOURCE = -(1 << 63)  # PCV_STAGING_SOURCE
 
 
 @dataclass(frozen=True)
@@ -86,11 +87,21 @@ class Searcher:
     def rebuild_source(self, rows, source_id):
         """Searcher::rebuild_source (search.rs:58-79): rows of other sources are ignored
         (search.rs:106-109); an empty replacement leaves the source absent."""
-        _ffi.check(_ffi.lib().pcv_searcher_clear_source(self._handle, int(source_id)))
-        self._insert((r for r in rows if int(r[1]) == int(source_id)))
+        # search.rs:57-79 builds the new index first and swaps it in only once it exists: the replacement is staged
+        # under PCV_STAGING_SOURCE, so that a bad row leaves the old rows of the source in place
+        lib, staging = _ffi.lib(), STAGING_SOURCE
+        _ffi.check(lib.pcv_searcher_clear_source(self._handle, staging))
+        try:
+            self._insert((r for r in rows if int(r[1]) == int(source_id)), into=staging)
+            self.finalize()
+        except Exception:
+            lib.pcv_searcher_clear_source(self._handle, staging)
+            lib.pcv_searcher_finalize(self._handle)
+            raise
+        _ffi.check(lib.pcv_searcher_replace_source(self._handle, staging, int(source_id)))
         self.finalize()
 
-    def _insert(self, rows):
+    def _insert(self, rows, into=None):
         by_source = {}
         for item_id, source_id, emb in rows:
             v = deserialize_embedding(emb) if isinstance(emb, (bytes, bytearray, memoryview)) else np.asarray(
@@ -98,7 +109,7 @@ class Searcher:
             )
             if v.shape != (self.dim,):
                 raise ValueError(f"embedding of item {item_id} has shape {v.shape}, index is {self.dim}-d")
-            ids, vecs = by_source.setdefault(int(source_id), ([], []))
+            ids, vecs = by_source.setdefault(int(source_id) if into is None else into, ([], []))
             ids.append(int(item_id))
             vecs.append(v)
         for source_id, (ids, vecs) in by_source.items():
@@ -130,8 +141,13 @@ class Searcher:
         """Announce that `n_rows` more rows are about to be added to `source_id` (one device segment for them)."""
         _ffi.check(_ffi.lib().pcv_searcher_reserve(self._handle, int(source_id), int(n_rows)))
 
-    def add_synthetic(self, source_id, n, seed, first_row=0, normalize=False, n_clusters=0, noise=0.0):
-        """Rows generated on the device.  n_clusters > 0: clustered rows (centroid/sqrt(dim) + noise * row)."""
+    def add_synthetic(self, source_id, n, seed, first_row=0, normalize=False, n_clusters=0, noise=0.0, amplitude=None):
+        """Rows generated on the device.  n_clusters > 0: clustered rows (centroid/sqrt(dim) + noise * row);
+        amplitude=(lo, hi): un-normalised rows a(row) * row with a uniform in [lo, hi) (norms spread: dot-metric corpora)."""
+        if amplitude is not None:
+            _ffi.check(_ffi.lib().pcv_searcher_add_synthetic_scaled(self._handle, int(source_id), int(n), int(seed), int(first_row),
+                                                                  float(amplitude[0]), float(amplitude[1])))
+            return
         _ffi.check(
             _ffi.lib().pcv_searcher_add_synthetic_clustered(
                 self._handle, int(source_id), int(n), int(seed), int(first_row), 1 if normalize else 0,
@@ -198,6 +214,11 @@ class Searcher:
         over = C.c_int()
         _ffi.check(_ffi.lib().pcv_searcher_search_device_end(self._handle, C.byref(over)))
         return bool(over.value)
+
+    def repeat_without_guess(self):
+        """A sharded step is repeated because some rank's pass was incomplete: this rank's repeat runs without a
+        speculative start threshold too (pcv_searcher_repeat_without_guess)."""
+        _ffi.check(_ffi.lib().pcv_searcher_repeat_without_guess(self._handle))
 
     def search_sharded(self, comm, sources, num_results, vectors):
         """Collective exact top-k over every rank's shard (pcv_searcher_search_sharded): local pass,

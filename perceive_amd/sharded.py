@@ -169,9 +169,10 @@ class ShardedSearcher:
                 self.searcher.search_device_end()
                 if not over:  # the same on every rank: it travelled with the hits
                     return ids, scores, counts
+                self.searcher.repeat_without_guess()  # on every rank: failed guesses must not take turns between the ranks
                 attempts -= 1
                 if attempts == 0:
-                    raise RuntimeError("candidate lists still overflow after 8 reruns")
+                    raise RuntimeError("the sharded step is still incomplete on some rank after 8 repeats (candidate lists keep overflowing)")
             self.searcher.search_device(sources, k, q, local.data_ptr())  # returns after its stream drained
             self._all_gather(gathered[: self.world * n], local[:n])
             torch.cuda.current_stream().synchronize()

@@ -57,6 +57,7 @@ pub struct pcv_scan_stats {
     pub bytes_streamed: i64,
     pub speculation_reruns: i32,
     pub reserved0: i32,
+    pub coarse_survivors: i64,
 }
 
 #[repr(C)]
@@ -106,6 +107,7 @@ pub const PCV_SCREEN_COPY_OFF: c_int = 0;
 pub const PCV_SCREEN_COPY_BF16: c_int = 1;
 pub const PCV_SCREEN_COPY_AUTO: c_int = 2;
 pub const PCV_SCREEN_COPY_INT8: c_int = 3;
+pub const PCV_MAX_RESULTS: c_int = 128;
 pub const PCV_GELU_ERF: c_int = 0;
 pub const PCV_GELU_TANH: c_int = 1;
 pub const PCV_POOL_MEAN: c_int = 0;
@@ -122,6 +124,7 @@ pub const PCV_TENSOR_F16: c_int = 1;
 pub const PCV_TENSOR_BF16: c_int = 2;
 pub const PCV_TENSOR_F64: c_int = 3;
 pub const PCV_TENSOR_OTHER: c_int = 4;
+pub const PCV_STAGING_SOURCE: i64 = i64::MIN;
 
 pub type pcv_tensor_visitor = Option<unsafe extern "C" fn(user: *mut c_void, name: *const c_char, shape: *const i64, rank: c_int, dtype: c_int, values: *const f32, numel: i64) -> c_int>;
 
@@ -147,8 +150,10 @@ extern "C" {
     pub fn pcv_searcher_add_blobs(s: *mut pcv_searcher, source_id: i64, ids: *const i64, blobs: *const u8, n: i64) -> c_int;
     pub fn pcv_searcher_add_synthetic(s: *mut pcv_searcher, source_id: i64, n: i64, seed: u64, first_row: i64, normalize: c_int) -> c_int;
     pub fn pcv_searcher_add_synthetic_clustered(s: *mut pcv_searcher, source_id: i64, n: i64, seed: u64, first_row: i64, normalize: c_int, n_clusters: c_int, noise: f32) -> c_int;
+    pub fn pcv_searcher_add_synthetic_scaled(s: *mut pcv_searcher, source_id: i64, n: i64, seed: u64, first_row: i64, amp_lo: f32, amp_hi: f32) -> c_int;
     pub fn pcv_searcher_reserve(s: *mut pcv_searcher, source_id: i64, n_rows: i64) -> c_int;
     pub fn pcv_searcher_clear_source(s: *mut pcv_searcher, source_id: i64) -> c_int;
+    pub fn pcv_searcher_replace_source(s: *mut pcv_searcher, from_source_id: i64, to_source_id: i64) -> c_int;
     pub fn pcv_searcher_finalize(s: *mut pcv_searcher) -> c_int;
     pub fn pcv_searcher_load_sqlite(s: *mut pcv_searcher, db_path: *const c_char, model_id: u32, model_version: u32, only_source: *const i64, out_rows: *mut i64) -> c_int;
     pub fn pcv_searcher_dim(s: *mut pcv_searcher, out_dim: *mut c_int) -> c_int;
@@ -167,6 +172,7 @@ extern "C" {
     pub fn pcv_searcher_search_device(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void, async_: c_int) -> c_int;
     pub fn pcv_searcher_search_device_begin(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void) -> c_int;
     pub fn pcv_searcher_search_device_end(s: *mut pcv_searcher, out_overflowed: *mut c_int) -> c_int;
+    pub fn pcv_searcher_repeat_without_guess(s: *mut pcv_searcher) -> c_int;
     pub fn pcv_merge_topk(ctx: *mut pcv_ctx, metric: c_int, dim: c_int, d_lists: *const c_void, n_shards: c_int, n_queries: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;
     pub fn pcv_merge_topk_flagged(ctx: *mut pcv_ctx, metric: c_int, dim: c_int, d_lists: *const c_void, n_shards: c_int, n_queries: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int, out_any_overflow: *mut c_int) -> c_int;
     pub fn pcv_merge_topk_host(metric: c_int, dim: c_int, lists: *const pcv_hit, n_shards: c_int, n_queries: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;

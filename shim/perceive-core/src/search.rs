@@ -50,7 +50,7 @@ impl Searcher {
             .collect::<Result<Vec<_>, _>>()?;
 
         let mut searcher = Searcher { handle: ptr::null_mut(), hidden: HashSet::default() };
-        searcher.load_sources(&conn, model_id, model_version, &sources)?;
+        searcher.load_sources(&conn, model_id, model_version, &sources, None)?;
         Ok(searcher)
     }
 
@@ -62,10 +62,22 @@ impl Searcher {
         model_version: u32,
     ) -> Result<(), eyre::Report> {
         let conn = database.read_pool.get()?;
-        if !self.handle.is_null() {
-            hip::check(unsafe { ffi::pcv_searcher_clear_source(self.handle, source_id) })?;
+        if self.handle.is_null() {
+            return self.load_sources(&conn, model_id, model_version, &[source_id], None);
         }
-        self.load_sources(&conn, model_id, model_version, &[source_id])?;
+        // search.rs:57-79 builds the new SourceSearch first and swaps it in only on success: the replacement is staged
+        // under PCV_STAGING_SOURCE; after a failure (a blob of the wrong size, an SQLite error) the old rows of the
+        // source are still searchable.
+        hip::check(unsafe { ffi::pcv_searcher_clear_source(self.handle, ffi::PCV_STAGING_SOURCE) })?;
+        if let Err(e) = self.load_sources(&conn, model_id, model_version, &[source_id], Some(ffi::PCV_STAGING_SOURCE)) {
+            unsafe {
+                ffi::pcv_searcher_clear_source(self.handle, ffi::PCV_STAGING_SOURCE);
+                ffi::pcv_searcher_finalize(self.handle);
+            }
+            return Err(e);
+        }
+        hip::check(unsafe { ffi::pcv_searcher_replace_source(self.handle, ffi::PCV_STAGING_SOURCE, source_id) })?;
+        hip::check(unsafe { ffi::pcv_searcher_finalize(self.handle) })?;
         Ok(())
     }
 
@@ -78,6 +90,7 @@ impl Searcher {
         model_id: u32,
         model_version: u32,
         sources: &[i64],
+        into: Option<i64>, // Some(id): every row goes to that (staging) source instead of its own
     ) -> Result<(), eyre::Report> {
         let mut stmt = conn.prepare(
             r##"SELECT items.id, source_id, embedding
@@ -106,11 +119,11 @@ impl Searcher {
             ids.push(id);
             bytes.extend_from_slice(blob);
             if ids.len() >= BUILD_CHUNK_ROWS {
-                self.flush(source_id, ids, bytes)?;
+                self.flush(into.unwrap_or(source_id), ids, bytes)?;
             }
         }
         for (source_idx, (ids, bytes)) in pending.iter_mut().enumerate() {
-            self.flush(sources[source_idx], ids, bytes)?;
+            self.flush(into.unwrap_or(sources[source_idx]), ids, bytes)?;
         }
         if !self.handle.is_null() {
             hip::check(unsafe { ffi::pcv_searcher_finalize(self.handle) })?;
@@ -134,7 +147,20 @@ impl Searcher {
         if self.handle.is_null() || num_results == 0 {
             return Vec::new();
         }
-        let k = num_results.min(128); // the library's limit per call (kMaxK)
+        // the C ABI reads `dim` floats from the pointer: a vector of another width must not reach it (the reference
+        // works on slices and panics inside hnsw_rs on a width mismatch; so does this)
+        let mut dim: i32 = 0;
+        hip::check(unsafe { ffi::pcv_searcher_dim(self.handle, &mut dim) }).expect("searcher_dim failed");
+        assert_eq!(vector.len(), dim as usize, "search_vector: the query has {} values, the index is {}-d", vector.len(), dim);
+        // One call returns at most PCV_MAX_RESULTS (128) hits.  The reference has no such limit; its callers ask for 10
+        // (perceive-tauri main.rs:48) or 20 (perceive-cli cmd/search.rs:35-36).  More is not truncated silently:
+        assert!(
+            num_results <= ffi::PCV_MAX_RESULTS as usize,
+            "search_vector: num_results {} is above the {} hits one exact scan pass ranks",
+            num_results,
+            ffi::PCV_MAX_RESULTS
+        );
+        let k = num_results;
         let mut ids = vec![-1i64; k];
         let mut scores = vec![f32::NAN; k];
         let mut count: i32 = 0;

@@ -48,6 +48,7 @@ class Oracle:
         L.orc_deserialize_embedding.restype = C.c_size_t
         L.orc_synth_rows.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, _F]
         L.orc_synth_rows_clustered.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, _F]
+        L.orc_synth_rows_scaled.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_float, _F]
         L.orc_baseline_scan_fused.argtypes = [_F, C.c_int, _F, C.c_int64, C.c_int, C.c_int, C.c_int, _I, _F]
         L.orc_baseline_scan_fused.restype = C.c_double
         L.orc_baseline_scan_reference_shaped.argtypes = L.orc_baseline_scan_fused.argtypes
@@ -133,6 +134,11 @@ class Oracle:
     def synth_rows_clustered(self, seed, first_row, n, D, n_clusters, noise, normalize=False):
         out = np.empty((n, D), np.float32)
         self.lib.orc_synth_rows_clustered(seed, first_row, n, D, 1 if normalize else 0, n_clusters, noise, _fp(out))
+        return out
+
+    def synth_rows_scaled(self, seed, first_row, n, D, amp_lo, amp_hi):
+        out = np.empty((n, D), np.float32)
+        self.lib.orc_synth_rows_scaled(seed, first_row, n, D, amp_lo, amp_hi, _fp(out))
         return out
 
     def baseline_scan(self, queries, m, k, threads, shaped=False):

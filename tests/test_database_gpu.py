@@ -119,3 +119,84 @@ def test_calculate_embeddings_pipeline_hook(ctx, golden_dir):
     assert np.abs(got[:6] - got[6:12]).max() < 1e-6  # same document in another batch (other padding length)
     assert pa.EMBEDDING_BATCH_SIZE == 256
     m.close()
+
+
+def test_rebuild_of_one_source_is_atomic(ctx, oracle, tmp_path):
+    """search.rs:57-79 builds the new SourceSearch first and swaps it in only on success.  A replacement with one blob of
+    the wrong size (or any SQLite error on the way) must leave the old rows of that source searchable, through the
+    library's own loader (pcv_searcher_load_sqlite) and through the row-stream form (Searcher.rebuild_source)."""
+    rng = np.random.default_rng(3)
+    D, N = 64, 300
+    emb = rng.standard_normal((N, D)).astype(np.float32)
+    path = str(tmp_path / "p.sqlite3")
+    conn = sqlite3.connect(path)
+    conn.executescript(SCHEMA)
+    conn.executemany("INSERT INTO sources (id, name) VALUES (?, ?)", [(1, "a"), (2, "b")])
+    src = np.where(np.arange(N) % 3 == 0, 2, 1)
+    for i in range(N):
+        conn.execute("INSERT INTO items (id, source_id, external_id, content) VALUES (?,?,?,?)", (i, int(src[i]), f"d{i}", "c"))
+        conn.execute("INSERT INTO item_embeddings VALUES (0, 0, ?, 1, ?)", (i, pa.serialize_embedding(emb[i])))
+    conn.commit()
+    db = pa.Database(path)
+    s = pa.build_searcher(ctx, db, 0, 0, metric="dot")
+    q = rng.standard_normal((5, D)).astype(np.float32)
+    before = [s.search_vectors(f, 10, q) for f in (None, [1], [2])]
+    # source 2's replacement: 40 good rows, then one blob of the wrong size
+    conn.execute("DELETE FROM item_embeddings WHERE item_id IN (SELECT id FROM items WHERE source_id = 2 AND id > 150)")
+    conn.execute("UPDATE item_embeddings SET embedding = ? WHERE item_id = 150", (b"\0" * (4 * D - 4),))
+    conn.commit()
+    with pytest.raises(pa.PcvError, match="bytes"):
+        pa.rebuild_source(s, db, 2, 0, 0)
+    assert s.num_rows == N and sorted(s.source_ids) == [1, 2]  # nothing of the half-built replacement is left
+    for f, ref in zip((None, [1], [2]), before):
+        got = s.search_vectors(f, 10, q)
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+    # the row-stream form: a row of the wrong width in the middle of the stream
+    rows = [(1000 + i, 2, emb[i]) for i in range(20)] + [(9999, 2, emb[0][:-1])] + [(2000 + i, 2, emb[i]) for i in range(20)]
+    with pytest.raises(ValueError):
+        s.rebuild_source(rows, 2)
+    assert s.num_rows == N
+    np.testing.assert_array_equal(s.search_vectors([2], 10, q)[0], before[2][0])
+    # a good replacement goes in, the other source keeps its place and its hits
+    conn.execute("UPDATE item_embeddings SET embedding = ? WHERE item_id = 150", (pa.serialize_embedding(emb[150]),))
+    conn.commit()
+    pa.rebuild_source(s, db, 2, 0, 0)
+    keep2 = np.array([i for i in range(N) if src[i] == 2 and i <= 150])
+    assert s.source_num_rows(2) == keep2.size and s.source_num_rows(1) == int((src == 1).sum())
+    np.testing.assert_array_equal(s.search_vectors([1], 10, q)[0], before[1][0])
+    oi, _ = oracle.search_vector(q[0], emb[keep2], keep2, np.full(keep2.size, 2), [2], 10)
+    assert list(s.search_vectors([2], 10, q[:1])[0][0]) == list(oi)
+    conn.close()
+    s.close()
+
+
+def test_replace_source_swaps_and_keeps_the_order_of_sources(ctx, oracle):
+    """pcv_searcher_replace_source: `from` takes `to`'s place (global positions of the other sources do not move), an unknown
+    or empty `from` leaves `to` absent (search.rs:67-69), a source cannot replace itself."""
+    from perceive_amd import _ffi
+
+    rng = np.random.default_rng(5)
+    D = 32
+    a, b, c, n = (rng.standard_normal((m, D)).astype(np.float32) for m in (50, 70, 30, 40))
+    s = pa.Searcher(ctx, D, "cosine")
+    s.add_rows(1, a, np.arange(50))
+    s.add_rows(2, b, 100 + np.arange(70))
+    s.add_rows(3, c, 200 + np.arange(30))
+    s.add_rows(pa.search.STAGING_SOURCE, n, 300 + np.arange(40))
+    s.finalize()
+    _ffi.check(_ffi.lib().pcv_searcher_replace_source(s._handle, pa.search.STAGING_SOURCE, 2))
+    with pytest.raises(pa.PcvError):  # dirty until finalize
+        s.search_vectors(None, 5, a[:1])
+    s.finalize()
+    assert s.source_ids == [1, 2, 3] and s.num_rows == 120
+    rows, ids = s.get_rows(np.arange(120))
+    np.testing.assert_array_equal(rows, np.concatenate([a, n, c]))  # source 2's new rows sit where its old ones did
+    np.testing.assert_array_equal(ids, np.concatenate([np.arange(50), 300 + np.arange(40), 200 + np.arange(30)]))
+    q = rng.standard_normal((3, D)).astype(np.float32)
+    np.testing.assert_array_equal(s.search_vectors(None, 7, q)[0], ids[oracle.topk(q, rows, 7)[0]])
+    _ffi.check(_ffi.lib().pcv_searcher_replace_source(s._handle, 777, 3))  # unknown `from`: source 3 disappears
+    s.finalize()
+    assert s.source_ids == [1, 2] and s.num_rows == 90
+    assert _ffi.lib().pcv_searcher_replace_source(s._handle, 1, 1) != 0
+    s.close()

@@ -165,7 +165,7 @@ def _code(path):
 def test_wrappers_call_only_declared_functions_and_are_balanced():
     declared = set(rust_functions())
     used = set()
-    for f in ("hip.rs", "model.rs", "search.rs", "configs.rs"):
+    for f in ("hip.rs", "model.rs", "search.rs", "configs.rs", "similarity.rs"):
         code = _code(os.path.join(SHIM, "src", f))
         for a, b in ("{}", "()", "[]"):
             assert code.count(a) == code.count(b), (f, a, code.count(a), code.count(b))
@@ -174,8 +174,28 @@ def test_wrappers_call_only_declared_functions_and_are_balanced():
     # the calls the hot path needs are there
     for need in ("pcv_init", "pcv_model_create_from_dir", "pcv_model_encode_text", "pcv_model_highlight", "pcv_model_destroy",
                  "pcv_searcher_create", "pcv_searcher_add_blobs", "pcv_searcher_clear_source", "pcv_searcher_finalize",
-                 "pcv_searcher_search", "pcv_searcher_destroy", "pcv_serialize_embedding", "pcv_deserialize_embedding"):
+                 "pcv_searcher_search", "pcv_searcher_destroy", "pcv_serialize_embedding", "pcv_deserialize_embedding",
+                 "pcv_searcher_replace_source", "pcv_searcher_dim", "pcv_dot_product", "pcv_cosine_similarity"):
         assert need in used, need
+
+
+def test_crate_level_similarity_functions_and_documented_signature_change():
+    """lib.rs:63-77 (dot_product, cosine_similarity_{single,multi}_query) exist over the C ABI, and the one public
+    signature that changes — new_pretrained's error type (model.rs:68) — is written down with the call sites it touches."""
+    sim = open(os.path.join(SHIM, "src", "similarity.rs")).read()
+    for pat in (r"pub fn dot_product\(set1: &Embeddings, set2: &Embeddings\) -> Embeddings",
+                r"pub fn cosine_similarity_single_query\(query: &Embeddings, matches: &Embeddings\) -> Embeddings",
+                r"pub fn cosine_similarity_multi_query\(set1: &Embeddings, set2: &Embeddings\) -> Embeddings"):
+        assert re.search(pat, sim), pat
+    readme = open(os.path.join(SHIM, "README.md")).read()
+    for need in ("RustBertError", "ModelError", "perceive-cli/state.rs:46-48", "perceive-tauri/src-tauri/main.rs:76", "similarity.rs"):
+        assert need in readme, need
+    # rebuild_source stages the replacement and swaps (search.rs:57-79); search_vector checks the query width before the FFI call
+    search = _code(os.path.join(SHIM, "src", "search.rs"))
+    body = search[search.index("pub fn rebuild_source"):search.index("fn load_sources")]
+    assert body.index("PCV_STAGING_SOURCE") < body.index("pcv_searcher_replace_source") and "pcv_searcher_clear_source(self.handle, source_id)" not in body
+    sv = search[search.index("pub fn search_vector("):search.index("pub fn search(")]
+    assert sv.index("pcv_searcher_dim") < sv.index("pcv_searcher_search(") and "assert_eq!(vector.len()" in sv and ".min(128)" not in sv
 
 
 def test_public_surface_of_the_reference_is_kept():

@@ -58,7 +58,8 @@ def test_golden_1000(ctx, oracle, g1000, kernel, B, screen):
     mfma = kernel == "mfma" or (kernel == "auto" and (B > 4 or screen != "off"))  # with copies the MFMA kernel streams fewer bytes
     assert st["kernel_used"] == (2 if mfma else 1)
     assert st["screening_copy"] == ({"int8": 2, "bf16": 1, "off": 0}[screen] if mfma else 0)
-    assert st["bytes_streamed"] == st["rows_scanned"] * 384 * {0: 4, 1: 2, 2: 1}[st["screening_copy"]]
+    nblk = (st["rows_scanned"] + 31) // 32  # per 32-row block: f32 pieces + 32 scales | bf16 pieces | int8 pieces + 36 scale floats
+    assert st["bytes_streamed"] == nblk * {0: 384 * 4 * 32 + 128, 1: 384 * 2 * 32, 2: 384 * 32 + 144}[st["screening_copy"]]
     assert st["rows_scanned"] >= 1000 and st["overflow_reruns"] == 0
     s.close()
 
@@ -773,6 +774,60 @@ def test_concurrent_searches_from_threads(ctx, oracle):
     for i in range(8):
         np.testing.assert_array_equal(got[i], exp[i])
     s.close()
+
+
+_TWO_CONTEXTS = r"""
+import sys, threading
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import oracle_ffi
+import perceive_amd as pa
+orc = oracle_ffi.load()
+rng = np.random.default_rng(7)
+m = rng.standard_normal((6000, 384)).astype(np.float32)
+wide = rng.standard_normal((600, 8192)).astype(np.float32)
+q = rng.standard_normal((200, 384)).astype(np.float32)     # 200 queries: the 102 KB tile of scan_mfma8_hold_kernel<3,4>
+qw = rng.standard_normal((4, 8192)).astype(np.float32)     # 4 x 8192-d: 128 KB of queries in scan_wave_kernel
+exp, expw = orc.topk(q, m, 10)[0], orc.topk(qw, wide, 5)[0]
+go = threading.Barrier(2)
+out, errs = {}, []
+def work(i):
+    try:
+        ctx = pa.Context(0)                                   # a context of its own per thread (same device)
+        s = pa.Searcher(ctx, 384, "cosine"); s.add_rows(1, m); s.finalize()
+        w = pa.Searcher(ctx, 8192, "cosine"); w.add_rows(1, wide); w.finalize()
+        go.wait()                                             # both threads launch each kernel for the first time together
+        a = s.search_vectors(None, 10, q)[0]
+        go.wait()
+        b = w.search_vectors(None, 5, qw)[0]
+        out[i] = (a, b, s.last_stats()["screening_copy"], w.last_stats()["kernel_used"])
+        s.close(); w.close(); ctx.close()
+    except Exception as e:
+        errs.append(repr(e))
+        try: go.abort()
+        except Exception: pass
+th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+[t.start() for t in th]; [t.join() for t in th]
+assert not errs, errs
+for i in range(2):
+    a, b, copy, kern = out[i]
+    assert copy == 2 and kern == 1, (copy, kern)
+    assert (a == exp).all() and (b == expw).all()
+print("two contexts ok")
+"""
+
+
+def test_two_contexts_two_threads_first_use_of_large_lds_kernels():
+    """Kernels that need more than 64 KB of dynamic LDS are allowed that per device, under a lock, at first use
+    (common.h: allow_dynamic_lds) — not through unsynchronised function statics.  In a fresh process (no kernel has run yet)
+    two threads, each with a context and searchers of its own, launch the 102 KB-tile int8 scan and the 128 KB wave scan
+    for the first time at the same moment."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _TWO_CONTEXTS, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "two contexts ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_create_destroy_does_not_leak(ctx):

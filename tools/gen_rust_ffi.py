@@ -123,6 +123,8 @@ def main():
         lines += ["}", ""]
     for name, value in enums(text):
         lines.append(f"pub const {name}: c_int = {value};")
+    for m in re.finditer(r"#define\s+(PCV_\w+)\s+INT64_MIN\b", strip_comments(text)):
+        lines.append(f"pub const {m.group(1)}: i64 = i64::MIN;")
     lines.append("")
     for ret, name, params in callbacks(text):
         SCALARS[name] = name
