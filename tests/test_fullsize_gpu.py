@@ -210,3 +210,58 @@ def test_config5_encode_256x256_then_search(ctx, big, oracle):
     st = big.last_stats()
     assert st["scan_launches"] == 1 and (cnt == 10).all() and st["overflow_reruns"] == 0
     _verify_topk(big, oracle, emb[[0, 100, 255]], got[[0, 100, 255]], sc[[0, 100, 255]], 10, N, rng, sample=128)
+
+
+def test_product_default_shape_768d_dot_unnormalised_10m(ctx, oracle):
+    """The reference's default model is MsMarcoBertBaseDotV5 (perceive-cli/state.rs:24): 768-d, dot metric with the distance
+    max(0, 1 - dot/len) (search.rs:266-279), rows NOT normalised.  10M rows whose norms spread over x[0.5, 2): batches of 1,
+    64, 128 and 200 queries through the int8 screen (whose margin scales with the row norms), against the independent f32
+    wave kernel and the copy-less MFMA scan; every score re-derived by the oracle from the rows read back; planted rows."""
+    n, d, k, seed, amp = 10_000_000, 768, 10, 0xD07, (0.5, 2.0)
+    s = pa.Searcher(ctx, d, "dot")
+    s.add_synthetic(1, n, seed, amplitude=amp)
+    s.finalize()
+    rng = np.random.default_rng(768)
+    twin = oracle.synth_rows_scaled(seed, 123_456, 3, d, *amp)
+    back, _ = s.get_rows(np.array([123_456, 123_457, 123_458]))
+    np.testing.assert_array_equal(back, twin)  # generator twins agree bit for bit
+    norms = np.linalg.norm(s.get_rows(rng.integers(0, n, 2000))[0], axis=1) / np.sqrt(d)
+    assert norms.min() < 0.6 and norms.max() > 1.9  # the amplitudes really spread
+
+    def verify(q, ids, dist, sample=256):
+        rows, rid = s.get_rows(ids.reshape(-1))
+        np.testing.assert_array_equal(rid, ids.reshape(-1))
+        samp = rng.integers(0, n, sample)
+        srows, _ = s.get_rows(samp)
+        for b in range(q.shape[0]):
+            dots = np.array([oracle.canonical_score(q[b], rows[b * k + j], 1) for j in range(k)])
+            assert (np.diff(dots) <= 0).all()  # best (largest dot product) first = ascending distance (search.rs:179)
+            np.testing.assert_allclose(dist[b], np.maximum(0.0, 1.0 - dots / d).astype(np.float32), atol=1e-6)
+            others = np.array([oracle.canonical_score(q[b], r, 1) for r in srows])
+            assert set(samp[others > dots[-1]]) <= set(ids[b])
+
+    results = {}
+    for B in (1, 64, 128, 200):
+        q = rng.standard_normal((B, d)).astype(np.float32)
+        if B >= 64:  # planted: a query that IS a stored row of large norm ranks itself first (dot = |x|^2)
+            q[3] = s.get_rows(np.array([n - 1]))[0][0] * 4.0
+        ids, dist, cnt = s.search_vectors(None, k, q)
+        st = s.last_stats()
+        assert st["kernel_used"] == 2 and st["screening_copy"] == 2 and st["overflow_reruns"] == 0 and (cnt == k).all(), st
+        assert st["scan_launches"] == (1 if B <= 128 else 2)  # 768-d: a pass takes 128 queries
+        pick = np.arange(B) if B <= 8 else np.array([0, 3, B // 2, B - 1])
+        verify(q[pick], ids[pick], dist[pick])
+        results[B] = (q, ids, dist)
+    q, ids, dist = results[64]
+    s.set_kernel("wave")  # the independent f32 kernel, 16 passes of 4 queries
+    iw, dw, _ = s.search_vectors(None, k, q)
+    np.testing.assert_array_equal(ids, iw)
+    np.testing.assert_array_equal(dist, dw)
+    s.set_kernel("mfma")
+    s.set_screening_copy("off")  # the bf16 MFMA screen fed from the f32 rows
+    q, ids, dist = results[128]
+    im, dm, _ = s.search_vectors(None, k, q)
+    assert s.last_stats()["screening_copy"] == 0
+    np.testing.assert_array_equal(ids, im)
+    np.testing.assert_array_equal(dist, dm)
+    s.close()
