@@ -1561,6 +1561,158 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
     }
 }
 
+// The block-holding scan with TWO held blocks per wave (DB form): while a wave multiplies the block it holds with the NH
+// halves of the query tile, ALL chunks of its next block are already on their way into a second set of registers — 24 KB in
+// flight per wave for the whole time a block takes, instead of chunk by chunk during the last half only (which left the
+// 256-query pass waiting on memory after every block: 3.2 TB/s).  Two register sets put the kernel at ~200 registers:
+// 2 waves per SIMD, i.e. one 512-thread workgroup per CU for the 102 KB tile of 256 queries, two 256-thread workgroups for
+// the 51 KB tile of 128.  The thresholds of a block's NH halves are fetched BEFORE its successor is requested: vmcnt retires
+// in order, so a threshold load issued behind the prefetch would make the first epilogue wait for the whole next block.
+template <bool NTL, int NCH, int NH>
+__global__ __launch_bounds__(NH == 2 ? 256 : 512, 2) void scan_mfma8_hold2_kernel(const ScanParams* __restrict__ pp) {
+    const ScanParams& p = *pp;
+    constexpr int TQ = NH * 64;
+    constexpr int WPB = NH == 2 ? 4 : 8;
+    extern __shared__ uint4 lq8[];  // [TQ][LDQ] pieces of 16 int8
+    constexpr int P16 = NCH * 8;
+    constexpr int LDQ = P16 + 1;
+    const int D4 = p.D4;
+    __shared__ uint32_t ltau0[TQ];
+    __shared__ float lsq[TQ], lvq[TQ], le32[TQ];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < TQ * P16; i += WPB * 64) {
+        const int q = i / P16, pc = i - q * P16;
+        lq8[(size_t)q * LDQ + pc] = __builtin_bit_cast(uint4, gld4((const float4*)p.q8 + i));
+    }
+    for (int q = threadIdx.x; q < TQ; q += WPB * 64) {
+        lsq[q] = gld(&p.q8c[2 * q]);
+        lvq[q] = gld(&p.q8c[2 * q + 1]);
+        le32[q] = q < p.B ? 0.5f * gld(&p.margin32[q]) : 0.0f;
+    }
+    for (int q = threadIdx.x >> 2; q < TQ; q += WPB * 16) {
+        const uint32_t key = seed_threshold_key(p, q, threadIdx.x & 3);
+        if ((threadIdx.x & 3) == 0) ltau0[q] = key;
+    }
+    __syncthreads();
+    const int c = lane & 31, h = lane >> 5;
+    const float nrm = (p.metric == PCV_METRIC_DOT) ? p.max_norm : 1.0f;
+    const float c1 = 0.5002f * sqrtf((float)(NCH * 128)) * nrm;
+    const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
+
+    const uint32_t total_waves = gridDim.x * WPB;
+    uint32_t gb = blockIdx.x * WPB + wave;  // the block being REQUESTED next
+    if (gb >= p.total_blocks) return;
+    SegCursor sc;  // segment of `gb`
+    // what is known of a held block: where it lives (for its survivors) and the scales of its rows
+    struct Held {
+        int si;
+        uint32_t lb;
+        const float* scale;
+        const float4* blk;
+        float srv;
+        float2 smm;
+    };
+    auto request = [&](float4 (&buf)[NCH][4], Held& hd) {  // all chunks + scales of block gb; gb moves on
+        seek_seg(p, sc, gb);
+        const uint32_t lb = gb - sc.begin;
+        const float4* base = (const float4*)sc.blk8 + (size_t)lb * P16 * 32 + h * 32 + c;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) buf[ch][i] = ld_row<NTL>(base + (size_t)(ch * 8 + i * 2) * 32);
+        const float* s8 = sc.scale8 + (size_t)lb * kScale8Stride;
+        hd.srv = gld(s8 + 16 * h + (lane & 15));
+        hd.smm.x = gld(s8 + 32 + 2 * h);
+        hd.smm.y = gld(s8 + 33 + 2 * h);
+        hd.si = sc.si;
+        hd.lb = lb;
+        hd.scale = sc.scale;
+        hd.blk = sc.blk;
+        gb += total_waves;
+    };
+    // one held block against the whole tile; `nxt` is requested first (if there is one)
+    auto work = [&](const float4 (&buf)[NCH][4], const Held& hd, float4 (&nbuf)[NCH][4], Held& nhd) {
+        uint32_t tauk[NH][2];
+#pragma unroll
+        for (int half = 0; half < NH; ++half)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int q = 64 * half + 32 * t + c;
+                tauk[half][t] = (q < p.B) ? max(ltau0[q], ld_relaxed(&p.tau[q * kHot])) : 0u;
+            }
+        const bool more = gb < p.total_blocks;
+        if (more) request(nbuf, nhd);
+        SegCursor esc;  // (fine_survivors reads si, scale and blk of it)
+        esc.si = hd.si;
+        esc.scale = hd.scale;
+        esc.blk = hd.blk;
+#pragma unroll
+        for (int half = 0; half < NH; ++half) {
+            const int q0 = 64 * half + c;
+            i32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = 0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const i32x4 a = __builtin_bit_cast(i32x4, buf[ch][ks]);
+                    const int pc = 2 * (ch * 4 + ks) + h;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const i32x4 q8 = *(const i32x4*)&lq8[(size_t)(q0 + 32 * t) * LDQ + pc];
+                        acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (or the scheduler fetches every query piece of the half first)
+            }
+            float U[2], vq[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int q = q0 + 32 * t;
+                const float sq = lsq[q];
+                vq[t] = lvq[q];
+                const float T = (key_f32(tauk[half][t]) - le32[q]) * sq;
+                U[t] = (q < p.B) ? (sq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
+            }
+            bool hot = false;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                int m = acc[t][0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
+                hot |= (float)m >= fmaf(U[t] >= 0.0f ? hd.smm.x : hd.smm.y, U[t], -vq[t]);
+            }
+            if (__any(hot)) {
+                uint32_t mask[2] = {0u, 0u};
+#define PCV_TEST(I)                                                                                                            \
+    {                                                                                                                          \
+        const float s_row = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hd.srv), 0x150 + I, 0xf, 0xf, false)); \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) mask[t] |= ((float)acc[t][I] >= fmaf(s_row, U[t], -vq[t])) ? (1u << I) : 0u;  \
+    }
+                PCV_TEST(0) PCV_TEST(1) PCV_TEST(2) PCV_TEST(3) PCV_TEST(4) PCV_TEST(5) PCV_TEST(6) PCV_TEST(7)
+                PCV_TEST(8) PCV_TEST(9) PCV_TEST(10) PCV_TEST(11) PCV_TEST(12) PCV_TEST(13) PCV_TEST(14) PCV_TEST(15)
+#undef PCV_TEST
+                if (__any((mask[0] | mask[1]) != 0)) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) fine_survivors(p, mask[t], 2 * half + t, esc, hd.lb, ltau0, lane, D4);
+                }
+            }
+        }
+        return more;
+    };
+    float4 bufA[NCH][4], bufB[NCH][4];
+    Held hA, hB;
+    request(bufA, hA);
+    while (true) {
+        if (!work(bufA, hA, bufB, hB)) return;
+        if (!work(bufB, hB, bufA, hA)) return;
+    }
+}
+
 __device__ __forceinline__ bool better(double sa, int64_t pa, double sb, int64_t pb) {
     return sa > sb || (sa == sb && pa < pb);
 }
@@ -2072,10 +2224,10 @@ int mfma8_pass_queries(int Dp) {
     return 0;
 }
 
-template <int NT, bool NTL, int NBUF = (NT == 2 ? 3 : 4)>  // 64 queries: three chunk buffers leave the registers the block pre-test needs
+template <int NT, bool NTL, int WPB = 4, int NBUF = (NT == 2 ? 3 : 4)>  // 64 queries: three chunk buffers leave the registers the block pre-test needs
 static void launch_mfma8_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
-    allow_dynamic_lds((const void*)scan_mfma8_kernel<NT, NTL, 4, NBUF>, lds);
-    scan_mfma8_kernel<NT, NTL, 4, NBUF><<<grid, 256, lds, st>>>(dp);
+    allow_dynamic_lds((const void*)scan_mfma8_kernel<NT, NTL, WPB, NBUF>, lds);
+    scan_mfma8_kernel<NT, NTL, WPB, NBUF><<<grid, WPB * 64, lds, st>>>(dp);
 }
 
 void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
@@ -2086,8 +2238,12 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
     const bool ntl = (p.flags & 1) == 0;
     const unsigned most = NT == 4 ? 2 : 3;  // waves per SIMD the register budget allows = 256-thread workgroups per CU
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(most, (156 * 1024) / lds));
+    // a 128-query tile that fits a CU only once (rows wider than 576 features: 100 KB at 768-d) is shared by eight waves,
+    // or the CU would run one wave per SIMD
+    const bool wide8 = NT == 4 && per_cu == 1;
+    const unsigned wpbt = wide8 ? 8 : 4;
     unsigned grid = (unsigned)num_cus * (gm ? gm : per_cu);
-    const unsigned need = (p.total_blocks + 3) / 4;
+    const unsigned need = (p.total_blocks + wpbt - 1) / wpbt;
     if (grid > need) grid = need;
     if (p.D4 * 4 > 1024) PCV_FAIL(PCV_ERR_UNSUPPORTED, "int8 screen: dimension %d is too large", p.D);
     quantize_queries_kernel<<<NT * 32 / 4, 256, 0, st>>>(dp);
@@ -2095,9 +2251,29 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
     const int nch = ((p.D4 * 4 + 127) & ~127) >> 7;
     if (p.B > 64 && nch <= 3 && (p.B > 128 || !(p.flags & 8u))) {  // (flag bit 3: the 128-query tile, for comparison)
         const bool four = p.B > 128;
+        const size_t ldsh = mfma8_lds(four ? 8 : 4, p.D4 * 4);
+        // two held blocks per wave (2 waves per SIMD) for the 256-query pass; flag bit 28: also for 128 queries; bit 29: never
+        const bool twoblk = !(p.flags & (1u << 29)) && (four || (p.flags & (1u << 28)));
+        if (twoblk) {
+            const unsigned wpb2 = four ? 8 : 4;
+            const unsigned g2 = std::min<unsigned>((unsigned)num_cus * (gm ? gm : (four ? 1u : 2u)), (p.total_blocks + wpb2 - 1) / wpb2);
+#define PCV_HOLD2(NCHV, NHV)                                                                           \
+    {                                                                                                  \
+        allow_dynamic_lds(ntl ? (const void*)scan_mfma8_hold2_kernel<true, NCHV, NHV> : (const void*)scan_mfma8_hold2_kernel<false, NCHV, NHV>, ldsh); \
+        if (ntl) scan_mfma8_hold2_kernel<true, NCHV, NHV><<<g2, NHV == 2 ? 256 : 512, ldsh, st>>>(dp); \
+        else scan_mfma8_hold2_kernel<false, NCHV, NHV><<<g2, NHV == 2 ? 256 : 512, ldsh, st>>>(dp);    \
+    }
+            if (four) {
+                if (nch == 3) PCV_HOLD2(3, 4) else if (nch == 2) PCV_HOLD2(2, 4) else PCV_HOLD2(1, 4)
+            } else {
+                if (nch == 3) PCV_HOLD2(3, 2) else if (nch == 2) PCV_HOLD2(2, 2) else PCV_HOLD2(1, 2)
+            }
+#undef PCV_HOLD2
+            PCV_LAUNCHED();
+            return;
+        }
         const unsigned wpb = four ? 12 : 4;
         const unsigned g3 = std::min<unsigned>((unsigned)num_cus * (gm ? gm : (four ? 1u : 3u)), (p.total_blocks + wpb - 1) / wpb);
-        const size_t ldsh = mfma8_lds(four ? 8 : 4, p.D4 * 4);
 #define PCV_HOLD(NCHV, NHV)                                                                           \
     {                                                                                                 \
         allow_dynamic_lds(ntl ? (const void*)scan_mfma8_hold_kernel<true, NCHV, NHV> : (const void*)scan_mfma8_hold_kernel<false, NCHV, NHV>, ldsh); \
@@ -2120,6 +2296,9 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
     } else if (NT == 2) {
         if (ntl) launch_mfma8_variant<2, true>(st, dp, grid, lds);
         else launch_mfma8_variant<2, false>(st, dp, grid, lds);
+    } else if (wide8) {
+        if (ntl) launch_mfma8_variant<4, true, 8>(st, dp, grid, lds);
+        else launch_mfma8_variant<4, false, 8>(st, dp, grid, lds);
     } else {
         if (ntl) launch_mfma8_variant<4, true>(st, dp, grid, lds);
         else launch_mfma8_variant<4, false>(st, dp, grid, lds);

@@ -1272,7 +1272,7 @@ pcv_status pcv_searcher_set_tuning(pcv_searcher* s, uint32_t flags) {
         std::lock_guard<std::mutex> lk(s->mu);
         PCV_REQUIRE(!s->pending.active, "set_tuning: a queued pass has not been collected");
         s->fail_copy_alloc = (flags & (uint32_t)PCV_TUNE_FAIL_COPY_ALLOC) != 0;
-        s->scan_flags = flags & 0x0fffffffu;
+        s->scan_flags = flags & 0x3fffffffu;
     });
 }
 

@@ -248,7 +248,7 @@ class Searcher:
     def set_tuning(self, flags=0, fail_copy_alloc=False):
         """Diagnostic / comparison switches (pcv_searcher_set_tuning): `flags` as PCV_SCAN_FLAGS (csrc/scan.h), e.g. 32 = no
         speculative start threshold; fail_copy_alloc: screening-copy allocations fail while set (tests)."""
-        _ffi.check(_ffi.lib().pcv_searcher_set_tuning(self._handle, (int(flags) & 0x0FFFFFFF) | ((1 << 30) if fail_copy_alloc else 0)))
+        _ffi.check(_ffi.lib().pcv_searcher_set_tuning(self._handle, (int(flags) & 0x3FFFFFFF) | ((1 << 30) if fail_copy_alloc else 0)))
 
     def set_screening_copy(self, mode="auto"):
         """"off" | "bf16" | "int8" | "auto" (= int8): keep a narrow copy of the scaled rows next to the f32 rows so that
