@@ -1417,7 +1417,10 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 // latency is covered by the rest of that half, its epilogue and the other eleven waves of the CU.
 // NH halves of 64 queries: 2 (up to 128 queries: 256-thread workgroups, three 51 KB tiles per CU) or 4 (up to 256 queries:
 // one 768-thread workgroup and one 102 KB tile per CU, the same 3 waves per SIMD) — one pass over the rows for 256 queries.
-template <bool NTL, int NCH, int NH>
+// PIPE > 0: the query pieces of a half are read from LDS PIPE multiplies ahead of their use, through PIPE + 1 rotating
+// registers sets, and the instruction scheduler is told to keep that order (one LDS read issued per multiply); PIPE = 0 leaves
+// the order to the compiler, which reads a piece one or two instructions before the multiply that needs it.
+template <bool NTL, int NCH, int NH, int PIPE = 0>
 __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
     constexpr int TQ = NH * 64;       // queries of the tile
@@ -1507,6 +1510,31 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
                 more = cur.gb < p.total_blocks;
                 if (more) enter();
             }
+            if constexpr (PIPE > 0) {
+                constexpr int NM = NCH * 8;  // multiplies of a half: piece kk = i >> 1 of the rows against tile t = i & 1
+                i32x4 bq[PIPE + 1];
+                const uint4* lrow = lq8 + (size_t)q0 * LDQ + h;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < PIPE; ++i) bq[i] = *(const i32x4*)&lrow[(size_t)(32 * (i & 1)) * LDQ + 2 * (i >> 1)];
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    if (i + PIPE < NM) bq[(i + PIPE) % (PIPE + 1)] = *(const i32x4*)&lrow[(size_t)(32 * ((i + PIPE) & 1)) * LDQ + 2 * ((i + PIPE) >> 1)];
+                    const int kk = i >> 1;
+                    const i32x4 a = __builtin_bit_cast(i32x4, buf[kk >> 2][kk & 3]);
+                    acc[i & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[i % (PIPE + 1)], acc[i & 1], 0, 0, 0);
+                    if ((i & 7) == 7 && half == NH - 1 && more) load_chunk(i >> 3);
+                }
+                // the order above, kept: PIPE reads, then (one multiply, one read) ..., the chunk's loads behind its last multiply
+                __builtin_amdgcn_sched_group_barrier(0x100, PIPE, 0);
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    if (i + PIPE < NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if ((i & 7) == 7 && half == NH - 1) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
@@ -1521,6 +1549,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
                 }
                 if (half == NH - 1 && more) load_chunk(ch);
                 __builtin_amdgcn_sched_barrier(0);  // (the scheduler would fetch all 2 * 4 * NCH query pieces first: 190 registers)
+            }
             }
             if (half == NH - 1 && more) load_scales();
             // epilogue of this half (scan_mfma8_kernel has the derivation)
@@ -2252,8 +2281,10 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
     if (p.B > 64 && nch <= 3 && (p.B > 128 || !(p.flags & 8u))) {  // (flag bit 3: the 128-query tile, for comparison)
         const bool four = p.B > 128;
         const size_t ldsh = mfma8_lds(four ? 8 : 4, p.D4 * 4);
-        // two held blocks per wave (2 waves per SIMD) for the 256-query pass; flag bit 28: also for 128 queries; bit 29: never
-        const bool twoblk = !(p.flags & (1u << 29)) && (four || (p.flags & (1u << 28)));
+        // flag bit 28 (comparison): two held blocks per wave at 2 waves per SIMD (scan_mfma8_hold2_kernel; measured slower: 12.7
+        // against 12.2 ms at 256 queries, 8.26 against 7.42 ms at 128 — the multiplies wait on LDS, not on HBM, and a third
+        // wave per SIMD hides more of that than a second block in flight)
+        const bool twoblk = (p.flags & (1u << 28)) != 0;
         if (twoblk) {
             const unsigned wpb2 = four ? 8 : 4;
             const unsigned g2 = std::min<unsigned>((unsigned)num_cus * (gm ? gm : (four ? 1u : 2u)), (p.total_blocks + wpb2 - 1) / wpb2);
@@ -2280,12 +2311,28 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
         if (ntl) scan_mfma8_hold_kernel<true, NCHV, NHV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp); \
         else scan_mfma8_hold_kernel<false, NCHV, NHV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp);    \
     }
+#define PCV_HOLDP(NHV, PV)                                                                            \
+    {                                                                                                 \
+        allow_dynamic_lds((const void*)scan_mfma8_hold_kernel<true, 3, NHV, PV>, ldsh);                \
+        scan_mfma8_hold_kernel<true, 3, NHV, PV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp);          \
+    }
+        const unsigned pipe = (p.flags >> 24) & 0xf;  // (tuning: LDS read-ahead of the 384-d forms)
+        if (nch == 3 && ntl && pipe) {
+            if (four) {
+                if (pipe == 3) PCV_HOLDP(4, 3) else PCV_HOLDP(4, 5)
+            } else {
+                if (pipe == 3) PCV_HOLDP(2, 3) else PCV_HOLDP(2, 5)
+            }
+            PCV_LAUNCHED();
+            return;
+        }
         if (four) {
             if (nch == 3) PCV_HOLD(3, 4) else if (nch == 2) PCV_HOLD(2, 4) else PCV_HOLD(1, 4)
         } else {
             if (nch == 3) PCV_HOLD(3, 2) else if (nch == 2) PCV_HOLD(2, 2) else PCV_HOLD(1, 2)
         }
 #undef PCV_HOLD
+#undef PCV_HOLDP
         PCV_LAUNCHED();
         return;
     }
