@@ -76,6 +76,20 @@ __device__ __forceinline__ float4 ld_row(const float4* p) {
     }
 }
 
+// Streamed row chunks are read through a buffer descriptor (four scalar registers: the block's base, wave-uniform) with the
+// lane's own byte offset — one vector register that never changes — and a scalar chunk offset: no 64-bit address arithmetic
+// in vector registers.  (The compiler did that arithmetic in the registers of a chunk buffer; overwriting a register that a
+// load may still be writing costs an s_waitcnt vmcnt(0), i.e. every chunk in flight, per block.)  Loads past `bytes` return 0.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* ubase, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)ubase, 0, bytes, 0x00020000);
+}
+template <bool NTL>
+__device__ __forceinline__ float4 ld_piece(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_bytes, uint32_t chunk_bytes) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, chunk_bytes, NTL ? 2 : 0);  // aux 2 = nt
+    return __builtin_bit_cast(float4, v);
+}
+
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int off) {
     const uint32_t lo = __shfl_xor((uint32_t)v, off), hi = __shfl_xor((uint32_t)(v >> 32), off);
     return ((unsigned long long)hi << 32) | lo;
@@ -93,6 +107,12 @@ struct SegCursor {
     const uint4* blk8 = nullptr;
     const float* scale8 = nullptr;
 };
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* ptr) {  // a wave-uniform pointer, moved to scalar registers
+    const uint64_t v = (uint64_t)ptr;
+    return (const T*)(((uint64_t)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v));
+}
 __device__ __forceinline__ void seek_seg(const ScanParams& p, SegCursor& c, uint32_t gb) {
     if (gb < c.end) return;
     int lo = c.si + 1, hi = p.nseg - 1;  // last table entry with blk0 <= gb
@@ -103,14 +123,17 @@ __device__ __forceinline__ void seek_seg(const ScanParams& p, SegCursor& c, uint
         else
             hi = mid - 1;
     }
+    // The fields come back through v_readfirstlane: the wait for these loads then sits HERE, on the rare path.  Left in vector
+    // registers, the compiler has to wait at the point where the two paths meet — an s_waitcnt vmcnt(0) in front of the first
+    // use of a pointer, at every block, which drains the row chunks in flight (and the cursor took ten vector registers).
     c.si = lo;
-    c.begin = gld(&p.seg[lo].blk0);
-    c.end = c.begin + gld(&p.seg[lo].nblocks);
-    c.blk = gld(&p.seg[lo].blk);
-    c.scale = gld(&p.seg[lo].scale);
-    c.blk16 = gld(&p.seg[lo].blk16);
-    c.blk8 = gld(&p.seg[lo].blk8);
-    c.scale8 = gld(&p.seg[lo].scale8);
+    c.begin = uniform(gld(&p.seg[lo].blk0));
+    c.end = c.begin + uniform(gld(&p.seg[lo].nblocks));
+    c.blk = uniform_ptr(gld(&p.seg[lo].blk));
+    c.scale = uniform_ptr(gld(&p.seg[lo].scale));
+    c.blk16 = uniform_ptr(gld(&p.seg[lo].blk16));
+    c.blk8 = uniform_ptr(gld(&p.seg[lo].blk8));
+    c.scale8 = uniform_ptr(gld(&p.seg[lo].scale8));
 }
 
 // slots[q][0..k) always hold f32 scores of k DISTINCT rows (or -inf), each slot only ever grows, so
@@ -727,6 +750,14 @@ __global__ __launch_bounds__(256) void prep_seed_mfma_kernel(const ScanParams* _
     }
 }
 
+struct BlockCursor {  // position of a wave in its flat (block, chunk) stream; all of it wave-uniform
+    uint32_t gb;      // launch-wide block index (>= total_blocks: exhausted)
+    SegCursor sc;     // segment
+    uint32_t lb;      // block inside the segment
+    __amdgpu_buffer_rsrc_t rows;  // descriptor of the block's bytes in what the scan streams
+    int ch;           // chunk inside the block
+};
+
 // Wave-reduction scan for 1..4 queries (BASELINE config "10M x 384, batch=1"): pure HBM streaming.
 // Lane (r = lane&31, h = lane>>5) owns row r of the block and the pieces f4 = 2j+h; the two halves
 // of a row are combined with one cross-lane add.  f32 FMA chain -> the fine test applies directly.
@@ -753,20 +784,15 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
 
     // Same flat (block, chunk) stream with register chunk buffers as the MFMA kernel: the loads of the
     // next chunk — also across block boundaries — are in flight while the current one is multiplied.
-    struct Cur {
-        uint32_t gb;
-        SegCursor sc;
-        uint32_t lb;
-        const float4* base;
-        int ch;
-    } cons, prod;
-    auto enter = [&](Cur& k, uint32_t gb) {
+    BlockCursor cons, prod;
+    const uint32_t lane_off = (uint32_t)(h * 32 + r) * 16u;
+    auto enter = [&](BlockCursor& k, uint32_t gb) {
         k.gb = gb;
         k.ch = 0;
         if (gb < p.total_blocks) {
             seek_seg(p, k.sc, gb);
             k.lb = gb - k.sc.begin;
-            k.base = k.sc.blk + (size_t)k.lb * p.D4 * 32 + h * 32 + r;
+            k.rows = row_rsrc(k.sc.blk + (size_t)k.lb * p.D4 * 32, (uint32_t)p.D4 * 512u);
         }
     };
     enter(cons, blockIdx.x * 4 + wave);
@@ -779,19 +805,24 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
 
     float4 buf[2][8];
     auto produce = [&](float4 (&bf)[8]) {
-        if (prod.gb >= p.total_blocks) return;
+        // ALWAYS issues its loads — past the end of the wave's stream they re-read a chunk of its last block (two or three
+        // chunks per wave and launch).  With an early return here the compiler has to place every s_waitcnt for the case that
+        // the younger chunks were never requested: each multiply then waited for (nearly) all loads in flight, the ones just
+        // issued included, and the chunk buffers hid nothing.
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bf[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 8 + i) * 64);
-        if (++prod.ch == NCH) {
-            enter(prod, prod.gb + total_waves);
-            if (prod.gb < p.total_blocks) sc_next = gld(&prod.sc.scale[(size_t)prod.lb * 32 + r]);
+        for (int i = 0; i < 8; ++i) bf[i] = ld_piece<NTL>(prod.rows, lane_off + (uint32_t)i * 1024u, (uint32_t)prod.ch * 8192u);
+        if (prod.gb < p.total_blocks && ++prod.ch == NCH) {
+            enter(prod, prod.gb + total_waves);  // (leaves descriptor and lb where they are when the stream is over)
+            sc_next = gld(&prod.sc.scale[(size_t)prod.lb * 32 + r]);
+        }
+    };
+    auto pre = [&]() {  // thresholds one chunk ahead of the block's end, requested before that step's row loads and not
+        if (cons.ch == (NCH >= 2 ? NCH - 2 : 0)) {  // touched until then (see scan_mfma_kernel)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) tk[b] = ld_relaxed(&p.tau[b * kHot]);
         }
     };
     auto consume = [&](const float4 (&bf)[8]) {
-        if (cons.ch == (NCH >= 2 ? NCH - 2 : 0)) {  // thresholds one chunk ahead of the epilogue
-#pragma unroll
-            for (int b = 0; b < NB; ++b) tk[b] = max(tau0[b], ld_relaxed(&p.tau[b * kHot]));
-        }
         const float* qb = sq + h * 4 + cons.ch * 64;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -813,7 +844,7 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
             for (int b = 0; b < NB; ++b) {
                 acc[b] += __shfl_xor(acc[b], 32);
                 s[b] = acc[b] * sc_cur;
-                thr[b] = key_f32(tk[b]) - mrg[b];
+                thr[b] = key_f32(max(tau0[b], tk[b])) - mrg[b];
                 any |= (h == 0) && (sc_cur != 0.0f) && !(s[b] < thr[b]);
                 acc[b] = 0.0f;
             }
@@ -829,9 +860,11 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
     };
     produce(buf[0]);
     while (true) {
+        pre();
         produce(buf[1]);
         consume(buf[0]);
         if (cons.gb >= p.total_blocks) return;
+        pre();
         produce(buf[0]);
         consume(buf[1]);
         if (cons.gb >= p.total_blocks) return;
@@ -855,13 +888,6 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(const ScanParams* __rest
 //             scan stays HBM-bound (MFMA ~25 % busy), so 128 queries cost the same 23 ms as 64
 // (A 512-thread / 4-waves-per-SIMD build of the B <= 64 kernel was tried: the 128-VGPR cap spills 23
 // registers into the chunk loop and runs 15 % slower.)
-struct BlockCursor {  // position of a wave in its flat (block, chunk) stream
-    uint32_t gb;      // launch-wide block index (>= total_blocks: exhausted)
-    SegCursor sc;     // segment
-    uint32_t lb;      // block inside the segment
-    const float4* base;
-    int ch;           // chunk inside the block
-};
 
 // exact-f32 dot of query row `qf` with corpus row (`rowbase` = its piece 0; pieces are 32 float4 apart),
 // computed by the whole wave: every lane returns the same bits
@@ -981,11 +1007,12 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
             seek_seg(p, k.sc, gb);
             k.lb = gb - k.sc.begin;
             if constexpr (SRC16)
-                k.base = (const float4*)k.sc.blk16 + (size_t)k.lb * (D4 >> 1) * 32 + h * 32 + c;
+                k.rows = row_rsrc((const float4*)k.sc.blk16 + (size_t)k.lb * (D4 >> 1) * 32, (uint32_t)(D4 >> 1) * 512u);
             else
-                k.base = k.sc.blk + (size_t)k.lb * D4 * 32 + h * 64 + c;
+                k.rows = row_rsrc(k.sc.blk + (size_t)k.lb * D4 * 32, (uint32_t)D4 * 512u);
         }
     };
+    const uint32_t lane_off = (uint32_t)(SRC16 ? h * 32 + c : h * 64 + c) * 16u;  // the lane's bytes inside a block
     BlockCursor cons, prod;  // consumer (MFMA) and producer (loads) positions; prod runs NBUF-1 chunks ahead
     enter_block(cons, blockIdx.x * WPB + wave);
     prod = cons;
@@ -999,27 +1026,32 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
     // lane's pieces of k-step ks of a chunk: f4 = chunk*16 + ks*4 + 2h + e  (2h folded into base);
     // screening copy: f8 = chunk*8 + ks*2 + h  (h folded into base)
     auto produce = [&](float4 (&b)[PCS]) {
-        if (prod.gb >= p.total_blocks) return;
+        // ALWAYS issues its loads — past the end of the wave's stream they re-read a chunk of its last block (two or three
+        // chunks per wave and launch).  With an early return here the compiler has to place every s_waitcnt for the case that
+        // the younger chunks were never requested: each multiply then waited for (nearly) all loads in flight, the ones just
+        // issued included, and the chunk buffers hid nothing.
 #pragma unroll
         for (int i = 0; i < PCS; ++i) {
             if constexpr (SRC16)
-                b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 8 + i * 2) * 32);
+                b[i] = ld_piece<NTL>(prod.rows, lane_off + (uint32_t)i * 1024u, (uint32_t)prod.ch * 4096u);
             else
-                b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 16 + (i >> 1) * 4 + (i & 1)) * 32);
+                b[i] = ld_piece<NTL>(prod.rows, lane_off + (uint32_t)((i >> 1) * 4 + (i & 1)) * 512u, (uint32_t)prod.ch * 8192u);
         }
-        if (++prod.ch == NCH) {
-            enter_block(prod, prod.gb + total_waves);
-            if constexpr (!SRC16)
-                if (prod.gb < p.total_blocks) sc_next = gld(&prod.sc.scale[(size_t)prod.lb * 32 + c]);
+        if (prod.gb < p.total_blocks && ++prod.ch == NCH) {
+            enter_block(prod, prod.gb + total_waves);  // (leaves descriptor and lb where they are when the stream is over)
+            if constexpr (!SRC16) sc_next = gld(&prod.sc.scale[(size_t)prod.lb * 32 + c]);
         }
     };
 
-    // thresholds of the block being finished: issued one chunk ahead of the epilogue so their
-    // latency is not exposed
+    // thresholds of the block being finished: requested one chunk ahead of the epilogue and BEFORE that step's row loads
+    // (PCV_STEP), and not touched until the epilogue: vmcnt retires in order, so the first use of a threshold waits for every
+    // load issued before it — used at once (a max with the seed threshold) it drained the row chunks in flight at every block.
+    // Loaded for every lane, also those of tile rows beyond the batch (their words exist and are never raised): a load under
+    // a lane-dependent condition is compiled as a branch with an s_waitcnt vmcnt(0) inside.
     uint32_t tauk[NT];
     auto tau_prefetch = [&]() {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? max(tau0[t], ld_relaxed(&p.tau[(32 * t + c) * kHot])) : 0u;
+        for (int t = 0; t < NT; ++t) tauk[t] = ld_relaxed(&p.tau[(32 * t + c) * kHot]);
     };
 
     auto epilogue = [&](const SegCursor& esc, uint32_t elb) {
@@ -1029,7 +1061,7 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int q = 32 * t + c;
-            thr[t] = (q < p.B) ? key_f32(tauk[t]) - mrg[t] : __builtin_inff();
+            thr[t] = (q < p.B) ? key_f32(max(tau0[t], tauk[t])) - mrg[t] : __builtin_inff();
 #pragma unroll
             for (int i = 0; i < 16; ++i) any |= !(acc[t][i] < thr[t]);
         }
@@ -1049,7 +1081,6 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
     };
 
     auto consume = [&](const float4 (&b)[PCS]) {
-        if (NCH >= 2 && cons.ch == NCH - 2) tau_prefetch();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 a;
@@ -1077,9 +1108,10 @@ __global__ __launch_bounds__(WPB * 64, WPB == 4 ? ((SRC16 ? NBUF <= 4 : NBUF == 
 
     // NBUF-1 chunks of loads are always in flight while one chunk feeds the matrix cores
     // (written out per buffer: every buf[] index must be a literal, or the array moves to scratch)
-#define PCV_STEP(REFILL, CONS)          \
-    produce(buf[REFILL]);               \
-    consume(buf[CONS]);                 \
+#define PCV_STEP(REFILL, CONS)                              \
+    if (NCH >= 2 && cons.ch == NCH - 2) tau_prefetch();     \
+    produce(buf[REFILL]);                                   \
+    consume(buf[CONS]);                                     \
     if (cons.gb >= p.total_blocks) return;
     produce(buf[0]);
     if constexpr (NBUF == 2) {
@@ -1280,9 +1312,10 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         if (gb < p.total_blocks) {
             seek_seg(p, k.sc, gb);
             k.lb = gb - k.sc.begin;
-            k.base = (const float4*)k.sc.blk8 + (size_t)k.lb * P16 * 32 + h * 32 + c;
+            k.rows = row_rsrc((const float4*)k.sc.blk8 + (size_t)k.lb * P16 * 32, (uint32_t)P16 * 512u);
         }
     };
+    const uint32_t lane_off = (uint32_t)(h * 32 + c) * 16u;
     BlockCursor cons, prod;
     enter_block(cons, blockIdx.x * WPB + wave);
     prod = cons;
@@ -1290,10 +1323,13 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     float4 buf[NBUF][4];
     // lane's piece of k-step ks of a chunk: f16 = chunk*8 + ks*2 + h  (h folded into base)
     auto produce = [&](float4 (&b)[4]) {
-        if (prod.gb >= p.total_blocks) return;
+        // ALWAYS issues its loads — past the end of the wave's stream they re-read a chunk of its last block (two or three
+        // chunks per wave and launch).  With an early return here the compiler has to place every s_waitcnt for the case that
+        // the younger chunks were never requested: each multiply then waited for (nearly) all loads in flight, the ones just
+        // issued included, and the chunk buffers hid nothing.
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b[i] = ld_row<NTL>(prod.base + (size_t)(prod.ch * 8 + i * 2) * 32);
-        if (++prod.ch == NCH) enter_block(prod, prod.gb + total_waves);
+        for (int i = 0; i < 4; ++i) b[i] = ld_piece<NTL>(prod.rows, lane_off + (uint32_t)i * 1024u, (uint32_t)prod.ch * 4096u);
+        if (prod.gb < p.total_blocks && ++prod.ch == NCH) enter_block(prod, prod.gb + total_waves);  // (the descriptor stays when the stream is over)
     };
 
     // thresholds and the quantisation scales of the block being finished, requested one chunk ahead of the epilogue:
@@ -1303,9 +1339,9 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     // (scale8 is stored in that order): the epilogue gets it with one row broadcast per accumulator
     float srv = 0.0f;
     float2 smm = make_float2(0.0f, 0.0f);  // smallest / largest scale among the 16 rows this lane tests
-    auto prefetch = [&]() {
+    auto prefetch = [&]() {  // (before the step's row loads and untouched until the epilogue: see scan_mfma_kernel)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) tauk[t] = (32 * t + c < p.B) ? max(tau0[t], ld_relaxed(&p.tau[(32 * t + c) * kHot])) : 0u;
+        for (int t = 0; t < NT; ++t) tauk[t] = ld_relaxed(&p.tau[(32 * t + c) * kHot]);
         const float* s8 = cons.sc.scale8 + (size_t)cons.lb * kScale8Stride;
         srv = gld(s8 + 16 * h + (lane & 15));
         smm.x = gld(s8 + 32 + 2 * h);
@@ -1318,7 +1354,7 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int q = 32 * t + c;
-            const float T = (key_f32(tauk[t]) - e32[t]) * sq[t];
+            const float T = (key_f32(max(tau0[t], tauk[t])) - e32[t]) * sq[t];
             // lowered by 2e-6 relative (f32 rounding of T and of the product with s_row) and by the |x^|_1 term
             // s_q = 0: a dead query.  Cosine: no row has a score, none is kept; dot (an all-zero query): every row scores 0,
             // all are kept and the fine screen sorts it out.
@@ -1337,6 +1373,9 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
             for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
             hot |= (float)m >= fmaf(U[t] >= 0.0f ? smm.x : smm.y, U[t], -vq[t]);
         }
+        // (srv is only read on the branch below; "used" here — beside the thresholds, which came with it — so that the compiler
+        // knows its load has landed: a register whose load may still be pending makes the next request for it wait vmcnt(0))
+        asm volatile("" : "+v"(srv));
         if (__any(hot)) {
         // accumulator I tests the row whose scale sits in lane I of this lane's 16-lane row: DPP row_newbcast:I (the
         // control word is an immediate; the value is used at once, so no 16 registers are held)
@@ -1366,7 +1405,6 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     };
 
     auto consume = [&](const float4 (&b)[4]) {
-        if (NCH >= 2 && cons.ch == NCH - 2) prefetch();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const i32x4 a = __builtin_bit_cast(i32x4, b[ks]);
@@ -1383,9 +1421,10 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         }
     };
 
-#define PCV_STEP(REFILL, CONS)          \
-    produce(buf[REFILL]);               \
-    consume(buf[CONS]);                 \
+#define PCV_STEP(REFILL, CONS)                          \
+    if (NCH >= 2 && cons.ch == NCH - 2) prefetch();     \
+    produce(buf[REFILL]);                               \
+    consume(buf[CONS]);                                 \
     if (cons.gb >= p.total_blocks) return;
     produce(buf[0]);
     if constexpr (NBUF == 3) {
@@ -1464,15 +1503,16 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
     float4 buf[NCH][4];
     float srv = 0.0f;
     float2 smm = make_float2(0.0f, 0.0f);
-    const float4* base = nullptr;
+    __amdgpu_buffer_rsrc_t rows;  // the block's bytes (see ld_piece)
+    const uint32_t lane_off = (uint32_t)(h * 32 + c) * 16u;
     auto enter = [&]() {  // the block `cur` points at
         seek_seg(p, cur.sc, cur.gb);
         cur.lb = cur.gb - cur.sc.begin;
-        base = (const float4*)cur.sc.blk8 + (size_t)cur.lb * P16 * 32 + h * 32 + c;
+        rows = row_rsrc((const float4*)cur.sc.blk8 + (size_t)cur.lb * P16 * 32, (uint32_t)P16 * 512u);
     };
     auto load_chunk = [&](int ch) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) buf[ch][i] = ld_row<NTL>(base + (size_t)(ch * 8 + i * 2) * 32);
+        for (int i = 0; i < 4; ++i) buf[ch][i] = ld_piece<NTL>(rows, lane_off + (uint32_t)i * 1024u, (uint32_t)ch * 4096u);
     };
     auto load_scales = [&]() {  // of the block's rows (see scan_mfma8_kernel)
         const float* s8 = cur.sc.scale8 + (size_t)cur.lb * kScale8Stride;
@@ -1495,7 +1535,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
             const int q0 = 64 * half + c;  // this lane's queries: q0, q0 + 32
             uint32_t tauk[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) tauk[t] = (q0 + 32 * t < p.B) ? max(ltau0[q0 + 32 * t], ld_relaxed(&p.tau[(q0 + 32 * t) * kHot])) : 0u;
+            for (int t = 0; t < 2; ++t) tauk[t] = ld_relaxed(&p.tau[(q0 + 32 * t) * kHot]);  // every lane, and not touched before the epilogue: see scan_mfma_kernel
             i32x16 acc[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -1555,12 +1595,13 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
             // epilogue of this half (scan_mfma8_kernel has the derivation)
             float U[2], vq[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t) {  // (every LDS word is read whatever the lane's query is: selects, not branches around reads)
                 const int q = q0 + 32 * t;
-                const float sq = lsq[q];
+                const float sq = lsq[q], e32 = le32[q];
                 vq[t] = lvq[q];
-                const float T = (key_f32(tauk[t]) - le32[q]) * sq;
-                U[t] = (q < p.B) ? (sq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
+                const float T = (key_f32(max(ltau0[q], tauk[t])) - e32) * sq;
+                const float live = (T - fabsf(T) * 2e-6f) - c1;
+                U[t] = (q < p.B) ? (sq != 0.0f ? live : dead) : __builtin_inff();
             }
             bool hot = false;
 #pragma unroll
@@ -1570,6 +1611,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
                 for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
                 hot |= (float)m >= fmaf(U[t] >= 0.0f ? smm_e.x : smm_e.y, U[t], -vq[t]);
             }
+            asm volatile("" : "+v"(srv_e));  // (see scan_mfma8_kernel)
             if (__any(hot)) {
                 uint32_t mask[2] = {0u, 0u};
 #define PCV_TEST(I)                                                                                                            \
@@ -1645,11 +1687,12 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512, 2) void scan_mfma8_hold2_kerne
     auto request = [&](float4 (&buf)[NCH][4], Held& hd) {  // all chunks + scales of block gb; gb moves on
         seek_seg(p, sc, gb);
         const uint32_t lb = gb - sc.begin;
-        const float4* base = (const float4*)sc.blk8 + (size_t)lb * P16 * 32 + h * 32 + c;
+        const __amdgpu_buffer_rsrc_t rows = row_rsrc((const float4*)sc.blk8 + (size_t)lb * P16 * 32, (uint32_t)P16 * 512u);
+        const uint32_t lane_off = (uint32_t)(h * 32 + c) * 16u;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) buf[ch][i] = ld_row<NTL>(base + (size_t)(ch * 8 + i * 2) * 32);
+            for (int i = 0; i < 4; ++i) buf[ch][i] = ld_piece<NTL>(rows, lane_off + (uint32_t)i * 1024u, (uint32_t)ch * 4096u);
         const float* s8 = sc.scale8 + (size_t)lb * kScale8Stride;
         hd.srv = gld(s8 + 16 * h + (lane & 15));
         hd.smm.x = gld(s8 + 32 + 2 * h);
@@ -1668,7 +1711,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512, 2) void scan_mfma8_hold2_kerne
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int q = 64 * half + 32 * t + c;
-                tauk[half][t] = (q < p.B) ? max(ltau0[q], ld_relaxed(&p.tau[q * kHot])) : 0u;
+                tauk[half][t] = ld_relaxed(&p.tau[q * kHot]);
             }
         const bool more = gb < p.total_blocks;
         if (more) request(nbuf, nhd);
@@ -1702,10 +1745,11 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 512, 2) void scan_mfma8_hold2_kerne
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int q = q0 + 32 * t;
-                const float sq = lsq[q];
+                const float sq = lsq[q], e32 = le32[q];
                 vq[t] = lvq[q];
-                const float T = (key_f32(tauk[half][t]) - le32[q]) * sq;
-                U[t] = (q < p.B) ? (sq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
+                const float T = (key_f32(max(ltau0[q], tauk[half][t])) - e32) * sq;
+                const float live = (T - fabsf(T) * 2e-6f) - c1;
+                U[t] = (q < p.B) ? (sq != 0.0f ? live : dead) : __builtin_inff();
             }
             bool hot = false;
 #pragma unroll
