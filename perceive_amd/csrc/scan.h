@@ -106,8 +106,7 @@ struct ScanParams {
                              // bit 0: plain (temporal) corpus loads instead of nt; bit 1: 16 queries per seed workgroup (VALU seed);
                              // bit 2: the VALU seed kernel; bit 3: the 128-query tile instead of the block-holding int8 scan;
                              // bit 5: no speculative start threshold; bit 7: no learned part of it; bits 8..15: workgroups per CU;
-                             // bits 16..23: seed workgroups; bits 24..27: chunk buffers (block-holding int8 scan: LDS
-                             // read-ahead, 3 or 5); bit 28: the two-block form of the block-holding int8 scan
+                             // bits 16..23: seed workgroups; bits 24..27: chunk buffers
     float eps16, eps32;      // |s - c| bounds of the bf16 / f32 screening scores, relative to |q||x|
     float max_norm;          // upper bound of |x| over the corpus (dot metric margins)
     // Speculative start threshold (MFMA scans; 0 = off).  The k slots the seed kernel fills are the best scores of k

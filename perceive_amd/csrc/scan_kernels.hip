@@ -1256,6 +1256,11 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
     set_guess(p, q, lane, have);
 }
 
+// (Measured, 100M x 384, 64 queries, one box: this form 6.241 ms; with a producer that returns early once the wave's stream is
+// over — the compiler then places every wait for the case that nothing younger was requested, so that each multiply waits for
+// nearly all loads in flight — 6.239; with plain global loads and 64-bit vector addresses 6.268; both 6.281.  At 3 waves per
+// SIMD and 12 per CU the other waves hide what one wave's chunk buffers would; the pass runs at the read rate the memory
+// system gives this pattern.)
 template <int NT, bool NTL, int WPB, int NBUF>
 __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
@@ -1448,18 +1453,25 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 #undef PCV_STEP
 }
 
-// 65..128 queries over rows of at most 384 features: the 128-query tile above needs 232 registers (64 accumulators, four
+// 65..256 queries over rows of at most 384 features: the 128-query tile above needs 232 registers (64 accumulators, four
 // chunk buffers) and runs at 2 waves per SIMD.  Here a wave HOLDS a block (NCH chunks = all its 12 KB, in the registers the
-// chunk buffers took) and multiplies it with the two 64-query halves of the tile one after the other, so only 32
-// accumulators are live: the register footprint of the 64-query form, 3 waves per SIMD, three 51 KB tiles per CU.  In the
-// second half every chunk of the next block is requested as soon as the MFMAs of the chunk it replaces are out; the
-// latency is covered by the rest of that half, its epilogue and the other eleven waves of the CU.
-// NH halves of 64 queries: 2 (up to 128 queries: 256-thread workgroups, three 51 KB tiles per CU) or 4 (up to 256 queries:
-// one 768-thread workgroup and one 102 KB tile per CU, the same 3 waves per SIMD) — one pass over the rows for 256 queries.
-// PIPE > 0: the query pieces of a half are read from LDS PIPE multiplies ahead of their use, through PIPE + 1 rotating
-// registers sets, and the instruction scheduler is told to keep that order (one LDS read issued per multiply); PIPE = 0 leaves
-// the order to the compiler, which reads a piece one or two instructions before the multiply that needs it.
-template <bool NTL, int NCH, int NH, int PIPE = 0>
+// chunk buffers took) and multiplies it with the 64-query halves of the tile one after the other, so only 32 accumulators are
+// live: 3 waves per SIMD.  NH halves of 64 queries: 2 (up to 128 queries: 256-thread workgroups, three 51 KB tiles per CU) or
+// 4 (up to 256 queries: one 768-thread workgroup and one 102 KB tile per CU) — one pass over the rows for 256 queries.
+//
+// The test of a half reads its right-hand side U_q from LDS: at every block a wave renews the 32 values of ONE tile from the
+// running thresholds (tile = (its block count + its number) mod tiles: every tile comes round every block), a half reads two
+// words per tile.  A stale U is a threshold that was valid earlier, i.e. a lower one: never wrong, at most a survivor more.
+// (Every wave deriving both U of every half from freshly loaded thresholds — ~45 vector instructions per tile and half, and
+// the loads under a lane-dependent condition, which the compiler turns into a branch with an s_waitcnt vmcnt(0) inside — took
+// 12.2 ms per 100M rows at 256 queries; the loads made unconditional 11.2; U from LDS 9.9; with the requests below 9.6.)
+//
+// Measured and not kept (100M x 384, 256 queries, same box each): the query pieces read from LDS three or five multiplies
+// ahead, order pinned with scheduling barriers: 12.18 against 12.28 ms (the waves do not wait on LDS); two held blocks per
+// wave at 2 waves per SIMD, the whole next block in flight: 11.27 against 11.10 ms (a third wave per SIMD hides as much);
+// the waves of a SIMD started a third of a half apart: 9.83 against 9.80 ms.  With no test at all the pass takes 8.7 ms,
+// and 7.3 ms with the rows coming from L2: the multiplies themselves, at the clock the chip holds under them (1.6 GHz).
+template <bool NTL, int NCH, int NH>
 __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
     constexpr int TQ = NH * 64;       // queries of the tile
@@ -1490,6 +1502,16 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
     const float nrm = (p.metric == PCV_METRIC_DOT) ? p.max_norm : 1.0f;
     const float c1 = 0.5002f * sqrtf((float)(NCH * 128)) * nrm;
     const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
+    __shared__ float lU[TQ];
+    // U_q of the test for the running threshold `tau_key` (derivation: scan_mfma8_kernel)
+    auto u_of = [&](int q, uint32_t tau_key) -> float {
+        const float sq = lsq[q];
+        const float T = (key_f32(max(ltau0[q], tau_key)) - le32[q]) * sq;
+        const float live = (T - fabsf(T) * 2e-6f) - c1;
+        return q < p.B ? (sq != 0.0f ? live : dead) : __builtin_inff();
+    };
+    for (int q = threadIdx.x; q < TQ; q += WPB * 64) lU[q] = u_of(q, ld_relaxed(&p.tau[q * kHot]));
+    __syncthreads();
 
     const uint32_t total_waves = gridDim.x * WPB;
     struct Cur {
@@ -1499,6 +1521,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
     } cur;
     cur.gb = blockIdx.x * WPB + wave;
     if (cur.gb >= p.total_blocks) return;
+    uint32_t renew = wave % (uint32_t)(TQ / 32);  // tile whose U this wave renews at its next block
 
     float4 buf[NCH][4];
     float srv = 0.0f;
@@ -1524,59 +1547,51 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) load_chunk(ch);
     load_scales();
+    // The first NA chunks of the NEXT block are asked for a whole block ahead, the others in the last half, each as soon as the
+    // multiplies of the chunk it replaces are out (the last half takes those chunks first).  A new block used to wait for its
+    // first chunk, requested only two thirds of a half before its first use.  Where a chunk waits for a block: in four
+    // registers (nb0, nb1: the 128-query form has them), or — 256 queries, where the registers do not reach — chunk 0 moves to
+    // 4 KB of LDS per wave in the middle of the block and nb0 takes chunk 1.  All loads of the loop are unconditional — past
+    // the end of the wave's stream they read its last block again — so that the compiler can count them (scan_mfma_kernel).
+    constexpr int NA = NCH >= 2 ? 2 : 1;
+    constexpr bool VIA_LDS = NA == 2 && NH == 4;
+    float4 nb0[4], nb1[4];
+    uint4* const stage = lq8 + (size_t)TQ * LDQ + (size_t)wave * 256 + lane;  // VIA_LDS: this wave's 4 KB behind the tile
 
     while (true) {
-        SegCursor esc = cur.sc;
-        uint32_t elb = cur.lb;
-        float srv_e = 0.0f;
-        float2 smm_e = make_float2(0.0f, 0.0f);
+        const SegCursor esc = cur.sc;  // the block held: where its survivors live, and the scales of its rows
+        const uint32_t elb = cur.lb;
+        const float srv_e = srv;
+        const float2 smm_e = smm;
+        cur.gb += total_waves;  // the next block: its cursor and descriptor now
+        const bool more = cur.gb < p.total_blocks;
+        if (more) enter();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nb0[i] = ld_piece<NTL>(rows, lane_off + (uint32_t)i * 1024u, 0u);
+        if constexpr (NA == 2 && !VIA_LDS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nb1[i] = ld_piece<NTL>(rows, lane_off + (uint32_t)i * 1024u, 4096u);
+        }
 #pragma unroll
         for (int half = 0; half < NH; ++half) {
             const int q0 = 64 * half + c;  // this lane's queries: q0, q0 + 32
-            uint32_t tauk[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) tauk[t] = ld_relaxed(&p.tau[(q0 + 32 * t) * kHot]);  // every lane, and not touched before the epilogue: see scan_mfma_kernel
+            uint32_t rtau = 0u;  // (every lane loads, and the value is not touched before the end of the half: see scan_mfma_kernel)
+            if (half == 0) rtau = ld_relaxed(&p.tau[(32 * renew + c) * kHot]);
             i32x16 acc[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = 0;
-            bool more = false;
-            if (half == 0) {
-                srv_e = srv;
-                smm_e = smm;
-            } else if (half == NH - 1) {  // last half: every chunk's registers are free once its MFMAs are out: the next block's chunk follows at once
-                cur.gb += total_waves;
-                more = cur.gb < p.total_blocks;
-                if (more) enter();
+            if (VIA_LDS && half == NH / 2) {  // chunk 0 of the next block has long arrived: to LDS with it, its registers ask for chunk 1
+#pragma unroll
+                for (int i = 0; i < 4; ++i) stage[i * 64] = __builtin_bit_cast(uint4, nb0[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nb0[i] = ld_piece<NTL>(rows, lane_off + (uint32_t)i * 1024u, 4096u);
             }
-            if constexpr (PIPE > 0) {
-                constexpr int NM = NCH * 8;  // multiplies of a half: piece kk = i >> 1 of the rows against tile t = i & 1
-                i32x4 bq[PIPE + 1];
-                const uint4* lrow = lq8 + (size_t)q0 * LDQ + h;
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < PIPE; ++i) bq[i] = *(const i32x4*)&lrow[(size_t)(32 * (i & 1)) * LDQ + 2 * (i >> 1)];
-#pragma unroll
-                for (int i = 0; i < NM; ++i) {
-                    if (i + PIPE < NM) bq[(i + PIPE) % (PIPE + 1)] = *(const i32x4*)&lrow[(size_t)(32 * ((i + PIPE) & 1)) * LDQ + 2 * ((i + PIPE) >> 1)];
-                    const int kk = i >> 1;
-                    const i32x4 a = __builtin_bit_cast(i32x4, buf[kk >> 2][kk & 3]);
-                    acc[i & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[i % (PIPE + 1)], acc[i & 1], 0, 0, 0);
-                    if ((i & 7) == 7 && half == NH - 1 && more) load_chunk(i >> 3);
-                }
-                // the order above, kept: PIPE reads, then (one multiply, one read) ..., the chunk's loads behind its last multiply
-                __builtin_amdgcn_sched_group_barrier(0x100, PIPE, 0);
-#pragma unroll
-                for (int i = 0; i < NM; ++i) {
-                    if (i + PIPE < NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if ((i & 7) == 7 && half == NH - 1) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
+            for (int cc = 0; cc < NCH; ++cc) {
+                // the last half takes the chunks whose successors are only requested now first (integer sums: any order)
+                const int ch = half == NH - 1 ? (cc + NA < NCH ? cc + NA : cc + NA - NCH) : cc;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const i32x4 a = __builtin_bit_cast(i32x4, buf[ch][ks]);
@@ -1587,21 +1602,31 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
                         acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
                     }
                 }
-                if (half == NH - 1 && more) load_chunk(ch);
+                if (half == NH - 1) {  // last half: the chunk's registers are free, the next block's chunk follows at once
+                    if (ch >= NA) {
+                        load_chunk(ch);
+                    } else if (ch == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) buf[0][i] = VIA_LDS ? __builtin_bit_cast(float4, stage[i * 64]) : nb0[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) buf[1][i] = VIA_LDS ? nb0[i] : nb1[i];
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);  // (the scheduler would fetch all 2 * 4 * NCH query pieces first: 190 registers)
             }
-            }
-            if (half == NH - 1 && more) load_scales();
+            if (half == NH - 1) load_scales();
             // epilogue of this half (scan_mfma8_kernel has the derivation)
             float U[2], vq[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {  // (every LDS word is read whatever the lane's query is: selects, not branches around reads)
                 const int q = q0 + 32 * t;
-                const float sq = lsq[q], e32 = le32[q];
                 vq[t] = lvq[q];
-                const float T = (key_f32(max(ltau0[q], tauk[t])) - e32) * sq;
-                const float live = (T - fabsf(T) * 2e-6f) - c1;
-                U[t] = (q < p.B) ? (sq != 0.0f ? live : dead) : __builtin_inff();
+                U[t] = lU[q];
+            }
+            if (half == 0) {  // (after the reads of this half: the renewed values serve the halves to come)
+                lU[32 * renew + c] = u_of(32 * (int)renew + c, rtau);
+                renew = renew + 1 == (uint32_t)(TQ / 32) ? 0u : renew + 1;
             }
             bool hot = false;
 #pragma unroll
@@ -1611,7 +1636,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
                 for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
                 hot |= (float)m >= fmaf(U[t] >= 0.0f ? smm_e.x : smm_e.y, U[t], -vq[t]);
             }
-            asm volatile("" : "+v"(srv_e));  // (see scan_mfma8_kernel)
+            asm volatile("" ::"v"(srv_e));  // (see scan_mfma8_kernel)
             if (__any(hot)) {
                 uint32_t mask[2] = {0u, 0u};
 #define PCV_TEST(I)                                                                                                            \
@@ -1628,161 +1653,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
                 }
             }
         }
-        if (cur.gb >= p.total_blocks) return;
-    }
-}
-
-// The block-holding scan with TWO held blocks per wave (DB form): while a wave multiplies the block it holds with the NH
-// halves of the query tile, ALL chunks of its next block are already on their way into a second set of registers — 24 KB in
-// flight per wave for the whole time a block takes, instead of chunk by chunk during the last half only (which left the
-// 256-query pass waiting on memory after every block: 3.2 TB/s).  Two register sets put the kernel at ~200 registers:
-// 2 waves per SIMD, i.e. one 512-thread workgroup per CU for the 102 KB tile of 256 queries, two 256-thread workgroups for
-// the 51 KB tile of 128.  The thresholds of a block's NH halves are fetched BEFORE its successor is requested: vmcnt retires
-// in order, so a threshold load issued behind the prefetch would make the first epilogue wait for the whole next block.
-template <bool NTL, int NCH, int NH>
-__global__ __launch_bounds__(NH == 2 ? 256 : 512, 2) void scan_mfma8_hold2_kernel(const ScanParams* __restrict__ pp) {
-    const ScanParams& p = *pp;
-    constexpr int TQ = NH * 64;
-    constexpr int WPB = NH == 2 ? 4 : 8;
-    extern __shared__ uint4 lq8[];  // [TQ][LDQ] pieces of 16 int8
-    constexpr int P16 = NCH * 8;
-    constexpr int LDQ = P16 + 1;
-    const int D4 = p.D4;
-    __shared__ uint32_t ltau0[TQ];
-    __shared__ float lsq[TQ], lvq[TQ], le32[TQ];
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < TQ * P16; i += WPB * 64) {
-        const int q = i / P16, pc = i - q * P16;
-        lq8[(size_t)q * LDQ + pc] = __builtin_bit_cast(uint4, gld4((const float4*)p.q8 + i));
-    }
-    for (int q = threadIdx.x; q < TQ; q += WPB * 64) {
-        lsq[q] = gld(&p.q8c[2 * q]);
-        lvq[q] = gld(&p.q8c[2 * q + 1]);
-        le32[q] = q < p.B ? 0.5f * gld(&p.margin32[q]) : 0.0f;
-    }
-    for (int q = threadIdx.x >> 2; q < TQ; q += WPB * 16) {
-        const uint32_t key = seed_threshold_key(p, q, threadIdx.x & 3);
-        if ((threadIdx.x & 3) == 0) ltau0[q] = key;
-    }
-    __syncthreads();
-    const int c = lane & 31, h = lane >> 5;
-    const float nrm = (p.metric == PCV_METRIC_DOT) ? p.max_norm : 1.0f;
-    const float c1 = 0.5002f * sqrtf((float)(NCH * 128)) * nrm;
-    const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
-
-    const uint32_t total_waves = gridDim.x * WPB;
-    uint32_t gb = blockIdx.x * WPB + wave;  // the block being REQUESTED next
-    if (gb >= p.total_blocks) return;
-    SegCursor sc;  // segment of `gb`
-    // what is known of a held block: where it lives (for its survivors) and the scales of its rows
-    struct Held {
-        int si;
-        uint32_t lb;
-        const float* scale;
-        const float4* blk;
-        float srv;
-        float2 smm;
-    };
-    auto request = [&](float4 (&buf)[NCH][4], Held& hd) {  // all chunks + scales of block gb; gb moves on
-        seek_seg(p, sc, gb);
-        const uint32_t lb = gb - sc.begin;
-        const __amdgpu_buffer_rsrc_t rows = row_rsrc((const float4*)sc.blk8 + (size_t)lb * P16 * 32, (uint32_t)P16 * 512u);
-        const uint32_t lane_off = (uint32_t)(h * 32 + c) * 16u;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) buf[ch][i] = ld_piece<NTL>(rows, lane_off + (uint32_t)i * 1024u, (uint32_t)ch * 4096u);
-        const float* s8 = sc.scale8 + (size_t)lb * kScale8Stride;
-        hd.srv = gld(s8 + 16 * h + (lane & 15));
-        hd.smm.x = gld(s8 + 32 + 2 * h);
-        hd.smm.y = gld(s8 + 33 + 2 * h);
-        hd.si = sc.si;
-        hd.lb = lb;
-        hd.scale = sc.scale;
-        hd.blk = sc.blk;
-        gb += total_waves;
-    };
-    // one held block against the whole tile; `nxt` is requested first (if there is one)
-    auto work = [&](const float4 (&buf)[NCH][4], const Held& hd, float4 (&nbuf)[NCH][4], Held& nhd) {
-        uint32_t tauk[NH][2];
-#pragma unroll
-        for (int half = 0; half < NH; ++half)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int q = 64 * half + 32 * t + c;
-                tauk[half][t] = ld_relaxed(&p.tau[q * kHot]);
-            }
-        const bool more = gb < p.total_blocks;
-        if (more) request(nbuf, nhd);
-        SegCursor esc;  // (fine_survivors reads si, scale and blk of it)
-        esc.si = hd.si;
-        esc.scale = hd.scale;
-        esc.blk = hd.blk;
-#pragma unroll
-        for (int half = 0; half < NH; ++half) {
-            const int q0 = 64 * half + c;
-            i32x16 acc[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] = 0;
-#pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const i32x4 a = __builtin_bit_cast(i32x4, buf[ch][ks]);
-                    const int pc = 2 * (ch * 4 + ks) + h;
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const i32x4 q8 = *(const i32x4*)&lq8[(size_t)(q0 + 32 * t) * LDQ + pc];
-                        acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);  // (or the scheduler fetches every query piece of the half first)
-            }
-            float U[2], vq[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int q = q0 + 32 * t;
-                const float sq = lsq[q], e32 = le32[q];
-                vq[t] = lvq[q];
-                const float T = (key_f32(max(ltau0[q], tauk[half][t])) - e32) * sq;
-                const float live = (T - fabsf(T) * 2e-6f) - c1;
-                U[t] = (q < p.B) ? (sq != 0.0f ? live : dead) : __builtin_inff();
-            }
-            bool hot = false;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                int m = acc[t][0];
-#pragma unroll
-                for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
-                hot |= (float)m >= fmaf(U[t] >= 0.0f ? hd.smm.x : hd.smm.y, U[t], -vq[t]);
-            }
-            if (__any(hot)) {
-                uint32_t mask[2] = {0u, 0u};
-#define PCV_TEST(I)                                                                                                            \
-    {                                                                                                                          \
-        const float s_row = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, hd.srv), 0x150 + I, 0xf, 0xf, false)); \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) mask[t] |= ((float)acc[t][I] >= fmaf(s_row, U[t], -vq[t])) ? (1u << I) : 0u;  \
-    }
-                PCV_TEST(0) PCV_TEST(1) PCV_TEST(2) PCV_TEST(3) PCV_TEST(4) PCV_TEST(5) PCV_TEST(6) PCV_TEST(7)
-                PCV_TEST(8) PCV_TEST(9) PCV_TEST(10) PCV_TEST(11) PCV_TEST(12) PCV_TEST(13) PCV_TEST(14) PCV_TEST(15)
-#undef PCV_TEST
-                if (__any((mask[0] | mask[1]) != 0)) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) fine_survivors(p, mask[t], 2 * half + t, esc, hd.lb, ltau0, lane, D4);
-                }
-            }
-        }
-        return more;
-    };
-    float4 bufA[NCH][4], bufB[NCH][4];
-    Held hA, hB;
-    request(bufA, hA);
-    while (true) {
-        if (!work(bufA, hA, bufB, hB)) return;
-        if (!work(bufB, hB, bufA, hA)) return;
+        if (!more) return;
     }
 }
 
@@ -2324,29 +2195,8 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
     const int nch = ((p.D4 * 4 + 127) & ~127) >> 7;
     if (p.B > 64 && nch <= 3 && (p.B > 128 || !(p.flags & 8u))) {  // (flag bit 3: the 128-query tile, for comparison)
         const bool four = p.B > 128;
-        const size_t ldsh = mfma8_lds(four ? 8 : 4, p.D4 * 4);
-        // flag bit 28 (comparison): two held blocks per wave at 2 waves per SIMD (scan_mfma8_hold2_kernel; measured slower: 12.7
-        // against 12.2 ms at 256 queries, 8.26 against 7.42 ms at 128 — the multiplies wait on LDS, not on HBM, and a third
-        // wave per SIMD hides more of that than a second block in flight)
-        const bool twoblk = (p.flags & (1u << 28)) != 0;
-        if (twoblk) {
-            const unsigned wpb2 = four ? 8 : 4;
-            const unsigned g2 = std::min<unsigned>((unsigned)num_cus * (gm ? gm : (four ? 1u : 2u)), (p.total_blocks + wpb2 - 1) / wpb2);
-#define PCV_HOLD2(NCHV, NHV)                                                                           \
-    {                                                                                                  \
-        allow_dynamic_lds(ntl ? (const void*)scan_mfma8_hold2_kernel<true, NCHV, NHV> : (const void*)scan_mfma8_hold2_kernel<false, NCHV, NHV>, ldsh); \
-        if (ntl) scan_mfma8_hold2_kernel<true, NCHV, NHV><<<g2, NHV == 2 ? 256 : 512, ldsh, st>>>(dp); \
-        else scan_mfma8_hold2_kernel<false, NCHV, NHV><<<g2, NHV == 2 ? 256 : 512, ldsh, st>>>(dp);    \
-    }
-            if (four) {
-                if (nch == 3) PCV_HOLD2(3, 4) else if (nch == 2) PCV_HOLD2(2, 4) else PCV_HOLD2(1, 4)
-            } else {
-                if (nch == 3) PCV_HOLD2(3, 2) else if (nch == 2) PCV_HOLD2(2, 2) else PCV_HOLD2(1, 2)
-            }
-#undef PCV_HOLD2
-            PCV_LAUNCHED();
-            return;
-        }
+        // (+ 4 KB per wave where a chunk of the next block waits in LDS: the 256-query form at more than one chunk per block)
+        const size_t ldsh = mfma8_lds(four ? 8 : 4, p.D4 * 4) + (four && nch >= 2 ? 12 * 4096 : 0);
         const unsigned wpb = four ? 12 : 4;
         const unsigned g3 = std::min<unsigned>((unsigned)num_cus * (gm ? gm : (four ? 1u : 3u)), (p.total_blocks + wpb - 1) / wpb);
 #define PCV_HOLD(NCHV, NHV)                                                                           \
@@ -2355,28 +2205,12 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
         if (ntl) scan_mfma8_hold_kernel<true, NCHV, NHV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp); \
         else scan_mfma8_hold_kernel<false, NCHV, NHV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp);    \
     }
-#define PCV_HOLDP(NHV, PV)                                                                            \
-    {                                                                                                 \
-        allow_dynamic_lds((const void*)scan_mfma8_hold_kernel<true, 3, NHV, PV>, ldsh);                \
-        scan_mfma8_hold_kernel<true, 3, NHV, PV><<<g3, NHV == 2 ? 256 : 768, ldsh, st>>>(dp);          \
-    }
-        const unsigned pipe = (p.flags >> 24) & 0xf;  // (tuning: LDS read-ahead of the 384-d forms)
-        if (nch == 3 && ntl && pipe) {
-            if (four) {
-                if (pipe == 3) PCV_HOLDP(4, 3) else PCV_HOLDP(4, 5)
-            } else {
-                if (pipe == 3) PCV_HOLDP(2, 3) else PCV_HOLDP(2, 5)
-            }
-            PCV_LAUNCHED();
-            return;
-        }
         if (four) {
             if (nch == 3) PCV_HOLD(3, 4) else if (nch == 2) PCV_HOLD(2, 4) else PCV_HOLD(1, 4)
         } else {
             if (nch == 3) PCV_HOLD(3, 2) else if (nch == 2) PCV_HOLD(2, 2) else PCV_HOLD(1, 2)
         }
 #undef PCV_HOLD
-#undef PCV_HOLDP
         PCV_LAUNCHED();
         return;
     }
