@@ -107,6 +107,7 @@ struct ScanParams {
                              // bit 2: the VALU seed kernel; bit 3: the 128-query tile instead of the block-holding int8 scan;
                              // bit 5: no speculative start threshold; bit 7: no learned part of it; bits 8..15: workgroups per CU;
                              // bits 16..23: seed workgroups; bits 24..27: chunk buffers
+    unsigned long long* stamps;  // diagnostic build only (-DPCV_STAMPS, tools/build_stamps.sh): 8 words per wave of the scan launch, else nullptr
     float eps16, eps32;      // |s - c| bounds of the bf16 / f32 screening scores, relative to |q||x|
     float max_norm;          // upper bound of |x| over the corpus (dot metric margins)
     // Speculative start threshold (MFMA scans; 0 = off).  The k slots the seed kernel fills are the best scores of k

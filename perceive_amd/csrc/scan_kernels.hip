@@ -1261,8 +1261,18 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
 // nearly all loads in flight — 6.239; with plain global loads and 64-bit vector addresses 6.268; both 6.281.  At 3 waves per
 // SIMD and 12 per CU the other waves hide what one wave's chunk buffers would; the pass runs at the read rate the memory
 // system gives this pattern.)
+#ifdef PCV_STAMPS  // diagnostic build (tools/build_stamps.sh): where a wave's time goes; the 100 MHz constant clock
+#define PCV_STAMP(slot)                                                                                            \
+    if (p.stamps && lane == 0) p.stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();
+#define PCV_COUNT(slot, n) \
+    if (p.stamps && lane == 0) p.stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + (slot)] += (n);
+#else
+#define PCV_STAMP(slot)
+#define PCV_COUNT(slot, n)
+#endif
 template <int NT, bool NTL, int WPB, int NBUF>
 __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(const ScanParams* __restrict__ pp) {
+    static_assert(WPB == 4 || WPB == 8 || WPB == 12, "4, 8 or 12 waves per workgroup");
     const ScanParams& p = *pp;
     extern __shared__ uint4 lq8[];  // [NT*32][LDQ] pieces of 16 int8
     const int D4 = p.D4;
@@ -1275,6 +1285,7 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     __shared__ float lsq[NT * 32], lvq[NT * 32];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PCV_STAMP(0)
     for (int i = threadIdx.x; i < NT * 32 * P16; i += WPB * 64) {  // the tile quantize_queries_kernel prepared
         const int q = i / P16, pc = i - q * P16;
         lq8[(size_t)q * LDQ + pc] = __builtin_bit_cast(uint4, gld4((const float4*)p.q8 + i));
@@ -1304,6 +1315,7 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 
     const uint32_t total_waves = gridDim.x * WPB;
     if (blockIdx.x * WPB + wave >= p.total_blocks) return;
+    PCV_STAMP(1)
 
     i32x16 acc[NT];
 #pragma unroll
@@ -1399,10 +1411,20 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 #pragma unroll
         for (int t = 0; t < NT; ++t) any |= mask[t] != 0;
         if (__any(any)) {
+#ifdef PCV_STAMPS
+            const unsigned long long ts = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
             for (int t = 0; t < NT; ++t) fine_survivors(p, mask[t], t, esc, elb, ltau0, lane, D4);
+#ifdef PCV_STAMPS
+            PCV_COUNT(5, __builtin_amdgcn_s_memrealtime() - ts)  // time inside the fine screen
+            PCV_COUNT(6, 1)                                      // blocks that reached it
+#endif
         }
+        PCV_COUNT(7, 1)  // blocks that passed the pre-test
         }
+        PCV_COUNT(4, 1)  // blocks
+        PCV_STAMP(3)     // (the last one stays: the wave's end)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -2219,7 +2241,10 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
         if (ntl) launch_mfma8_variant<1, true>(st, dp, grid, lds);
         else launch_mfma8_variant<1, false>(st, dp, grid, lds);
     } else if (NT == 2) {
-        if (ntl) launch_mfma8_variant<2, true>(st, dp, grid, lds);
+        if (ntl && (p.flags & (1u << 28))) {  // (comparison: one 12-wave workgroup per CU instead of three 4-wave ones)
+            const unsigned g12 = std::min<unsigned>((unsigned)num_cus, (p.total_blocks + 11) / 12);
+            launch_mfma8_variant<2, true, 12>(st, dp, g12, lds);
+        } else if (ntl) launch_mfma8_variant<2, true>(st, dp, grid, lds);
         else launch_mfma8_variant<2, false>(st, dp, grid, lds);
     } else if (wide8) {
         if (ntl) launch_mfma8_variant<4, true, 8>(st, dp, grid, lds);

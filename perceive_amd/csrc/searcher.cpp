@@ -97,6 +97,9 @@ struct pcv_searcher {
     DevBuf<uint16_t> d_qbf16;
     DevBuf<int8_t> d_q8;
     DevBuf<float> d_q8c;
+#ifdef PCV_STAMPS
+    DevBuf<unsigned long long> d_stamps;     // diagnostic build: per-wave time stamps of the scan launch (scan_mfma8_kernel)
+#endif
     DevBuf<uint32_t> d_spec;                 // speculative start thresholds of a pass (scan.h)
     bool spec_hold = false;                  // a guess failed: the repeat of that pass runs without one
     int spec_rest = 0;                       // ... and so do the next passes: 16 after a first failure, doubling up to 1024
@@ -612,6 +615,11 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
             }
         }
     }
+#ifdef PCV_STAMPS
+    s->d_stamps.ensure(8 * 65536);
+    PCV_HIP(hipMemsetAsync(s->d_stamps.p, 0, 8 * 65536 * sizeof(unsigned long long), st));
+    p.stamps = s->d_stamps.p;
+#endif
     p.eps32 = (float)(s->Dp + 16) * 1.2e-7f;
     p.eps16 = 0.0039101f + 2.0f * p.eps32;
     p.max_norm = s->max_norm;
@@ -729,6 +737,16 @@ bool finish_pass(pcv_searcher* s) {
     s->stats.host_wait_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     PCV_HIP(hipGetLastError());
     if (s->pending.done) return false;
+#ifdef PCV_STAMPS
+    if (const char* f = getenv("PCV_STAMPS_FILE")) {  // one record per pass: 65536 waves x 8 words
+        std::vector<unsigned long long> h(8 * 65536);
+        PCV_HIP(hipMemcpy(h.data(), s->d_stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE* fp = fopen(f, "ab")) {
+            fwrite(h.data(), sizeof(unsigned long long), h.size(), fp);
+            fclose(fp);
+        }
+    }
+#endif
     s->state_clean = true;  // rescore_select_kernel left the scan state as a pass expects it
     const int B = s->pending.B;
     const int64_t rows = s->pending.rows;
