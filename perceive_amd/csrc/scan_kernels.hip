@@ -1256,6 +1256,12 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
     set_guess(p, q, lane, have);
 }
 
+// (Where the waves' time goes, tools/build_stamps.sh, 100M x 384, 64 queries: with every wave taking the same number of blocks the
+// first workgroup to arrive on a CU is done after 5.71 ms, the second after 5.98, the third after 6.25, the launch after 6.38:
+// the CU's arbitration favours its older waves.  That is no loss: with the blocks handed out at run time — claims of 16
+// consecutive blocks from per-XCD counters, requested one claim ahead — every wave ends between 6.20 and 6.37 ms and the launch
+// takes the same 6.3-6.4 ms; so does one 12-wave workgroup per CU.  The memory system delivers ~6.2 TB/s to this access
+// pattern whether 8 or 12 waves per CU are asking.  The fine screen takes 1.2 % of a wave's time at this size.)
 // (Measured, 100M x 384, 64 queries, one box: this form 6.241 ms; with a producer that returns early once the wave's stream is
 // over — the compiler then places every wait for the case that nothing younger was requested, so that each multiply waits for
 // nearly all loads in flight — 6.239; with plain global loads and 64-bit vector addresses 6.268; both 6.281.  At 3 waves per
@@ -1272,7 +1278,6 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
 #endif
 template <int NT, bool NTL, int WPB, int NBUF>
 __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(const ScanParams* __restrict__ pp) {
-    static_assert(WPB == 4 || WPB == 8 || WPB == 12, "4, 8 or 12 waves per workgroup");
     const ScanParams& p = *pp;
     extern __shared__ uint4 lq8[];  // [NT*32][LDQ] pieces of 16 int8
     const int D4 = p.D4;
@@ -2241,10 +2246,7 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
         if (ntl) launch_mfma8_variant<1, true>(st, dp, grid, lds);
         else launch_mfma8_variant<1, false>(st, dp, grid, lds);
     } else if (NT == 2) {
-        if (ntl && (p.flags & (1u << 28))) {  // (comparison: one 12-wave workgroup per CU instead of three 4-wave ones)
-            const unsigned g12 = std::min<unsigned>((unsigned)num_cus, (p.total_blocks + 11) / 12);
-            launch_mfma8_variant<2, true, 12>(st, dp, g12, lds);
-        } else if (ntl) launch_mfma8_variant<2, true>(st, dp, grid, lds);
+        if (ntl) launch_mfma8_variant<2, true>(st, dp, grid, lds);
         else launch_mfma8_variant<2, false>(st, dp, grid, lds);
     } else if (wide8) {
         if (ntl) launch_mfma8_variant<4, true, 8>(st, dp, grid, lds);
