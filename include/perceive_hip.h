@@ -199,6 +199,19 @@ pcv_status pcv_searcher_set_tuning(pcv_searcher* s, uint32_t flags);
 enum { PCV_SCREEN_COPY_OFF = 0, PCV_SCREEN_COPY_BF16 = 1, PCV_SCREEN_COPY_AUTO = 2, PCV_SCREEN_COPY_INT8 = 3 };
 pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode);
 
+/* Mid copy: a third, optional representation of the rows — 16-bit fixed point per row, ROW-MAJOR (2 bytes per feature + 4 per
+ * row: 76.8 GB for 100M x 384) — read by the fine screen in front of the f32 rows.  Worth its memory on corpora whose
+ * coarse (int8) screen lets thousands of rows per query through (clustered embeddings): a coarse survivor then costs 768
+ * contiguous bytes instead of 96 cache lines of the blocked f32 layout, and only rows within ~1e-4 of the running threshold
+ * go on to their f32 row.  Results are identical with and without it (a certified bound, like the other screens).
+ *   PCV_MID_COPY_AUTO (default): built by a search call once the coarse screen has let more than 4096 rows per query through
+ *                        for 4 passes in a row over int8 copies, if the memory is there; dropped again — before the
+ *                        screening copies — when an allocation for rows fails
+ *   PCV_MID_COPY_ON    : built at the next finalize (an allocation failure is an error)
+ *   PCV_MID_COPY_OFF   : never built; an existing one is freed */
+enum { PCV_MID_COPY_OFF = 0, PCV_MID_COPY_AUTO = 1, PCV_MID_COPY_ON = 2 };
+pcv_status pcv_searcher_set_mid_copy(pcv_searcher* s, int mode);
+
 /* Most hits one search call ranks per query (num_results of search.rs:160; the reference's callers ask for 10 and 20). */
 enum { PCV_MAX_RESULTS = 128 };
 
@@ -318,9 +331,10 @@ typedef struct pcv_scan_stats {
                                     the f32 pieces + 32 row scales, or the bf16 pieces, or the int8 pieces + 36 scale floats */
     int32_t speculation_reruns;  /* passes repeated because a speculative start threshold (a guess taken from the seed
                                     rows and checked at the end of the pass) did not hold; results are exact either way */
-    int32_t reserved0;
+    int32_t mid_copy;            /* 1 if the last pass had the mid copy of every selected segment (pcv_searcher_set_mid_copy) */
     int64_t coarse_survivors;    /* MFMA scans: (row, query) pairs that passed the coarse screen and had their f32 row read
                                     by the fine screen, summed over queries and launches */
+    int64_t mid_survivors;       /* ... and those of them that also passed the mid screen (= f32 rows read), when a mid copy exists */
 } pcv_scan_stats;
 pcv_status pcv_searcher_last_stats(pcv_searcher* s, pcv_scan_stats* out);
 

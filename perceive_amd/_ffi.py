@@ -42,8 +42,9 @@ class ScanStats(C.Structure):
         ("host_wait_ms", C.c_float),
         ("bytes_streamed", C.c_int64),
         ("speculation_reruns", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("mid_copy", C.c_int32),
         ("coarse_survivors", C.c_int64),
+        ("mid_survivors", C.c_int64),
     ]
 
 
@@ -120,6 +121,7 @@ SYMBOLS = {
     "pcv_searcher_get_rows": (C.c_int, [_P, _I64P, C.c_int64, _F32P, _I64P]),
     "pcv_searcher_set_kernel": (C.c_int, [_P, C.c_int]),
     "pcv_searcher_set_screening_copy": (C.c_int, [_P, C.c_int]),
+    "pcv_searcher_set_mid_copy": (C.c_int, [_P, C.c_int]),
     "pcv_searcher_set_candidate_capacity": (C.c_int, [_P, C.c_uint32]),
     "pcv_searcher_set_tuning": (C.c_int, [_P, C.c_uint32]),
     "pcv_searcher_search": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _I64P, _F32P, _INTP]),

@@ -21,6 +21,14 @@
 // 384 B per 384-d vector, with the certified bound
 //       |c - acc / (s_row s_q)| <= |q'|_1 * 0.5 / s_row  +  |x^|_1 / s_row * 0.5 / s_q        (+ the f32 term eps32)
 // and |x^|_1 <= sqrt(D) (s_row |y|_2 + 0.5 sqrt(D)), so one float per row (s_row) is all the test needs.
+//
+// Mid copy (optional, built when the coarse screen of a corpus lets many rows through: clustered embeddings): y = row x scale
+// quantised per row to int16, Y_i = rint(y_i * s2), s2 = 32766 / max|y_i|, stored ROW-MAJOR, Dp int16 per row:
+//       mid16[row * (Dp / 8) + piece]          scale16[row] = s2  (NaN = row not searchable)
+// A coarse survivor's exact-f32 check reads its f32 row out of the blocked layout — 96 pieces of 16 bytes, 512 bytes apart:
+// 96 cache lines, 12 KB of traffic for 1536 bytes.  With the mid copy the fine screen first reads the row's 768 contiguous bytes
+// (6 lines) and drops it unless   q'.Y / s2  >=  tau - (|q'|_1 * 0.5002 / s2 + margin32 * 1.5)   — |y_i - Y_i / s2| <= 0.5002 / s2,
+// so the bound is ~1e-4 in cosine, the size of the f32 margin itself: what passes goes on to the f32 row as before.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -54,6 +62,8 @@ struct SegDesc {
     uint32_t pad;
     const uint4* blk16;  // bf16 screening copy (see below), or nullptr
     const uint4* blk8;   // int8 screening copy, or nullptr
+    const uint4* mid16;  // row-major 16-bit copy (see below), or nullptr
+    const float* scale16;
     const float* scale8; // [nblocks][kScale8Stride] quantisation scales of the int8 copy's rows (NaN = row not searchable), within a
                          // block in the order of the MFMA accumulators (row 8g + 4h + j at 16h + 4g + j), then the smallest
                          // and largest scale of set h = 0 and of set h = 1
@@ -82,7 +92,7 @@ struct ScanParams {
     float* qf32;             // [B][Dp]   scan-side query (normalised for cosine), zero padded
     uint16_t* qbf16;         // [128][Dp] same, rounded to bf16
     int8_t* q8;              // [128][Dp8] same, quantised per query to int8 (int8 screen; Dp8 = Dp rounded up to 128)
-    float* q8c;              // [128][2]  s_q (quantisation scale, 0 = dead query) and V_q of the int8 test (scan_mfma8_kernel)
+    float* q8c;              // [256][4]  s_q (quantisation scale, 0 = dead query), V_q of the int8 test (scan_mfma8_kernel), |q'|_1 (mid screen), -
     float* qraw;             // [B][Dp]   original query values, zero padded (exact rescoring)
     float* margin;           // [B]  coarse screen: rows with s16 < tau - margin are dropped       (eps16 + eps32)
     float* margin32;         // [B]  fine screen:   rows with s32 < tau - margin32 are dropped     (2 * eps32)
@@ -95,7 +105,7 @@ struct ScanParams {
     pcv_hit_dev* out;        // [B][k] device results
     pcv_hit_dev* out_host;   // pinned host mirror of `out`, or nullptr
     uint32_t* cnt_host;      // [B] pinned host: survivors per query, uncapped (the host sizes a rerun from it)
-    uint32_t* coarse_host;   // [B] pinned host: coarse survivors per query (MFMA scans)
+    uint32_t* coarse_host;   // [2][256] pinned host: coarse survivors per query (MFMA scans), then the pairs the mid screen let through
     pcv_hit_dev* flag_rec;   // overflow record behind a shard's hit list (device), or nullptr
     uint32_t cand_cap;
     uint32_t seed_blocks;    // blocks of segment 0 ranked by the seed kernel: blocks i << seed_shift, i < seed_blocks — spread
@@ -160,6 +170,8 @@ void launch_coarse_pack8(hipStream_t st, const float4* blk, const float* scale, 
                          uint32_t nblocks, int D4);
 void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);  // quantises the queries first
 int mfma8_pass_queries(int Dp);  // queries one int8 MFMA pass can take (LDS-limited)
+// mid copy + its scales of rows [first_row, nrows) of a segment
+void launch_mid_pack(hipStream_t st, const float4* blk, const float* scale, uint4* mid16, float* scale16, uint32_t first_row, uint32_t nrows, int D4);
 void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nrows, uint32_t row0, int D, int D4, uint64_t seed,
                        int64_t first_row, int normalize, uint32_t n_clusters, float noise, float amp_lo = 0.0f, float amp_hi = 0.0f);
 void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const int64_t* d_pos, int64_t n, int D,

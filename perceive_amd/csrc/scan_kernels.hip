@@ -106,6 +106,8 @@ struct SegCursor {
     const uint4* blk16 = nullptr;
     const uint4* blk8 = nullptr;
     const float* scale8 = nullptr;
+    const uint4* mid16 = nullptr;
+    const float* scale16 = nullptr;
 };
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 template <class T>
@@ -134,6 +136,8 @@ __device__ __forceinline__ void seek_seg(const ScanParams& p, SegCursor& c, uint
     c.blk16 = uniform_ptr(gld(&p.seg[lo].blk16));
     c.blk8 = uniform_ptr(gld(&p.seg[lo].blk8));
     c.scale8 = uniform_ptr(gld(&p.seg[lo].scale8));
+    c.mid16 = uniform_ptr(gld(&p.seg[lo].mid16));
+    c.scale16 = uniform_ptr(gld(&p.seg[lo].scale16));
 }
 
 // slots[q][0..k) always hold f32 scores of k DISTINCT rows (or -inf), each slot only ever grows, so
@@ -354,6 +358,41 @@ __global__ __launch_bounds__(256) void coarse_pack8_kernel(const float4* __restr
 }
 
 
+// Mid copy of rows [first_row, nrows) (scan.h): one wave per row at a time; lane j < Dp/8 owns the 8 features 8j..8j+7 (two
+// pieces of the blocked row), the maximum goes round the wave, the 16 bytes go out as part of the row's Dp * 2 contiguous ones.
+__global__ __launch_bounds__(256) void mid_pack_kernel(const float4* __restrict__ blk, const float* __restrict__ scale, uint4* __restrict__ mid16,
+                                                       float* __restrict__ scale16, uint32_t first_row, uint32_t nrows, int D4) {
+    const int lane = threadIdx.x & 63;
+    const int P8 = D4 >> 1;  // 16-byte pieces of a mid row
+    for (uint32_t row = first_row + blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += gridDim.x * 4) {
+        const float sc = scale[row];
+        const float4* src = blk + (size_t)(row >> 5) * D4 * 32 + (row & 31);
+        float mx = 0.0f;
+        for (int j = lane; j < P8; j += 64) {
+            const float4 a = src[(size_t)(2 * j) * 32], b = src[(size_t)(2 * j + 1) * 32];
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(a.x * sc), fabsf(a.y * sc)), fmaxf(fabsf(a.z * sc), fabsf(a.w * sc))),
+                                 fmaxf(fmaxf(fabsf(b.x * sc), fabsf(b.y * sc)), fmaxf(fabsf(b.z * sc), fabsf(b.w * sc)))));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const bool searchable = sc != 0.0f && mx < __builtin_inff();
+        const float s2 = !searchable ? 0.0f : (mx > 0.0f ? 32766.0f / mx : 1.0f);
+        for (int j = lane; j < P8; j += 64) {
+            const float4 a = src[(size_t)(2 * j) * 32], b = src[(size_t)(2 * j + 1) * 32];
+            const float y[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, b.x * sc, b.y * sc, b.z * sc, b.w * sc};
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int lo = searchable ? max(-32767, min(32767, (int)rintf(y[2 * e] * s2))) : 0;
+                const int hi = searchable ? max(-32767, min(32767, (int)rintf(y[2 * e + 1] * s2))) : 0;
+                w[e] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+            }
+            mid16[(size_t)row * P8 + j] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        if (lane == 0) scale16[row] = searchable ? s2 : __builtin_nanf("");
+    }
+}
+
 struct SynthShape {  // n_clusters == 0: plain i.i.d. rows, times a per-row amplitude in [amp_lo, amp_lo + amp_span) if amp_span >= 0
     uint32_t n_clusters;
     float noise, inv_sqrt_d;
@@ -445,6 +484,7 @@ __global__ __launch_bounds__(256) void reset_scan_state_kernel(uint32_t* __restr
         tau[t * kHot] = kKeyNegInf;
         cand_cnt[t * kHot] = 0;
         cand_cnt[t * kHot + 32] = 0;
+        cand_cnt[t * kHot + 33] = 0;
     }
 }
 
@@ -935,6 +975,32 @@ __device__ __forceinline__ void fine_survivors(const ScanParams& p, uint32_t mas
             // per survivor (tested one after the other they were three, ~6 us under a saturated stream)
             const float sc = gld(&scp[rib]);
             const uint32_t tkey = ld_relaxed(&p.tau[q * kHot]);
+            if (esc.mid16) {
+                // mid screen (scan.h): the row's 16-bit copy, Dp * 2 contiguous bytes, one 16-byte piece per lane; only what it
+                // cannot rule out goes on to the f32 row.  (Requested with scale and threshold: one round trip.)
+                const uint32_t row = elb * 32 + (uint32_t)rib;
+                const float s2 = gld(&esc.scale16[row]);
+                float part = 0.0f;
+                if (lane < (Dp >> 3)) {
+                    const uint4 pv = __builtin_bit_cast(uint4, gld4((const float4*)esc.mid16 + (size_t)row * (Dp >> 3) + lane));
+                    const float4 qa = gld4(p.qf32 + (size_t)q * Dp + 8 * lane), qb = gld4(p.qf32 + (size_t)q * Dp + 8 * lane + 4);
+                    part = qa.x * (float)(int16_t)(pv.x & 0xffff);
+                    part = fmaf(qa.y, (float)((int32_t)pv.x >> 16), part);
+                    part = fmaf(qa.z, (float)(int16_t)(pv.y & 0xffff), part);
+                    part = fmaf(qa.w, (float)((int32_t)pv.y >> 16), part);
+                    part = fmaf(qb.x, (float)(int16_t)(pv.z & 0xffff), part);
+                    part = fmaf(qb.y, (float)((int32_t)pv.z >> 16), part);
+                    part = fmaf(qb.z, (float)(int16_t)(pv.w & 0xffff), part);
+                    part = fmaf(qb.w, (float)((int32_t)pv.w >> 16), part);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+                if (sc == 0.0f) continue;
+                const float taum = key_f32(max(ltau0[q], tkey));
+                const float quant = gld(&p.q8c[4 * q + 2]) * 0.5003f / s2;  // |q'|_1 * 0.5002 / s2, rounded up
+                if (!(part / s2 >= taum - (quant + 1.5f * m32))) continue;  // (NaN scale: dropped)
+                if (lane == 0) g_atomic_add(&p.cand_cnt[q * kHot + 33], 1u);  // statistics: pairs the mid screen let through
+            }
             const float dot = wave_dot_f32(p.qf32 + (size_t)q * Dp, bbase + rib, D4, lane);
             if (sc == 0.0f) continue;  // padding / unsearchable row
             const float s32 = dot * sc;
@@ -1250,8 +1316,9 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
         if (i < Dp8) row[i] = (int8_t)max(-127, min(127, (int)rintf((s_q != 0.0f ? x[j] : 0.0f) * s_q)));
     }
     if (lane == 0) {
-        p.q8c[2 * q] = s_q;
-        p.q8c[2 * q + 1] = 0.5002f * l1 * s_q + 0.2501f * (float)Dp8 + 4.0f;
+        p.q8c[4 * q] = s_q;
+        p.q8c[4 * q + 1] = 0.5002f * l1 * s_q + 0.2501f * (float)Dp8 + 4.0f;
+        p.q8c[4 * q + 2] = l1;
     }
     set_guess(p, q, lane, have);
 }
@@ -1296,8 +1363,8 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         lq8[(size_t)q * LDQ + pc] = __builtin_bit_cast(uint4, gld4((const float4*)p.q8 + i));
     }
     for (int q = threadIdx.x; q < NT * 32; q += WPB * 64) {
-        lsq[q] = gld(&p.q8c[2 * q]);
-        lvq[q] = gld(&p.q8c[2 * q + 1]);
+        lsq[q] = gld(&p.q8c[4 * q]);
+        lvq[q] = gld(&p.q8c[4 * q + 1]);
     }
     for (int q = threadIdx.x >> 2; q < NT * 32; q += WPB * 16) {
         const uint32_t key = seed_threshold_key(p, q, threadIdx.x & 3);
@@ -1516,8 +1583,8 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
         lq8[(size_t)q * LDQ + pc] = __builtin_bit_cast(uint4, gld4((const float4*)p.q8 + i));
     }
     for (int q = threadIdx.x; q < TQ; q += WPB * 64) {
-        lsq[q] = gld(&p.q8c[2 * q]);
-        lvq[q] = gld(&p.q8c[2 * q + 1]);
+        lsq[q] = gld(&p.q8c[4 * q]);
+        lvq[q] = gld(&p.q8c[4 * q + 1]);
         le32[q] = q < p.B ? 0.5f * gld(&p.margin32[q]) : 0.0f;
     }
     for (int q = threadIdx.x >> 2; q < TQ; q += WPB * 16) {
@@ -1911,8 +1978,12 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
     if (tid == 0) {
         const bool failed = guessed && n_spec < (uint32_t)p.k;  // (after the last slice's barrier)
         if (p.cnt_host) p.cnt_host[q] = failed ? kSpecFailed : raw_cnt;
-        if (p.coarse_host) p.coarse_host[q] = ld_relaxed(&p.cand_cnt[q * kHot + 32]);
+        if (p.coarse_host) {
+            p.coarse_host[q] = ld_relaxed(&p.cand_cnt[q * kHot + 32]);
+            p.coarse_host[kMfmaQueries + q] = ld_relaxed(&p.cand_cnt[q * kHot + 33]);
+        }
         st_relaxed(&p.cand_cnt[q * kHot + 32], 0u);
+        st_relaxed(&p.cand_cnt[q * kHot + 33], 0u);
         if ((raw_cnt > p.cand_cap || failed) && p.flag_rec) p.flag_rec->pos = 1;
         st_relaxed(&p.tau[q * kHot], kKeyNegInf);
         st_relaxed(&p.cand_cnt[q * kHot], 0u);
@@ -2263,6 +2334,13 @@ void launch_coarse_pack8(hipStream_t st, const float4* blk, const float* scale, 
     if (first_block >= nblocks) return;
     const unsigned grid = (unsigned)std::min<uint32_t>((nblocks - first_block + 3) / 4, 1u << 16);
     coarse_pack8_kernel<<<grid, 256, 0, st>>>(blk, scale, blk8, scale8, first_block, nblocks, D4);
+    PCV_LAUNCHED();
+}
+
+void launch_mid_pack(hipStream_t st, const float4* blk, const float* scale, uint4* mid16, float* scale16, uint32_t first_row, uint32_t nrows, int D4) {
+    if (first_row >= nrows) return;
+    const unsigned grid = (unsigned)std::min<uint32_t>((nrows - first_row + 3) / 4, 256u * 8 * 4);
+    mid_pack_kernel<<<grid, 256, 0, st>>>(blk, scale, mid16, scale16, first_row, nrows, D4);
     PCV_LAUNCHED();
 }
 

@@ -30,6 +30,9 @@ struct Segment {
     uint4* blk16 = nullptr;  // bf16 screening copy (scan.h), built at finalize for the rows that have their scale
     uint4* blk8 = nullptr;   // int8 screening copy + its per-row quantisation scales
     float* scale8 = nullptr;
+    uint4* mid16 = nullptr;  // row-major 16-bit copy (scan.h) + its per-row scales
+    float* scale16 = nullptr;
+    uint32_t mid_rows = 0;   // rows the mid copy covers
     int64_t id0 = 0;
     int64_t pos0 = 0;
     uint32_t nrows = 0, cap_rows = 0, scaled_rows = 0;
@@ -153,7 +156,7 @@ struct pcv_searcher {
     // what one pass brings back: written by rescore_select_kernel straight into pinned memory
     struct Pinned {
         uint32_t cnt[kMfmaQueries];
-        uint32_t coarse[kMfmaQueries];  // rows per query that passed the coarse screen (statistics)
+        uint32_t coarse[2 * kMfmaQueries];  // rows per query that passed the coarse screen, then those that also passed the mid screen (statistics)
         float spec_base[kMfmaQueries];  // median / best seed slot per query, k-th best exact score per query (scan.h: spec_gap)
         float spec_top[kMfmaQueries];
         float kth[kMfmaQueries];
@@ -164,6 +167,10 @@ struct pcv_searcher {
     uint32_t cand_cap = 8192;
     uint32_t scan_flags = 0;  // tuning knobs: PCV_SCAN_FLAGS at creation, pcv_searcher_set_tuning
     bool fail_copy_alloc = false;  // PCV_TUNE_FAIL_COPY_ALLOC
+    int mid_copy = PCV_MID_COPY_AUTO;        // pcv_searcher_set_mid_copy
+    bool mid_gave_way = false;               // AUTO: building it failed, or it was dropped to make room for rows: not tried again
+    bool mids_present = false;               // every row of every segment is covered by a mid copy
+    int mid_hot_passes = 0;                  // AUTO: passes in a row whose coarse screen let more than kMidTrigger rows per query through
     int screen_copy = PCV_SCREEN_COPY_AUTO;  // pcv_searcher_set_screening_copy
     bool screen_copy_gave_way = false;       // AUTO: the copies were dropped to make room for rows
     int copies_kind = 0;                     // 0: not every row of every segment is covered by a screening copy; 1 bf16; 2 int8
@@ -194,6 +201,7 @@ struct pcv_searcher {
         bool done = false;  // nothing was launched (no selected rows): only the stream has to drain
         int B = 0;
         int64_t rows = 0;
+        bool mid = false;  // every selected segment had its mid copy
         int src = 0;  // what the scan streamed: 0 f32 rows, 1 bf16 copies, 2 int8 copies
         int64_t stream_bytes = 0;  // ... and how many bytes of it the scan kernel has to read, padding included
         bool replayed = false;  // launched as a graph: only the pass as a whole was timed
@@ -223,7 +231,63 @@ void free_segment(Segment& g) {
     if (g.blk16) (void)hipFree(g.blk16);
     if (g.blk8) (void)hipFree(g.blk8);
     if (g.scale8) (void)hipFree(g.scale8);
+    if (g.mid16) (void)hipFree(g.mid16);
+    if (g.scale16) (void)hipFree(g.scale16);
     g = Segment();
+}
+
+constexpr int64_t kMidTrigger = 4096;  // coarse survivors per query and pass above which AUTO builds the mid copy ...
+constexpr int kMidPasses = 4;          // ... once that many passes in a row were above it
+
+void drop_mid_copies(pcv_searcher* s) {
+    s->mids_present = false;
+    for (auto& src : s->sources)
+        for (auto& g : src.segs) {
+            if (g.mid16) (void)hipFree(g.mid16);
+            if (g.scale16) (void)hipFree(g.scale16);
+            g.mid16 = nullptr;
+            g.scale16 = nullptr;
+            g.mid_rows = 0;
+        }
+}
+
+// Mid copies (scan.h) of the rows that have their scale and no copy yet.  `must`: an allocation failure is an error
+// (PCV_MID_COPY_ON); otherwise it ends the attempt for good (mid_gave_way).
+void build_mid_copies(pcv_searcher* s, bool must) {
+    hipStream_t st = s->ctx->stream;
+    for (auto& src : s->sources)
+        for (auto& g : src.segs) {
+            if (g.nrows == 0 || (g.mid16 && g.mid_rows >= g.scaled_rows)) continue;
+            if (!g.mid16) {
+                const size_t bytes = (size_t)g.cap_rows * s->Dp * 2;
+                hipError_t e = s->fail_copy_alloc ? hipErrorOutOfMemory : hipMalloc((void**)&g.mid16, bytes);
+                if (e == hipSuccess) {
+                    e = hipMalloc((void**)&g.scale16, (size_t)g.cap_rows * sizeof(float));
+                    if (e != hipSuccess) {
+                        (void)hipFree(g.mid16);
+                        g.mid16 = nullptr;
+                    }
+                }
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    g.mid16 = nullptr;
+                    g.scale16 = nullptr;
+                    if (must)
+                        PCV_FAIL(PCV_ERR_DEVICE, "hipMalloc of %.2f GB for the mid copy of %u rows failed: %s", bytes / 1e9, g.cap_rows, hipGetErrorString(e));
+                    PCV_HIP(hipStreamSynchronize(st));
+                    drop_mid_copies(s);
+                    s->mid_gave_way = true;
+                    return;
+                }
+                g.mid_rows = 0;
+            }
+            launch_mid_pack(st, g.blk, g.scale, g.mid16, g.scale16, g.mid_rows, g.scaled_rows, s->D4);
+            g.mid_rows = g.scaled_rows;
+        }
+    s->mids_present = true;
+    for (const auto& src : s->sources)
+        for (const auto& g : src.segs)
+            if (g.nrows > 0 && (!g.mid16 || g.mid_rows < g.nrows)) s->mids_present = false;
 }
 
 void drop_screening_copies(pcv_searcher* s) {
@@ -258,6 +322,14 @@ Segment alloc_segment(pcv_searcher* s, int64_t cap_rows, bool with_ids) {
     g.cap_rows = nblk * kBlockRows;
     const size_t bytes = (size_t)nblk * s->D4 * 32 * sizeof(float4);
     hipError_t e = hipMalloc((void**)&g.blk, bytes);
+    if (e != hipSuccess && s->mids_present && s->mid_copy == PCV_MID_COPY_AUTO) {
+        // the rows themselves come first: the mid copies go before the screening copies do
+        (void)hipGetLastError();
+        PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+        drop_mid_copies(s);
+        s->mid_gave_way = true;
+        e = hipMalloc((void**)&g.blk, bytes);
+    }
     if (e != hipSuccess && s->screen_copy == PCV_SCREEN_COPY_AUTO && !s->screen_copy_gave_way) {
         // the rows themselves come first: give the screening copies back and scan the f32 rows from now on
         (void)hipGetLastError();
@@ -440,11 +512,17 @@ void do_finalize(pcv_searcher* s) {
     s->sources.erase(std::remove_if(s->sources.begin(), s->sources.end(),
                                     [](const Source& x) { return x.segs.empty(); }),
                      s->sources.end());
+    if (s->mid_copy == PCV_MID_COPY_ON || (s->mid_copy == PCV_MID_COPY_AUTO && s->mids_present))
+        build_mid_copies(s, s->mid_copy == PCV_MID_COPY_ON);  // new rows join the copy that is there
     assign_positions(s);
     s->copies_kind = s->sources.empty() ? 0 : copy_kind_wanted(s);
     for (const auto& src : s->sources)
         for (const auto& g : src.segs)
             if (g.nrows > 0 && ((s->copies_kind == 1 ? g.blk16 == nullptr : g.blk8 == nullptr) || g.copied_rows < g.nrows)) s->copies_kind = 0;
+    if (s->mids_present)
+        for (const auto& src : s->sources)
+            for (const auto& g : src.segs)
+                if (g.nrows > 0 && (!g.mid16 || g.mid_rows < g.nrows)) s->mids_present = false;
     uint32_t bits = 0;
     PCV_HIP(hipMemcpyAsync(&bits, s->d_max_norm_bits, 4, hipMemcpyDeviceToHost, st));
     PCV_HIP(hipStreamSynchronize(st));
@@ -479,7 +557,7 @@ void ensure_workspace(pcv_searcher* s) {
     s->d_qraw.ensure(Q * s->Dp);
     s->d_qbf16.ensure(Q * s->Dp);
     s->d_q8.ensure(Q * (size_t)((s->Dp + 127) & ~127));
-    s->d_q8c.ensure(Q * 2);
+    s->d_q8c.ensure(Q * 4);
     s->d_spec.ensure(Q);
     s->d_margin.ensure(Q);
     s->d_margin32.ensure(Q);
@@ -538,13 +616,16 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p = ScanParams{};
     uint32_t blk0 = 0;
     int64_t rows = 0;
+    bool have_mid = true;
     // stream the screening copies iff every selected segment has one of the kind the searcher keeps
     int src_kind = (kernel == PCV_KERNEL_MFMA) ? copy_kind_wanted(s) : 0;
     if (src_kind == 2 && (mfma8_pass_queries(s->Dp) < B || s->Dp > 1024)) src_kind = 0;
     const int src_wanted = src_kind;
     for (int i = 0; i < nseg; ++i) {
         const Segment& g = *segs[i].g;
-        tab[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), blk0, 0, g.blk16, g.blk8, g.scale8};
+        const bool mid = g.mid16 != nullptr && g.mid_rows >= g.nrows;  // (a copy that does not cover every row yet is not used)
+        tab[i] = SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), blk0, 0, g.blk16, g.blk8, mid ? g.mid16 : nullptr, mid ? g.scale16 : nullptr, g.scale8};
+        have_mid = have_mid && mid;
         if ((src_kind == 1 ? g.blk16 == nullptr : (src_kind == 2 ? g.blk8 == nullptr : false)) || g.copied_rows < g.nrows) src_kind = 0;
         PCV_REQUIRE((uint64_t)blk0 + g.nblocks() < 0xffffff00ull, "search: more than 2^32 row blocks in one launch");
         blk0 += g.nblocks();
@@ -714,6 +795,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     s->pending.B = B;
     s->pending.rows = rows;
     s->pending.src = src_kind;
+    s->pending.mid = have_mid && nseg > 0;
     // what the scan kernel of this pass must pull from HBM, per 32-row block: the int8 pieces + the 36 floats of scales and
     // set extremes; the bf16 pieces; or the f32 pieces + the 32 row scales
     const int64_t Dp8 = (s->Dp + 127) & ~127;
@@ -778,7 +860,19 @@ bool finish_pass(pcv_searcher* s) {
         mx = std::max(mx, cnt[b]);
         sum += cnt[b];
     }
-    for (int b = 0; b < B; ++b) s->stats.coarse_survivors += s->pin->coarse[b];
+    int64_t coarse = 0;
+    for (int b = 0; b < B; ++b) {
+        coarse += s->pin->coarse[b];
+        s->stats.mid_survivors += s->pin->coarse[kMfmaQueries + b];
+    }
+    s->stats.coarse_survivors += coarse;
+    s->stats.mid_copy = s->pending.mid ? 1 : 0;
+    // AUTO: a corpus whose coarse screen keeps letting thousands of rows per query through gets its mid copy (built by the
+    // next search call, before its passes: search_hits)
+    if (s->pending.src == 2 && !s->pending.mid && coarse > kMidTrigger * (int64_t)B)
+        s->mid_hot_passes += 1;
+    else
+        s->mid_hot_passes = 0;
     if (mx <= s->cand_cap && !guess_failed) {
         s->stats.candidates += sum;
         s->spec_hold = false;
@@ -869,6 +963,17 @@ void search_hits(pcv_searcher* s, const float* queries, int n_queries, const int
     s->stats.kernel_used = kernel;
     if (segs.empty()) return;
     const int qstep = pass_queries(s, kernel);
+    if (s->mid_copy == PCV_MID_COPY_AUTO && !s->mids_present && !s->mid_gave_way && s->mid_hot_passes >= kMidPasses) {
+        // (only if the memory is plainly there: the copy is a convenience, the headroom is for rows)
+        size_t free_b = 0, total_b = 0, need = 0;
+        for (const auto& src : s->sources)
+            for (const auto& g : src.segs) need += (size_t)g.cap_rows * ((size_t)s->Dp * 2 + 4);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + ((size_t)4 << 30))
+            build_mid_copies(s, false);
+        else
+            s->mid_gave_way = true;
+        s->mid_hot_passes = 0;
+    }
     for (int q0 = 0; q0 < n_queries; q0 += qstep) {
         const int B = std::min(qstep, n_queries - q0);
         run_pass(s, queries + (size_t)q0 * s->D, B, segs.data(), (int)segs.size(), k, kernel, nullptr, true);
@@ -1216,7 +1321,7 @@ pcv_status pcv_searcher_get_rows(pcv_searcher* s, const int64_t* positions, int6
         std::vector<SegDesc> segs;
         for (auto& src : s->sources)
             for (auto& g : src.segs)
-                segs.push_back(SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), 0, 0});
+                segs.push_back(SegDesc{g.blk, g.scale, g.ids, g.id0, g.pos0, g.nrows, g.nblocks(), 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr});
         DevBuf<SegDesc> d_segs;
         DevBuf<int64_t> d_pos, d_ids;
         DevBuf<float> d_rows;
@@ -1267,6 +1372,24 @@ pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode) {
         }
         s->screen_copy = mode;
         s->screen_copy_gave_way = false;
+    });
+}
+
+pcv_status pcv_searcher_set_mid_copy(pcv_searcher* s, int mode) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "searcher_set_mid_copy: searcher is NULL");
+        PCV_REQUIRE(mode >= PCV_MID_COPY_OFF && mode <= PCV_MID_COPY_ON, "searcher_set_mid_copy: unknown mode %d", mode);
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->pending.active, "searcher_set_mid_copy: a queued pass has not been collected");
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        if (mode == PCV_MID_COPY_OFF) {
+            PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+            drop_mid_copies(s);
+        }
+        if (mode == PCV_MID_COPY_ON && !s->mids_present) s->dirty = true;  // built by the next finalize
+        s->mid_copy = mode;
+        s->mid_gave_way = false;
+        s->mid_hot_passes = 0;
     });
 }
 
@@ -1599,6 +1722,8 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
             total.kernel_used = s->stats.kernel_used;
             total.bytes_streamed += s->stats.bytes_streamed;
             total.coarse_survivors += s->stats.coarse_survivors;
+            total.mid_survivors += s->stats.mid_survivors;
+            total.mid_copy = s->stats.mid_copy;
             total.screening_copy = s->stats.screening_copy;
         };
         for (int q0 = 0; q0 < n_queries; q0 += qstep) {

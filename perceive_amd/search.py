@@ -256,6 +256,11 @@ class Searcher:
         finalize.  Results do not depend on it."""
         _ffi.check(_ffi.lib().pcv_searcher_set_screening_copy(self._handle, {"off": 0, "bf16": 1, "on": 1, "auto": 2, "int8": 3}[mode]))
 
+    def set_mid_copy(self, mode="auto"):
+        """"off" | "auto" | "on": the row-major 16-bit copy the fine screen reads in front of the f32 rows
+        (pcv_searcher_set_mid_copy); results do not depend on it."""
+        _ffi.check(_ffi.lib().pcv_searcher_set_mid_copy(self._handle, {"off": 0, "auto": 1, "on": 2}[mode]))
+
     def set_shard_offset(self, first_global_pos):
         _ffi.check(_ffi.lib().pcv_searcher_set_shard_offset(self._handle, int(first_global_pos)))
 
@@ -294,7 +299,7 @@ class Searcher:
     def last_stats(self):
         st = _ffi.ScanStats()
         _ffi.check(_ffi.lib().pcv_searcher_last_stats(self._handle, C.byref(st)))
-        return {f: getattr(st, f) for f, _ in _ffi.ScanStats._fields_ if f != "reserved"}
+        return {f: getattr(st, f) for f, _ in _ffi.ScanStats._fields_}
 
     @property
     def _handle(self):

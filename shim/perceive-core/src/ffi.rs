@@ -56,8 +56,9 @@ pub struct pcv_scan_stats {
     pub host_wait_ms: f32,
     pub bytes_streamed: i64,
     pub speculation_reruns: i32,
-    pub reserved0: i32,
+    pub mid_copy: i32,
     pub coarse_survivors: i64,
+    pub mid_survivors: i64,
 }
 
 #[repr(C)]
@@ -107,6 +108,9 @@ pub const PCV_SCREEN_COPY_OFF: c_int = 0;
 pub const PCV_SCREEN_COPY_BF16: c_int = 1;
 pub const PCV_SCREEN_COPY_AUTO: c_int = 2;
 pub const PCV_SCREEN_COPY_INT8: c_int = 3;
+pub const PCV_MID_COPY_OFF: c_int = 0;
+pub const PCV_MID_COPY_AUTO: c_int = 1;
+pub const PCV_MID_COPY_ON: c_int = 2;
 pub const PCV_MAX_RESULTS: c_int = 128;
 pub const PCV_GELU_ERF: c_int = 0;
 pub const PCV_GELU_TANH: c_int = 1;
@@ -167,6 +171,7 @@ extern "C" {
     pub fn pcv_searcher_set_candidate_capacity(s: *mut pcv_searcher, n_candidates: u32) -> c_int;
     pub fn pcv_searcher_set_tuning(s: *mut pcv_searcher, flags: u32) -> c_int;
     pub fn pcv_searcher_set_screening_copy(s: *mut pcv_searcher, mode: c_int) -> c_int;
+    pub fn pcv_searcher_set_mid_copy(s: *mut pcv_searcher, mode: c_int) -> c_int;
     pub fn pcv_searcher_search(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;
     pub fn pcv_searcher_set_shard_offset(s: *mut pcv_searcher, first_global_pos: i64) -> c_int;
     pub fn pcv_searcher_search_device(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void, async_: c_int) -> c_int;

@@ -1262,3 +1262,109 @@ def test_guess_on_and_off_give_the_same_hits(ctx, monkeypatch, kind):
         for (ia, sa), (ib, sb) in zip(hits["0"], hits["32"]):
             np.testing.assert_array_equal(ia, ib)
             np.testing.assert_array_equal(sa, sb)
+
+
+def _clustered(oracle, n, d, n_clusters, noise, seed, nq, rng):
+    rows = oracle.synth_rows_clustered(seed, 0, n, d, n_clusters, noise)
+    probe = rows[rng.integers(0, n, nq)]
+    return rows, (probe + 0.5 * noise * rng.standard_normal(probe.shape)).astype(np.float32)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_mid_copy_is_invisible_in_the_results_and_cuts_the_f32_reads(ctx, oracle, metric):
+    """The row-major 16-bit mid copy (scan.h): on a clustered corpus the coarse int8 screen lets a whole cluster through per
+    query; with the mid copy nearly all of those are ruled out from 2 bytes per feature and only a few rows have their f32 row
+    read.  Hits and scores are the oracle's with the copy forced on, off, and built by AUTO after four such passes; rows added
+    later join the copy; a failed allocation switches AUTO off for good and makes ON an error."""
+    rng = np.random.default_rng(31)
+    n, d, k = 240_000, 128, 10
+    rows, q = _clustered(oracle, n, d, 16, 0.004, 0xC1, 64, rng)
+    ref = oracle.topk(q, rows, k, 1 if metric == "dot" else 0)
+    s = pa.Searcher(ctx, d, metric)
+    s.add_rows(1, rows[:200_000], np.arange(200_000))
+    s.finalize()
+    sub = oracle.topk(q, rows[:200_000], k, 1 if metric == "dot" else 0)
+
+    def check(ids, sc, want):
+        np.testing.assert_array_equal(ids, want[0])
+        if metric == "cosine":
+            np.testing.assert_allclose(sc, want[1].astype(np.float32), rtol=0, atol=1e-6)
+
+    s.set_mid_copy("off")
+    ids, sc, _ = s.search_vectors(None, k, q)
+    st0 = s.last_stats()
+    check(ids, sc, sub)
+    assert st0["screening_copy"] == 2 and st0["mid_copy"] == 0 and st0["coarse_survivors"] > 4096 * 64, st0
+    s.set_mid_copy("auto")
+    for i in range(4):  # four passes above the trigger: the fifth call builds the copy before it searches
+        ids, sc, _ = s.search_vectors(None, k, q)
+        assert s.last_stats()["mid_copy"] == 0
+        check(ids, sc, sub)
+    ids, sc, _ = s.search_vectors(None, k, q)
+    st1 = s.last_stats()
+    check(ids, sc, sub)
+    assert st1["mid_copy"] == 1 and 0 < st1["mid_survivors"] < st1["coarse_survivors"] // 8, st1
+    # rows added afterwards join the copy at finalize (AUTO keeps what it has built)
+    s.add_rows(1, rows[200_000:], np.arange(200_000, n))
+    s.finalize()
+    ids, sc, _ = s.search_vectors(None, k, q)
+    check(ids, sc, ref)
+    assert s.last_stats()["mid_copy"] == 1
+    # a second source whose copies cannot be allocated: AUTO gives the mid copy (and the int8 copies) up for good, results unchanged
+    extra = (rows[:1000] * 0.5).astype(np.float32)
+    s.set_tuning(fail_copy_alloc=True)
+    s.add_rows(2, extra, n + np.arange(1000))
+    s.finalize()
+    s.set_tuning()
+    ids, sc, _ = s.search_vectors([1], k, q)
+    check(ids, sc, ref)
+    assert s.last_stats()["mid_copy"] == 0 and s.last_stats()["screening_copy"] == 0
+    s.close()
+    # ON: built at finalize, also on a corpus the trigger would never see; OFF afterwards frees it
+    t = pa.Searcher(ctx, d, metric)
+    t.set_mid_copy("on")
+    t.add_rows(7, rows[:50_000], np.arange(50_000))
+    t.finalize()
+    ids, sc, _ = t.search_vectors(None, k, q[:5])
+    assert t.last_stats()["mid_copy"] == 1
+    want = oracle.topk(q[:5], rows[:50_000], k, 1 if metric == "dot" else 0)
+    check(ids, sc, want)
+    t.set_mid_copy("off")
+    ids2, sc2, _ = t.search_vectors(None, k, q[:5])
+    assert t.last_stats()["mid_copy"] == 0
+    np.testing.assert_array_equal(ids, ids2)
+    np.testing.assert_array_equal(sc, sc2)
+    t.close()
+    u = pa.Searcher(ctx, d, metric)
+    u.set_mid_copy("on")
+    u.set_tuning(fail_copy_alloc=True)
+    u.set_screening_copy("off")
+    u.add_rows(1, rows[:1000])
+    with pytest.raises(pa.PcvError):
+        u.finalize()
+    u.close()
+
+
+def test_mid_copy_on_rows_that_quantise_badly(ctx, oracle):
+    """Rows with one dominant feature (the per-row 16-bit scale is set by it, everything else lands on a few levels), zero rows,
+    rows of tiny norm, a zero query: the mid screen's bound must hold for each; forced on, against the oracle."""
+    rng = np.random.default_rng(32)
+    n, d, k = 40_000, 96, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[::7, 3] *= 400.0
+    rows[5::11] *= 1e-6
+    rows[100] = 0.0
+    q = rng.standard_normal((33, d)).astype(np.float32)
+    q[4] = rows[7] * 2.0
+    q[9] = 0.0
+    for metric in ("cosine", "dot"):
+        s = pa.Searcher(ctx, d, metric)
+        s.set_mid_copy("on")
+        s.add_rows(1, rows)
+        s.finalize()
+        ids, sc, cnt = s.search_vectors(None, k, q)
+        assert s.last_stats()["mid_copy"] == 1 and s.last_stats()["screening_copy"] == 2
+        opos, osc, ocnt = oracle.topk(q, rows, k, 1 if metric == "dot" else 0)
+        np.testing.assert_array_equal(cnt, ocnt)
+        np.testing.assert_array_equal(ids, opos)
+        s.close()

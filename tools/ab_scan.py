@@ -27,11 +27,13 @@ def main():
     ap.add_argument("--flags", nargs="+", default=["0"])
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--screen", default="auto")
+    ap.add_argument("--mid", default="auto", choices=["auto", "on", "off"], help="the row-major 16-bit mid copy (pcv_searcher_set_mid_copy)")
     args = ap.parse_args()
     ctx = pa.Context(0)
     s = pa.Searcher(ctx, args.dim, args.metric)
     if args.screen != "auto":
         s.set_screening_copy(args.screen)
+    s.set_mid_copy(args.mid)
     ncl = max(1, args.rows // 20_000) if args.clustered else 0
     s.add_synthetic(1, args.rows, 0x5EED, n_clusters=ncl, noise=0.004 if args.clustered else 0.0, amplitude=args.amplitude)
     s.finalize()
@@ -65,7 +67,7 @@ def main():
             gb = st["bytes_streamed"] / max(1, st["scan_launches"]) / 1e9
             print(f"rows={args.rows} dim={args.dim} {args.metric} B={B} flags={f:#x}: kernel median {np.median(t):.3f} ms  min {t.min():.3f}  "
                   f"pass {np.median(passes[f]):.3f} ms  {gb / np.median(t):.0f} GB/s = {gb / np.median(t) / 8:.3f} of 8 TB/s  launches {st['scan_launches']}  "
-                  f"cand/q {st['candidates'] / B:.0f} coarse/q {st['coarse_survivors'] / B:.0f} copy {st['screening_copy']}", flush=True)
+                  f"cand/q {st['candidates'] / B:.0f} coarse/q {st['coarse_survivors'] / B:.0f} copy {st['screening_copy']} mid {st['mid_copy']} mid/q {st['mid_survivors'] / B:.0f}", flush=True)
     s.close()
     ctx.close()
 
