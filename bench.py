@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--clustered", action="store_true",
                     help="main leg on clustered rows (centroid + noise: ~2e4 rows within 0.01 cosine of every query's top-k)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (config 2, shard, encoder, end to end, clustered)")
+    ap.add_argument("--only", default="", help="comma-separated names of the extra legs to run (default: all of them); what "
+                    "tools/profile_round.sh uses to put one leg of this file under rocprofv3 at a time")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = --rows is the whole corpus, sharded (BASELINE configs[3]); weak = --rows per GPU")
     return ap.parse_args()
@@ -203,6 +205,7 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
         "mid_copy": bool(st["mid_copy"]), "mid_survivors_per_query": float(np.mean(mids)) / batch,
         "overflow_reruns": reruns, "speculation_reruns": spec_reruns, "steps": steps,
     }
+    rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = measured_traffic(kname, streamed / max(launches, 1), clustered)
     if tuning:
         searcher.set_tuning(env_flags)
     if own and not keep:
@@ -277,19 +280,19 @@ def e2e_leg(pa, ctx, searcher, rows, steps=5, warmup=2, batch=256, seq=256, k=10
     }
 
 
-def measured_traffic(kernel, rows, dim, streamed_per_row):
-    """HBM bytes per launch from the committed PMC pass of this command (profiles/traffic.json,
-    written by tools/summarize_profiles.py; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 guide), scaled by
-    rows.  bench.py cannot collect PMC counters on itself; None when no pass covers this kernel."""
+def measured_traffic(kernel, required_bytes, clustered=False):
+    """HBM bytes per launch from the committed PMC passes of this file's legs (profiles/traffic.json, written by
+    tools/summarize_profiles.py; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 guide): the leg of the same kernel whose
+    required bytes per launch are this run's (within 2 %).  bench.py cannot collect PMC counters on itself; None when
+    no pass covers this kernel and size."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
-        if t["dim"] != dim or not t["bytes_per_row"]:
-            return None, None
-        if not (0.9 * streamed_per_row <= t["bytes_per_row"] <= 1.25 * streamed_per_row):  # the pass was taken in another streaming mode
-            return None, None
-        return t["bytes_per_row"] * rows, t["source"]
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        for t in table.values():
+            if t["kernel"].split("<")[0] == kernel and bool(t.get("clustered")) == bool(clustered) and abs(t["required_bytes_per_launch"] / required_bytes - 1.0) < 0.02:
+                return t["bytes_per_launch"] * required_bytes / t["required_bytes_per_launch"], t["source"]
     except Exception:
-        return None, None
+        pass
+    return None, None
 
 
 def measured_read_ceiling():
@@ -339,6 +342,13 @@ def main():
 
     ctx = pa.Context(local_rank if use_dist else 0)
     total_rows = args.rows * world if args.scaling == "weak" else args.rows
+    # --only with legs that bring their own corpus: the headline shrinks to a token (100k rows through the wave kernel,
+    # so that its launches do not share a kernel name with the leg under the profiler) and is marked as skipped
+    HEADLINE_LEGS = ("no_guess", "config5_end_to_end", "batch128", "batch256", "f32_rows_b64", "bf16_copy_b64")
+    only_legs = [x for x in args.only.split(",") if x]
+    token_headline = bool(only_legs) and not any(x in HEADLINE_LEGS for x in only_legs) and world == 1
+    if token_headline:
+        total_rows, args.kernel = min(total_rows, 100_000), "wave"
     lo = total_rows * rank // world
     hi = total_rows * (rank + 1) // world
     searcher = pa.Searcher(ctx, args.dim, "cosine")
@@ -438,7 +448,7 @@ def main():
         ids, scores, counts = last
         kname = scan_kernel_name(st_last, B, args.dim)
         roof = roofline_of({"bytes_streamed": per_launch_streamed}, 1, mean_scan_ms, hi - lo, args.dim)
-        traffic, traffic_src = measured_traffic(kname, (hi - lo), args.dim, per_launch_streamed / max(1, hi - lo))
+        traffic, traffic_src = measured_traffic(kname, per_launch_streamed, args.clustered)
         roof.update({
             "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "streams": {None: "f32 rows + row scales", "bf16": "bf16 screening copy",
                                                                                           "int8": "int8 screening copy + row scales"}[copy],
@@ -489,19 +499,28 @@ def main():
         if world == 1 and not args.no_extra:
             # the other legs BASELINE.json names, measured in the same run (single GPU only)
             extra = {}
+            only = only_legs
+            if token_headline:
+                out["headline_skipped"] = "--only: the top-level figures are a 100k-row token run, not a measurement"
+
+            def want(*names):
+                return not only or any(n in only for n in names)
+
             es, ew = max(3, min(args.steps, 20)), max(1, min(args.warmup, 3))
             # the same workload without the speculative start threshold (scan.h; PCV_SCAN_FLAGS bit 5): the headline's kernel
             # time includes a guess learned from the bench's own i.i.d. queries — this is the figure without it
-            ng = scan_leg(pa, ctx, total_rows, B, k, args.kernel, max(3, es // 2), ew, searcher=searcher, dim=args.dim, tuning=32)
-            out["roofline"]["no_guess"] = {"kernel_ms": ng["kernel_ms"], "frac": ng["roofline"]["frac"], "candidates_per_query": ng["candidates_per_query"]}
-            if args.dim == 384:
+            if want("no_guess"):
+                ng = scan_leg(pa, ctx, total_rows, B, k, args.kernel, max(3, es // 2), ew, searcher=searcher, dim=args.dim, tuning=32)
+                out["roofline"]["no_guess"] = {"kernel_ms": ng["kernel_ms"], "frac": ng["roofline"]["frac"], "candidates_per_query": ng["candidates_per_query"]}
+            if args.dim == 384 and want("config5_end_to_end"):
                 extra["config5_end_to_end"] = e2e_leg(pa, ctx, searcher, total_rows)
             searcher.set_kernel(args.kernel)
             if copy == "int8":
                 # larger batches on the same corpus (the block-holding form of the int8 scan up to 384-d: 128 queries; 256 in one pass)
                 for nq in (128, 256):
-                    extra[f"batch{nq}"] = scan_leg(pa, ctx, total_rows, nq, k, args.kernel, max(3, es // 2), ew, searcher=searcher, dim=args.dim)
-            if copy is not None:
+                    if want(f"batch{nq}"):
+                        extra[f"batch{nq}"] = scan_leg(pa, ctx, total_rows, nq, k, args.kernel, max(3, es // 2), ew, searcher=searcher, dim=args.dim)
+            if copy is not None and want("f32_rows_b64", "bf16_copy_b64"):
                 # the same corpus and queries' shape without the int8 copy: the scan streams the f32 rows themselves
                 # (1536 B/vector, the SURVEY 8d / north_star workload) or the bf16 copy; results are the same exact top-k
                 held = {"int8": args.dim + 5, "bf16": 2 * args.dim}  # bytes per row of a copy
@@ -515,27 +534,35 @@ def main():
                 f = extra["f32_rows_b64"]
                 out["roofline"]["f32_rows"] = {"kernel": f["kernel"], "kernel_ms": f["kernel_ms"], "achieved": f["roofline"]["achieved"],
                                                "frac": f["roofline"]["frac"], "vectors_per_s": f["vectors_per_s"]}
-            if not args.clustered and args.rows >= 1_000_000:
+            if not args.clustered and args.rows >= 1_000_000 and want("clustered_b64", "d768_dot_b64", "d768_dot_b128", "d768_dot_b1"):
                 searcher.close()  # two 153.6 GB corpora do not fit: the clustered one replaces the headline one
                 searcher = None
                 settle(total_rows * (args.dim * 4 + 2 * args.dim + 8))
                 # (six warm-up passes: the searcher's AUTO policy builds the row-major 16-bit mid copy once four passes in a row
                 # had more than 4096 coarse survivors per query — pcv_searcher_set_mid_copy — and the steady state is what is timed)
-                extra["clustered_b64"] = scan_leg(pa, ctx, args.rows, B, k, args.kernel, es, max(ew, 6), clustered=True, dim=args.dim)
+                if want("clustered_b64"):
+                    extra["clustered_b64"] = scan_leg(pa, ctx, args.rows, B, k, "auto" if token_headline else args.kernel, es, max(ew, 6), clustered=True, dim=args.dim)
                 # the reference's default model (MsMarcoBertBaseDotV5, perceive-cli/state.rs:24): 768-d, dot metric
                 # (search.rs:266-279), rows not normalised — norms spread over x[0.5, 2)
                 big = max(1_000_000, args.rows // 2)  # as many bytes of rows as the headline corpus
-                rec, s768 = scan_leg(pa, ctx, big, 64, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0), keep=True)
-                extra["d768_dot_b64"] = rec
-                extra["d768_dot_b128"] = scan_leg(pa, ctx, big, 128, k, "auto", max(3, es // 2), ew, searcher=s768, dim=768, metric="dot", amplitude=(0.5, 2.0))
-                s768.close()
-                settle(big * (768 * 4 + 768 + 8))
-                extra["d768_dot_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0))
-            extra["config2_10m_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew)
-            extra["shard_12p5m_b64"] = scan_leg(pa, ctx, max(100_000, args.rows // 8), 64, k, "auto", es, ew)
-            extra["encoder_256x256"] = encoder_leg(pa, ctx, "f32")
-            extra["encoder_256x256_split_precision"] = [encoder_leg(pa, ctx, "bf16x3"), encoder_leg(pa, ctx, "f16x2")]
-            extra["encoder_bertbase_64x256"] = encoder_leg(pa, ctx, "f32", batch=64, seq=256, shape="bert_base")
+                if want("d768_dot_b64", "d768_dot_b128"):
+                    rec, s768 = scan_leg(pa, ctx, big, 64, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0), keep=True)
+                    extra["d768_dot_b64"] = rec
+                    extra["d768_dot_b128"] = scan_leg(pa, ctx, big, 128, k, "auto", max(3, es // 2), ew, searcher=s768, dim=768, metric="dot", amplitude=(0.5, 2.0))
+                    s768.close()
+                    settle(big * (768 * 4 + 768 + 8))
+                if want("d768_dot_b1"):
+                    extra["d768_dot_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0))
+            if want("config2_10m_b1"):
+                extra["config2_10m_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew)
+            if want("shard_12p5m_b64"):
+                extra["shard_12p5m_b64"] = scan_leg(pa, ctx, max(100_000, args.rows // 8), 64, k, "auto", es, ew)
+            if want("encoder_256x256"):
+                extra["encoder_256x256"] = encoder_leg(pa, ctx, "f32")
+            if want("encoder_256x256_split_precision"):
+                extra["encoder_256x256_split_precision"] = [encoder_leg(pa, ctx, "bf16x3"), encoder_leg(pa, ctx, "f16x2")]
+            if want("encoder_bertbase_64x256"):
+                extra["encoder_bertbase_64x256"] = encoder_leg(pa, ctx, "f32", batch=64, seq=256, shape="bert_base")
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)

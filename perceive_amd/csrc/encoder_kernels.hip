@@ -1454,45 +1454,40 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(float* __restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention: one wave per (batch, head, 32-query block), online softmax over chunks of 128 keys.
+// Attention: one wave per (batch, head, 32-query block), online softmax over chunks of 32*TPC keys.
 // S^T = K Q^T is computed so that the query sits on the lane and the keys in the accumulator
-// registers: row max / sum are in-register reductions plus one cross-half exchange, and the
-// probabilities are, as they stand, the A operand of the P V product (k index = key).
+// registers: row max / sum are in-register reductions plus one cross-half exchange.  The output is
+// accumulated transposed as well, O^T = V^T P^T: the probabilities, as they stand in the S^T
+// accumulators, are the B operand of that product (k index = key acc_row(r,h), column = query = lane),
+// so the running output of a query lives on the query's own lane and the online-softmax rescale is a
+// per-lane multiply (the untransposed form needed 16 ds_bpermute per chunk to fetch each row's factor).
+// q is scaled by log2(e)/sqrt(HD) once, so the scores come out of the MFMA in log2 units.
 // ------------------------------------------------------------------------------------------------
-// STAGED: the four waves of a workgroup are four query blocks of the same (batch, head), so the
+// STAGED: the NW waves of a workgroup are NW query blocks of the same (batch, head), so the
 // workgroup first copies that head's K and V for the whole sequence into LDS (rows padded by 4 floats:
-// conflict-free ds_read_b128 for the K fragments, ds_read_b32 for V) and the inner loops never wait
-// on global memory.  Used whenever 2 * L * (HD+4) * 4 bytes fit the LDS.
+// conflict-free ds_read_b128 for the K fragments, ds_read_b32 for V) plus the additive mask in log2
+// units, and the inner loops never wait on global memory.  All of a thread's staging loads are issued
+// before the first LDS write (the rolled loop waited for each pair of loads in turn: four dependent
+// memory round trips per workgroup at 256 keys).  Used whenever the copies fit the LDS.
 // NW waves per workgroup (32 queries each), TPC 32-key tiles per softmax chunk
 template <int HD, bool STAGED, int NW = 4, int TPC = 4>
 __global__ __launch_bounds__(NW * 64) void attention_kernel(const float* __restrict__ qkv,
                                                         const float* __restrict__ mask_add, float* __restrict__ ctx,
                                                         int B, int L, int Lp, int H) {
     constexpr int KS = HD / 2;   // k-steps of the QK^T product; also floats of a row held per lane
-    constexpr int CT = HD / 32;  // 32-wide column tiles of the output
+    constexpr int CT = HD / 32;  // 32-wide row tiles of the transposed output
     constexpr int LDK = HD + 4;  // padded LDS row (floats)
-    extern __shared__ float kv_lds[];  // [L][LDK] keys, then [L][LDK] values
+    constexpr float kLog2e = 1.44269504088896340736f;
+    extern __shared__ float kv_lds[];  // [Lp][LDK] keys, [Lp][LDK] values, [Lp] mask * log2(e)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int qb = blockIdx.x * NW + wave, head = blockIdx.y, b = blockIdx.z;
     const int H3 = 3 * H;
     float* Ks = kv_lds;
-    float* Vs = kv_lds + (size_t)L * LDK;
-    if (STAGED) {
-        constexpr int C4 = HD / 4;  // float4 pieces per row
-        for (int e = threadIdx.x; e < L * C4; e += NW * 64) {
-            const int key = e / C4, c4 = e - key * C4;
-            const float* src = qkv + (size_t)(b * L + key) * H3 + H + head * HD + c4 * 4;
-            *(f32x4*)&Ks[key * LDK + c4 * 4] = *(const f32x4*)src;
-            *(f32x4*)&Vs[key * LDK + c4 * 4] = *(const f32x4*)(src + H);
-        }
-        __syncthreads();
-    }
-    if (qb * 32 >= L) return;
-    constexpr float kLog2e = 1.44269504088896340736f;
-    const float scale = kLog2e / sqrtf((float)HD);
-    const float ninf = -__builtin_inff();
+    float* Vs = kv_lds + (size_t)Lp * LDK;
+    float* Ms = Vs + (size_t)Lp * LDK;
 
+    // this lane's half of its query row (in flight while the keys and values are staged)
     const int qrow = min(qb * 32 + i, L - 1);
     const float* qp = qkv + (size_t)(b * L + qrow) * H3 + head * HD + KS * h;
     float qf[KS];
@@ -1501,17 +1496,52 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const float* __restr
         const float4 x = *(const float4*)(qp + 4 * v);
         qf[4 * v] = x.x; qf[4 * v + 1] = x.y; qf[4 * v + 2] = x.z; qf[4 * v + 3] = x.w;
     }
+    if (STAGED) {
+        constexpr int C4 = HD / 4;  // float4 pieces per row
+        constexpr int U = 4;        // pieces of K and of V a thread has in flight
+        // rows L..Lp-1 are staged as zeros, so that no key index in the loops below needs clamping (an index clamp per
+        // LDS read was a third of the kernel's vector instructions)
+        const int total = Lp * C4, real = L * C4;
+        for (int e0 = threadIdx.x; e0 < total; e0 += NW * 64 * U) {
+            f32x4 kk[U], vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = min(e0 + u * NW * 64, real - 1);
+                const int key = e / C4, c4 = e - key * C4;
+                const float* src = qkv + (size_t)(b * L + key) * H3 + H + head * HD + c4 * 4;
+                kk[u] = *(const f32x4*)src;
+                vv[u] = *(const f32x4*)(src + H);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * NW * 64;
+                if (e < total) {
+                    const int key = e / C4, c4 = e - key * C4;
+                    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                    *(f32x4*)&Ks[key * LDK + c4 * 4] = e < real ? kk[u] : zero;
+                    *(f32x4*)&Vs[key * LDK + c4 * 4] = e < real ? vv[u] : zero;
+                }
+            }
+        }
+        for (int e = threadIdx.x; e < Lp; e += NW * 64) Ms[e] = mask_add[(size_t)b * Lp + e] * kLog2e;
+        __syncthreads();
+    }
+    if (qb * 32 >= L) return;
+    const float scale = kLog2e / sqrtf((float)HD);
+    const float ninf = -__builtin_inff();
+#pragma unroll
+    for (int e = 0; e < KS; ++e) qf[e] *= scale;
 
     float m_run = ninf, l_run = 0.0f;
-    f32x16 o[CT];
+    f32x16 o[CT];  // O^T: o[c][r] = output dim 32c + acc_row(r,h) of query i
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[c][r] = 0.0f;
 
-    for (int k0 = 0; k0 < L; k0 += 32 * TPC) {
-        f32x16 s[TPC];
-        float mc = ninf;
+    // scores of the chunk of keys that starts at k0 (S^T tiles in log2 units, mask included) and their maximum per lane
+    auto scores = [&](int k0, f32x16 (&s)[TPC], float& mc) {
+        mc = ninf;
 #pragma unroll
         for (int t = 0; t < TPC; ++t) {
             const int kt = k0 + 32 * t;
@@ -1520,37 +1550,41 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const float* __restr
                 for (int r = 0; r < 16; ++r) s[t][r] = ninf;
                 continue;
             }
-            const int krow = min(kt + i, L - 1);
-            const float* kp = STAGED ? &Ks[krow * LDK + KS * h]
-                                     : qkv + (size_t)(b * L + krow) * H3 + H + head * HD + KS * h;
+            const float* kp = STAGED ? &Ks[(kt + i) * LDK + KS * h]
+                                     : qkv + (size_t)(b * L + min(kt + i, L - 1)) * H3 + H + head * HD + KS * h;
             float kf[KS];
 #pragma unroll
             for (int v = 0; v < KS / 4; ++v) {
                 const float4 x = *(const float4*)(kp + 4 * v);
                 kf[4 * v] = x.x; kf[4 * v + 1] = x.y; kf[4 * v + 2] = x.z; kf[4 * v + 3] = x.w;
             }
+            // the accumulators start at the additive mask of their keys kt + 8g + 4h + 0..3 in log2 units (0 for a real
+            // token, -10000 log2(e) for a masked one, -inf beyond L), so the last MFMA delivers the finished scores
             f32x16 a;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
-#pragma unroll
-            for (int e = 0; e < KS; ++e) a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[e], a, 0, 0, 0);
-            const float* mp = mask_add + (size_t)b * Lp + kt + 4 * h;
-#pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 ma = *(const float4*)(mp + 8 * g);  // keys kt + 8g + 4h + 0..3 (-inf beyond L)
-                s[t][4 * g + 0] = fmaf(a[4 * g + 0], scale, ma.x * kLog2e);  // scores in log2 units
-                s[t][4 * g + 1] = fmaf(a[4 * g + 1], scale, ma.y * kLog2e);
-                s[t][4 * g + 2] = fmaf(a[4 * g + 2], scale, ma.z * kLog2e);
-                s[t][4 * g + 3] = fmaf(a[4 * g + 3], scale, ma.w * kLog2e);
+                float4 ma;
+                if (STAGED) {
+                    ma = *(const float4*)&Ms[kt + 4 * h + 8 * g];
+                } else {
+                    ma = *(const float4*)(mask_add + (size_t)b * Lp + kt + 4 * h + 8 * g);
+                    ma.x *= kLog2e; ma.y *= kLog2e; ma.z *= kLog2e; ma.w *= kLog2e;
+                }
+                a[4 * g + 0] = ma.x; a[4 * g + 1] = ma.y; a[4 * g + 2] = ma.z; a[4 * g + 3] = ma.w;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mc = fmaxf(mc, s[t][r]);
+            for (int e = 0; e < KS; ++e) a = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[e], a, 0, 0, 0);
+            s[t] = a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mc = fmaxf(mc, a[r]);
         }
+    };
+    // online-softmax step on one chunk's scores, then O^T += V^T P^T
+    auto fold = [&](int k0, f32x16 (&s)[TPC], float mc) {
         mc = fmaxf(mc, __shfl_xor(mc, 32));
         const float m_new = fmaxf(m_run, mc);
-        // exp2 on scores kept in log2 units: one v_exp_f32 per probability (libm expf is ~25 VALU, and VALU
-        // time is matrix-pipe time on this part).  m_new is finite — key 0 is always a real key — so
-        // exp2(-inf - m_new) is an exact 0 for masked-out keys and no select is needed.
+        // exp2 on scores kept in log2 units: one v_exp_f32 per probability (libm expf is ~25 VALU).  m_new is finite —
+        // key 0 is always a real key — so exp2(-inf - m_new) is an exact 0 for masked-out keys and no select is needed.
         const float factor = (m_run == ninf) ? 0.0f : __builtin_amdgcn_exp2f(m_run - m_new);
         float lc = 0.0f;
 #pragma unroll
@@ -1564,48 +1598,50 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const float* __restr
         lc += __shfl_xor(lc, 32);
         l_run = l_run * factor + lc;
         m_run = m_new;
-        // rescale the running output: its rows are queries acc_row(r,h), whose factor sits on that lane
+        // rescale the running output: this lane's query, this lane's factor
+        if (k0 > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float fr = __shfl(factor, acc_row(r, h));
+            for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int c = 0; c < CT; ++c) o[c][r] *= fr;
+                for (int r = 0; r < 16; ++r) o[c][r] *= factor;
         }
-        // O += P V : k index = key acc_row(r,h) of tile t; B operand = V[key][32c + i]
+        // O^T += V^T P^T : k index = key acc_row(r,h) of tile t; A operand = V[key][32c + i], B operand = p of that key
+        // (keys beyond L carry p = 0; their staged rows are zeros, the unstaged form clamps the index)
 #pragma unroll
         for (int t = 0; t < TPC; ++t) {
             const int kt = k0 + 32 * t;
             if (kt >= L) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = min(kt + acc_row(r, h), L - 1);  // clamped keys carry p = 0
-                const float* vp = STAGED ? &Vs[key * LDK + i] : qkv + (size_t)(b * L + key) * H3 + 2 * H + head * HD + i;
+                const float* vp = STAGED ? &Vs[(kt + acc_row(r, h)) * LDK + i]
+                                         : qkv + (size_t)(b * L + min(kt + acc_row(r, h), L - 1)) * H3 + 2 * H + head * HD + i;
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
-                    o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[t][r], vp[32 * c], o[c], 0, 0, 0);
+                    o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * c], s[t][r], o[c], 0, 0, 0);
             }
         }
+    };
+    // (measured and dropped, 256 x 256 tokens, 224 us per call either way: the scores of chunk c+1 computed before the
+    // softmax of chunk c so that its vector instructions issue between those MFMAs; two alternating accumulators for the
+    // P V product instead of one chain of 32 dependent MFMAs; s_setprio 1 for the younger half of the workgroup; 128-key
+    // chunks: 254 us, 32-key chunks: 229 us)
+    for (int k0 = 0; k0 < L; k0 += 32 * TPC) {
+        f32x16 s[TPC];
+        float mc;
+        scores(k0, s, mc);
+        fold(k0, s, mc);
     }
-    // full query tiles store without a branch per element (see store_quarter: a branch per store costs an
-    // s_waitcnt vmcnt(0), i.e. an HBM round trip, per store)
-    float linv[16];
+    // this lane holds, of query i, the output dims 32c + 8g + 4h + 0..3: four 16-byte stores per tile
+    if (qb * 32 + i < L) {
+        const float linv = 1.0f / l_run;
+        float* const cp = ctx + (size_t)(b * L + qb * 32 + i) * H + head * HD + 4 * h;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) linv[r] = 1.0f / __shfl(l_run, acc_row(r, h));
-    if (qb * 32 + 32 <= L) {  // wave-uniform
-        float* const cp = ctx + (size_t)(b * L + qb * 32 + 4 * h) * H + head * HD + i;
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int c = 0; c < CT; ++c) cp[(size_t)acc_row(r, 0) * H + 32 * c] = o[c][r] * linv[r];
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = qb * 32 + acc_row(r, h);
-        if (row < L) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c) ctx[(size_t)(b * L + row) * H + head * HD + 32 * c + i] = o[c][r] * linv[r];
-        }
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {o[c][4 * g] * linv, o[c][4 * g + 1] * linv, o[c][4 * g + 2] * linv, o[c][4 * g + 3] * linv};
+                *(f32x4*)(cp + 32 * c + 8 * g) = v;
+            }
     }
 }
 
@@ -1939,7 +1975,7 @@ void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, f
                       int heads) {
     const int Lp = (L + 31) / 32 * 32;
     const int HD = H / heads;
-    const size_t lds = (size_t)2 * L * (HD + 4) * sizeof(float);
+    const size_t lds = ((size_t)2 * Lp * (HD + 4) + Lp) * sizeof(float);  // K, V (rows padded to whole 32-key tiles), mask
     const bool staged = lds <= 150 * 1024;
     if (staged) {  // eight waves + 64-key chunks where the sequence has eight query tiles (13.61 vs 13.93 ms per forward)
         const bool wide = Lp >= 256;

@@ -1,12 +1,14 @@
 # SQ pipe / stall counters of ONE scan shape (rocprofv3, a few counters per run, kernel-trace only besides them).
 #   gpurun --timeout 900 -- "bash tools/profile_kernel_pmc.sh <tag> <ab_scan.py arguments...>"
 # e.g.  bash tools/profile_kernel_pmc.sh hold256 --rows 50000000 --batch 256
+# PCV_PMC_PROG="tools/bench_encode.py" bash tools/profile_kernel_pmc.sh attn --compute f32 --steps 2 --warmup 1    # profiles another program
 # writes gpurun_out/pmc_<tag>_summary.txt (per-launch averages of every counter for the scan kernels)
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 G=$R/gpurun_out
 mkdir -p $G
+if [ -n "$PCV_PMC_PROG" ]; then PROG="$R/$PCV_PMC_PROG"; else PROG="$R/tools/ab_scan.py --rounds 2"; fi
 i=0
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS" \
@@ -17,7 +19,7 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
   i=$((i+1))
   rm -rf $G/pmc_${TAG}_$i
   timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $G/pmc_${TAG}_$i -o p -- \
-    python3 $R/tools/ab_scan.py --rounds 2 "$@" > $G/pmc_${TAG}_$i.log 2>&1 || { echo "FAILED set $i"; tail -5 $G/pmc_${TAG}_$i.log; }
+    python3 $PROG "$@" > $G/pmc_${TAG}_$i.log 2>&1 || { echo "FAILED set $i"; tail -5 $G/pmc_${TAG}_$i.log; }
 done
 python3 - "$TAG" <<'PY'
 import csv, glob, os, collections, sys

@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 outputs of one round (gpurun_out/...) into the committed summaries under
-profiles/: kernel-stats CSVs are copied as they are; PMC passes are reduced to per-launch HBM
-traffic, corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes for gfx950
-(FETCH_SIZE counts 64 B per 128 B request on wide coalesced streaming reads: x2; WRITE_SIZE exact;
-both in KiB).
+"""Turn the rocprofv3 outputs of one round (gpurun_out/prof_<leg>, pmc_fetch_<leg>, pmc_write_<leg>, written by
+tools/profile_round.sh) into the committed summaries under profiles/:
 
-    python tools/summarize_profiles.py r01
+  <tag>_<leg>_kernel_stats.csv   the `--kernel-trace --stats` table of the leg's bench.py command, as rocprofv3 wrote it
+  <tag>_summary.json             per leg: the kernel bench.py names, its average duration under the profiler and from
+                                 bench.py's own HIP events in the same process, the bytes it has to move per launch,
+                                 the roofline fraction from either clock, and the PMC traffic per launch
+  traffic.json                   per leg HBM bytes per launch; bench.py reads it for `roofline.traffic`
+
+PMC passes are corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes for gfx950 (FETCH_SIZE counts 64 B
+per 128 B request on wide coalesced streaming reads: x2; WRITE_SIZE exact; both in KiB).
+
+    python tools/summarize_profiles.py r03
 """
 import csv
 import glob
@@ -17,6 +23,23 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
 GO = os.path.join(ROOT, "gpurun_out")
+PEAK = 8000.0  # GB/s
+
+# leg of bench.py -> (profile directory suffix, where its record sits in the JSON line the run printed)
+SCAN_LEGS = [
+    ("headline", "headline", None),
+    ("f32_rows_b64", "f32_rows_b64", None),
+    ("bf16_copy_b64", "bf16_copy_b64", None),
+    ("batch128", "batch128", "batch128"),
+    ("batch256", "batch256", "batch256"),
+    ("clustered_b64", "clustered_b64", None),
+    ("d768_dot_b64", "d768_dot_b64_b128", "d768_dot_b64"),
+    ("d768_dot_b128", "d768_dot_b64_b128", "d768_dot_b128"),
+    ("d768_dot_b1", "d768_dot_b1", "d768_dot_b1"),
+    ("config2_10m_b1", "config2_10m_b1", None),
+    ("shard_12p5m_b64", "shard_12p5m_b64", None),
+]
+ENC_LEGS = ["encoder_256x256", "encoder_256x256_split_precision", "encoder_bertbase_64x256", "config5_end_to_end"]
 
 
 def newest(pattern):
@@ -27,94 +50,121 @@ def newest(pattern):
     return files[-1:]
 
 
-def pmc_mean(dirname, counter, kernel_substr):
+def bench_line(logname):
+    """The JSON line bench.py printed inside a profiler run's log."""
+    try:
+        for line in reversed(open(os.path.join(GO, logname + ".log")).read().splitlines()):
+            if line.startswith('{"metric"'):
+                return json.loads(line)
+    except OSError:
+        pass
+    return None
+
+
+def stats_rows(dirname):
+    for f in newest(os.path.join(GO, dirname, "*", "*_kernel_stats.csv")):
+        return f, list(csv.DictReader(open(f)))
+    return None, []
+
+
+def pick_kernel(rows, base, kernel_ms):
+    """Of the kernels of a run whose name contains `base`, the one whose average is nearest to the duration bench.py
+    measured for the leg (a run holds at most the token headline's wave kernel besides the leg's own)."""
+    cand = [r for r in rows if base + "<" in r["Name"] or base + "(" in r["Name"]]
+    if not cand:
+        return None
+    return min(cand, key=lambda r: abs(float(r["AverageNs"]) / 1e6 - kernel_ms))
+
+
+def pmc_mean(dirname, counter, kernel_name):
     vals = []
     for f in newest(os.path.join(GO, dirname, "*", "*_counter_collection.csv")):
         for row in csv.DictReader(open(f)):
-            if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+            if row["Counter_Name"] == counter and row["Kernel_Name"] == kernel_name:
                 vals.append(float(row["Counter_Value"]))
+    if len(vals) > 2:
+        vals = vals[1:]  # the first launch of a process also pages the code object in
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-def kernel_avg_ms(dirname, kernel_substr):
-    for f in newest(os.path.join(GO, dirname, "*", "*_kernel_stats.csv")):
-        for row in csv.DictReader(open(f)):
-            if kernel_substr in row["Name"]:
-                return float(row["AverageNs"]) / 1e6, int(row["Calls"])
-    return None, 0
+def short(name):
+    return name.replace("void (anonymous namespace)::", "").split("(")[0]
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     os.makedirs(OUT, exist_ok=True)
-    summary = {}
-    cases = [
-        # (label, stats dir, fetch dir, write dir, kernel, rows, dim)
-        ("100m_b64_int8", "prof_default", "pmc_fetch", "pmc_write", "scan_mfma8_kernel", 100_000_000, 384),
-        ("100m_b64_bf16", "prof_default_bf16", "pmc_fetch_bf16", "pmc_write_bf16", "scan_mfma_kernel", 100_000_000, 384),
-        ("100m_b64_f32rows", "prof_default_f32", None, None, "scan_mfma_kernel", 100_000_000, 384),
-        ("10m_b1_int8", "prof_10m_b1", "pmc_fetch_10m_b1", "pmc_write_10m_b1", "scan_mfma8_kernel", 10_000_000, 384),
-        ("12p5m_b64_int8", "prof_12p5m", None, None, "scan_mfma8_kernel", 12_500_000, 384),
-        ("100m_b64_int8_clustered", "prof_clustered", None, None, "scan_mfma8_kernel", 100_000_000, 384),
-    ]
-    for c in ("f32", "bf16x3", "f16x2"):  # encoder forward per kernel
-        for f in newest(os.path.join(GO, f"prof_enc_{c}", "*", "*_kernel_stats.csv")):
-            shutil.copy(f, os.path.join(OUT, f"{tag}_encode_b256_l256_{c}_kernel_stats.csv"))
-    for label, sdir, fdir, wdir, kern, rows, dim in cases:
-        for f in newest(os.path.join(GO, sdir, "*", "*_kernel_stats.csv")):
-            shutil.copy(f, os.path.join(OUT, f"{tag}_{label}_kernel_stats.csv"))
-        ms, calls = kernel_avg_ms(sdir, kern)
-        fetch_kib, nf = pmc_mean(fdir, "FETCH_SIZE", kern) if fdir else (None, 0)
-        write_kib, nw = pmc_mean(wdir, "WRITE_SIZE", kern) if wdir else (None, 0)
-        alg = rows * dim * 4
-        fixed = {}
-        for f in newest(os.path.join(GO, sdir, "*", "*_kernel_stats.csv")):
-            for row in csv.DictReader(open(f)):
-                for k in ("upload_kernel", "prep_seed", "rescore_select", "quantize_queries"):
-                    if k in row["Name"]:
-                        fixed[k + "_avg_us"] = float(row["AverageNs"]) / 1e3
+    summary, traffic = {}, {}
+    for leg, suffix, key in SCAN_LEGS:
+        out = bench_line("prof_" + suffix)
+        f, rows = stats_rows("prof_" + suffix)
+        if out is None or f is None:
+            print(f"(no profile of {leg})")
+            continue
+        shutil.copy(f, os.path.join(OUT, f"{tag}_{suffix}_kernel_stats.csv"))
+        if key is None:
+            rec = {"kernel": out["roofline"]["kernel"], "kernel_ms": out["roofline"]["kernel_ms"],
+                   "bytes_per_launch": out["roofline"]["bytes_per_launch"], "workload": out["config"]["workload"],
+                   "ms_per_step": out["ms_per_step"], "candidates_per_query": out["candidates_per_query"]}
+        else:
+            e = out["extra"][key]
+            rec = {"kernel": e["kernel"], "kernel_ms": e["kernel_ms"], "bytes_per_launch": e["roofline"]["bytes_per_launch"],
+                   "workload": e["workload"], "ms_per_step": e["ms_per_step"], "candidates_per_query": e["candidates_per_query"]}
+        row = pick_kernel(rows, rec["kernel"], rec["kernel_ms"])
+        if row is None:
+            print(f"(kernel {rec['kernel']} not in {f})")
+            continue
+        prof_ms = float(row["AverageNs"]) / 1e6
         entry = {
-            "kernel": kern, "rows": rows, "dim": dim, "algorithmic_bytes_per_launch": alg, "other_kernels_of_a_pass": fixed,
-            "rocprof_avg_kernel_ms": ms, "rocprof_calls": calls,
-            "achieved_GBps_from_rocprof": alg / (ms * 1e-3) / 1e9 if ms else None,
-            "FETCH_SIZE_KiB_raw": fetch_kib, "FETCH_launches": nf,
-            "WRITE_SIZE_KiB_raw": write_kib, "WRITE_launches": nw,
+            "workload": rec["workload"], "command": "bench.py --no-cpu-baseline " + ("--only " + key if key else "--no-extra") + " (tools/profile_round.sh)",
+            "kernel": short(row["Name"]), "bytes_per_launch": rec["bytes_per_launch"],
+            "rocprof_avg_kernel_ms": prof_ms, "rocprof_calls": int(row["Calls"]),
+            "bench_hip_event_kernel_ms": rec["kernel_ms"], "rocprof_over_bench": prof_ms / rec["kernel_ms"],
+            "frac_of_8TBps_rocprof": rec["bytes_per_launch"] / (prof_ms * 1e-3) / 1e9 / PEAK,
+            "frac_of_8TBps_bench": rec["bytes_per_launch"] / (rec["kernel_ms"] * 1e-3) / 1e9 / PEAK,
+            "ms_per_step_under_profiler": rec["ms_per_step"], "candidates_per_query": rec["candidates_per_query"],
+            "other_kernels_of_a_pass_avg_us": {short(r["Name"]): round(float(r["AverageNs"]) / 1e3, 1) for r in rows
+                                               if any(k in r["Name"] for k in ("upload_kernel", "prep_seed", "rescore_select", "quantize_queries"))},
         }
+        # PMC passes of the same command (fewer steps): counters of exactly this kernel name
+        pout = bench_line("pmc_fetch_" + suffix)
+        fetch_kib, nf = pmc_mean("pmc_fetch_" + suffix, "FETCH_SIZE", row["Name"])
+        write_kib, nw = pmc_mean("pmc_write_" + suffix, "WRITE_SIZE", row["Name"])
         if fetch_kib is not None:
             read_b = fetch_kib * 1024 * 2.0  # gfx950 correction for 16 B/lane streaming reads
             write_b = (write_kib or 0.0) * 1024
-            entry["hbm_read_bytes_per_launch"] = read_b
-            entry["hbm_write_bytes_per_launch"] = write_b
-            entry["traffic_bytes_per_launch"] = read_b + write_b
-            entry["traffic_over_algorithmic"] = (read_b + write_b) / alg
-            entry["traffic_bytes_per_row"] = (read_b + write_b) / rows
-        summary[label] = entry
-    with open(os.path.join(OUT, f"{tag}_summary.json"), "w") as f:
-        json.dump(summary, f, indent=1)
-    # what bench.py reads to fill roofline.traffic (per-row figure of the newest round)
-    with open(os.path.join(OUT, "traffic.json"), "w") as f:
-        table = {}
-        for k, e in summary.items():  # the first (largest) measured configuration of a kernel wins
-            if e.get("traffic_bytes_per_row") and e["kernel"] not in table:
-                table[e["kernel"]] = {"bytes_per_row": e["traffic_bytes_per_row"], "dim": e["dim"],
-                                      "source": f"profiles/{tag}_summary.json:{k}"}
-        json.dump(table, f, indent=1)
-    # encoder forward: per-kernel time per forward and TFLOP/s of the GEMM shapes (MiniLM-L6 shape, 256 x 256 tokens)
-    enc = {}
-    for c in ("f32", "bf16x3", "f16x2"):
-        for f in newest(os.path.join(GO, f"prof_enc_{c}", "*", "*_kernel_stats.csv")):
-            rows_ = list(csv.DictReader(open(f)))
-            fwd = 9  # bench_encode.py --steps 7 --warmup 2
-            tot = sum(float(r["TotalDurationNs"]) for r in rows_ if "synth_weights" not in r["Name"] and "split_planes" not in r["Name"])
-            enc[c] = {"ms_per_forward": tot / 1e6 / fwd, "effective_TFLOPps": 1.546188e12 / (tot / 1e9 / fwd) / 1e12,
-                      "kernels_us_per_forward": {r["Name"].split("(anonymous namespace)::")[-1].split("(")[0]:
-                                                 round(float(r["TotalDurationNs"]) / 1e3 / fwd, 1) for r in rows_
-                                                 if float(r["TotalDurationNs"]) / 1e3 / fwd > 5}}
-    if enc:
-        summary["encoder_256x256"] = enc
-        with open(os.path.join(OUT, f"{tag}_summary.json"), "w") as f:
-            json.dump(summary, f, indent=1)
-    print(json.dumps(summary, indent=1))
+            entry.update({"FETCH_SIZE_KiB_raw": fetch_kib, "FETCH_launches": nf, "WRITE_SIZE_KiB_raw": write_kib, "WRITE_launches": nw,
+                          "hbm_read_bytes_per_launch": read_b, "hbm_write_bytes_per_launch": write_b,
+                          "traffic_bytes_per_launch": read_b + write_b,
+                          "traffic_over_bytes_per_launch": (read_b + write_b) / rec["bytes_per_launch"]})
+            traffic[leg] = {"bytes_per_launch": read_b + write_b, "required_bytes_per_launch": rec["bytes_per_launch"],
+                            "kernel": entry["kernel"], "clustered": "clustered" in leg, "source": f"profiles/{tag}_summary.json:{leg}"}
+        elif pout is None:
+            entry["pmc"] = None
+        summary[leg] = entry
+    # encoder legs: per-kernel time per forward
+    for leg in ENC_LEGS:
+        out = bench_line("prof_" + leg)
+        f, rows = stats_rows("prof_" + leg)
+        if out is None or f is None:
+            print(f"(no profile of {leg})")
+            continue
+        shutil.copy(f, os.path.join(OUT, f"{tag}_{leg}_kernel_stats.csv"))
+        e = out["extra"][leg]
+        es = e if isinstance(e, list) else [e]
+        kern = {short(r["Name"]): {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3)}
+                for r in rows if any(k in r["Name"] for k in ("gemm", "attention", "embed", "pool", "layer_norm", "scan_mfma8", "rescore", "prep_seed", "quantize"))}
+        summary[leg] = {"bench": [{k: x.get(k) for k in ("workload", "compute", "device_ms", "ms_per_step", "encode_ms", "scan_ms", "effective_TFLOPps", "roofline") if k in x} for x in es],
+                        "kernels_under_profiler": kern}
+    with open(os.path.join(OUT, f"{tag}_summary.json"), "w") as fo:
+        json.dump(summary, fo, indent=1)
+    if traffic:
+        with open(os.path.join(OUT, "traffic.json"), "w") as fo:
+            json.dump(traffic, fo, indent=1)
+    for leg, e in summary.items():
+        if "rocprof_avg_kernel_ms" in e:
+            print(f"{leg:20s} {e['kernel'][:44]:44s} rocprof {e['rocprof_avg_kernel_ms']:.3f} ms  bench {e['bench_hip_event_kernel_ms']:.3f} ms  "
+                  f"ratio {e['rocprof_over_bench']:.3f}  frac {e['frac_of_8TBps_rocprof']:.3f}  traffic/required {e.get('traffic_over_bytes_per_launch')}")
 
 
 if __name__ == "__main__":
