@@ -4,6 +4,7 @@
 // Numerics: f32 end to end like the reference (tch default dtype, no autocast).  Every contraction
 // runs on the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain in k
 // order), so the result differs from a CPU f32 evaluation only by summation order.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -1470,68 +1471,19 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(float* __restrict__ x, 
 // before the first LDS write (the rolled loop waited for each pair of loads in turn: four dependent
 // memory round trips per workgroup at 256 keys).  Used whenever the copies fit the LDS.
 // NW waves per workgroup (32 queries each), TPC 32-key tiles per softmax chunk
-template <int HD, bool STAGED, int NW = 4, int TPC = 4>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(const float* __restrict__ qkv,
-                                                        const float* __restrict__ mask_add, float* __restrict__ ctx,
-                                                        int B, int L, int Lp, int H) {
+// One wave's 32 queries against all L keys.  qf: this lane's half of its query row, already scaled.  NEXTQ: once the
+// last chunk's scores are out, qf is dead, and the half row at `next_qp` is requested into it (the persistent form's
+// next query block: the request then flies under the last softmax and P V product, the stores and the workgroup barriers).
+template <int HD, bool STAGED, int TPC, bool NEXTQ>
+__device__ __forceinline__ void attn_wave(float (&qf)[HD / 2], const float* next_qp, const float* Ks, const float* Vs, const float* Ms,
+                                          const float* __restrict__ qkv, const float* __restrict__ mask_add,
+                                          float* __restrict__ ctx, int b, int head, int qb, int L, int Lp, int H, int i, int h) {
     constexpr int KS = HD / 2;   // k-steps of the QK^T product; also floats of a row held per lane
     constexpr int CT = HD / 32;  // 32-wide row tiles of the transposed output
     constexpr int LDK = HD + 4;  // padded LDS row (floats)
     constexpr float kLog2e = 1.44269504088896340736f;
-    extern __shared__ float kv_lds[];  // [Lp][LDK] keys, [Lp][LDK] values, [Lp] mask * log2(e)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31, h = lane >> 5;
-    const int qb = blockIdx.x * NW + wave, head = blockIdx.y, b = blockIdx.z;
     const int H3 = 3 * H;
-    float* Ks = kv_lds;
-    float* Vs = kv_lds + (size_t)Lp * LDK;
-    float* Ms = Vs + (size_t)Lp * LDK;
-
-    // this lane's half of its query row (in flight while the keys and values are staged)
-    const int qrow = min(qb * 32 + i, L - 1);
-    const float* qp = qkv + (size_t)(b * L + qrow) * H3 + head * HD + KS * h;
-    float qf[KS];
-#pragma unroll
-    for (int v = 0; v < KS / 4; ++v) {
-        const float4 x = *(const float4*)(qp + 4 * v);
-        qf[4 * v] = x.x; qf[4 * v + 1] = x.y; qf[4 * v + 2] = x.z; qf[4 * v + 3] = x.w;
-    }
-    if (STAGED) {
-        constexpr int C4 = HD / 4;  // float4 pieces per row
-        constexpr int U = 4;        // pieces of K and of V a thread has in flight
-        // rows L..Lp-1 are staged as zeros, so that no key index in the loops below needs clamping (an index clamp per
-        // LDS read was a third of the kernel's vector instructions)
-        const int total = Lp * C4, real = L * C4;
-        for (int e0 = threadIdx.x; e0 < total; e0 += NW * 64 * U) {
-            f32x4 kk[U], vv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = min(e0 + u * NW * 64, real - 1);
-                const int key = e / C4, c4 = e - key * C4;
-                const float* src = qkv + (size_t)(b * L + key) * H3 + H + head * HD + c4 * 4;
-                kk[u] = *(const f32x4*)src;
-                vv[u] = *(const f32x4*)(src + H);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = e0 + u * NW * 64;
-                if (e < total) {
-                    const int key = e / C4, c4 = e - key * C4;
-                    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-                    *(f32x4*)&Ks[key * LDK + c4 * 4] = e < real ? kk[u] : zero;
-                    *(f32x4*)&Vs[key * LDK + c4 * 4] = e < real ? vv[u] : zero;
-                }
-            }
-        }
-        for (int e = threadIdx.x; e < Lp; e += NW * 64) Ms[e] = mask_add[(size_t)b * Lp + e] * kLog2e;
-        __syncthreads();
-    }
-    if (qb * 32 >= L) return;
-    const float scale = kLog2e / sqrtf((float)HD);
     const float ninf = -__builtin_inff();
-#pragma unroll
-    for (int e = 0; e < KS; ++e) qf[e] *= scale;
-
     float m_run = ninf, l_run = 0.0f;
     f32x16 o[CT];  // O^T: o[c][r] = output dim 32c + acc_row(r,h) of query i
 #pragma unroll
@@ -1624,13 +1576,24 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const float* __restr
     // (measured and dropped, 256 x 256 tokens, 224 us per call either way: the scores of chunk c+1 computed before the
     // softmax of chunk c so that its vector instructions issue between those MFMAs; two alternating accumulators for the
     // P V product instead of one chain of 32 dependent MFMAs; s_setprio 1 for the younger half of the workgroup; 128-key
-    // chunks: 254 us, 32-key chunks: 229 us)
-    for (int k0 = 0; k0 < L; k0 += 32 * TPC) {
-        f32x16 s[TPC];
-        float mc;
+    // chunks: 254 us, 32-key chunks: 229 us.  With the loads, the exps, the LDS addresses and the stores all stubbed out
+    // the kernel still took 218 us: the time was in workgroup turnover, see attention_persist_kernel.)
+    f32x16 s[TPC];
+    float mc;
+    int k0 = 0;
+    for (; k0 + 32 * TPC < L; k0 += 32 * TPC) {
         scores(k0, s, mc);
         fold(k0, s, mc);
     }
+    scores(k0, s, mc);  // the last chunk (L >= 1: there always is one)
+    if (NEXTQ) {
+#pragma unroll
+        for (int v = 0; v < KS / 4; ++v) {
+            const float4 x = *(const float4*)(next_qp + 4 * v);
+            qf[4 * v] = x.x; qf[4 * v + 1] = x.y; qf[4 * v + 2] = x.z; qf[4 * v + 3] = x.w;
+        }
+    }
+    fold(k0, s, mc);
     // this lane holds, of query i, the output dims 32c + 8g + 4h + 0..3: four 16-byte stores per tile
     if (qb * 32 + i < L) {
         const float linv = 1.0f / l_run;
@@ -1642,6 +1605,153 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const float* __restr
                 f32x4 v = {o[c][4 * g] * linv, o[c][4 * g + 1] * linv, o[c][4 * g + 2] * linv, o[c][4 * g + 3] * linv};
                 *(f32x4*)(cp + 32 * c + 8 * g) = v;
             }
+    }
+}
+
+template <int HD, bool STAGED, int NW = 4, int TPC = 4>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const float* __restrict__ qkv,
+                                                        const float* __restrict__ mask_add, float* __restrict__ ctx,
+                                                        int B, int L, int Lp, int H) {
+    constexpr int KS = HD / 2;
+    constexpr int LDK = HD + 4;
+    constexpr float kLog2e = 1.44269504088896340736f;
+    extern __shared__ float kv_lds[];  // [Lp][LDK] keys, [Lp][LDK] values, [Lp] mask * log2(e)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int qb = blockIdx.x * NW + wave, head = blockIdx.y, b = blockIdx.z;
+    const int H3 = 3 * H;
+    float* Ks = kv_lds;
+    float* Vs = kv_lds + (size_t)Lp * LDK;
+    float* Ms = Vs + (size_t)Lp * LDK;
+
+    // this lane's half of its query row (in flight while the keys and values are staged)
+    const int qrow = min(qb * 32 + i, L - 1);
+    const float* qp = qkv + (size_t)(b * L + qrow) * H3 + head * HD + KS * h;
+    float qf[KS];
+#pragma unroll
+    for (int v = 0; v < KS / 4; ++v) {
+        const float4 x = *(const float4*)(qp + 4 * v);
+        qf[4 * v] = x.x; qf[4 * v + 1] = x.y; qf[4 * v + 2] = x.z; qf[4 * v + 3] = x.w;
+    }
+    if (STAGED) {
+        constexpr int C4 = HD / 4;  // float4 pieces per row
+        constexpr int U = 4;        // pieces of K and of V a thread has in flight
+        // rows L..Lp-1 are staged as zeros, so that no key index in the loops needs clamping (an index clamp per
+        // LDS read was a third of the kernel's vector instructions)
+        const int total = Lp * C4, real = L * C4;
+        for (int e0 = threadIdx.x; e0 < total; e0 += NW * 64 * U) {
+            f32x4 kk[U], vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = min(e0 + u * NW * 64, real - 1);
+                const int key = e / C4, c4 = e - key * C4;
+                const float* src = qkv + (size_t)(b * L + key) * H3 + H + head * HD + c4 * 4;
+                kk[u] = *(const f32x4*)src;
+                vv[u] = *(const f32x4*)(src + H);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * NW * 64;
+                if (e < total) {
+                    const int key = e / C4, c4 = e - key * C4;
+                    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                    *(f32x4*)&Ks[key * LDK + c4 * 4] = e < real ? kk[u] : zero;
+                    *(f32x4*)&Vs[key * LDK + c4 * 4] = e < real ? vv[u] : zero;
+                }
+            }
+        }
+        for (int e = threadIdx.x; e < Lp; e += NW * 64) Ms[e] = mask_add[(size_t)b * Lp + e] * kLog2e;
+        __syncthreads();
+    }
+    if (qb * 32 >= L) return;
+    const float scale = kLog2e / sqrtf((float)HD);
+#pragma unroll
+    for (int e = 0; e < KS; ++e) qf[e] *= scale;
+    attn_wave<HD, STAGED, TPC, false>(qf, nullptr, Ks, Vs, Ms, qkv, mask_add, ctx, b, head, qb, L, Lp, H, i, h);
+}
+
+// Persistent form of the staged kernel for the shapes the encoder runs at full batches (sequences of up to NW query
+// blocks whose K and V a thread stages as PF pieces each): a workgroup walks (batch, head) items blockIdx.x,
+// + gridDim.x, ...; the next item's K / V pieces and mask are requested into registers as soon as the current item's
+// are in LDS and fly under its MFMAs, and each wave requests its next query rows when the last chunk's scores are out.
+// Between items: one barrier (everyone is done reading), the LDS writes, one barrier.  Why: with one item per
+// workgroup 19 % of the wave slots stood empty (SQ_WAVE_CYCLES against 4 x 1024 SIMDs x kernel cycles: a 75 KB
+// workgroup starts only when all eight waves of its predecessor have ended), and a new workgroup's staging round trip
+// came on top.
+template <int HD, int NW, int TPC, int PF, bool AHEAD>
+__global__ __launch_bounds__(NW * 64, HD == 32 ? 4 : 2) void attention_persist_kernel(const float* __restrict__ qkv,
+                                                                const float* __restrict__ mask_add,
+                                                                float* __restrict__ ctx, int L, int Lp, int H, int heads,
+                                                                int n_items) {
+    constexpr int KS = HD / 2;
+    constexpr int LDK = HD + 4;
+    constexpr int C4 = HD / 4;
+    constexpr float kLog2e = 1.44269504088896340736f;
+    extern __shared__ float kv_lds[];  // [Lp][LDK] keys, [Lp][LDK] values, [Lp] mask * log2(e)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int H3 = 3 * H;
+    float* Ks = kv_lds;
+    float* Vs = kv_lds + (size_t)Lp * LDK;
+    float* Ms = Vs + (size_t)Lp * LDK;
+    const int total = Lp * C4, real = L * C4;  // host: total <= PF * NW * 64, Lp <= NW * 64, Lp <= 32 * NW
+    const int qb = wave;
+    const int qrow = min(qb * 32 + i, L - 1);
+    const float scale = kLog2e / sqrtf((float)HD);
+
+    f32x4 kk[PF], vv[PF];
+    float mk;
+    auto fetch = [&](int item) {
+        const int b = item / heads, head = item - b * heads;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int e = min((int)threadIdx.x + u * NW * 64, real - 1);
+            const int key = e / C4, c4 = e - key * C4;
+            const float* src = qkv + (size_t)(b * L + key) * H3 + H + head * HD + c4 * 4;
+            kk[u] = *(const f32x4*)src;
+            vv[u] = *(const f32x4*)(src + H);
+        }
+        mk = mask_add[(size_t)b * Lp + min((int)threadIdx.x, Lp - 1)];
+    };
+    auto q_ptr = [&](int item) {
+        const int b = item / heads, head = item - b * heads;
+        return qkv + (size_t)(b * L + qrow) * H3 + head * HD + KS * h;
+    };
+    int item = blockIdx.x;  // host: gridDim.x <= n_items
+    if (AHEAD) fetch(item);
+    float qf[KS];
+    {
+        const float* qp = q_ptr(item);
+#pragma unroll
+        for (int v = 0; v < KS / 4; ++v) {
+            const float4 x = *(const float4*)(qp + 4 * v);
+            qf[4 * v] = x.x; qf[4 * v + 1] = x.y; qf[4 * v + 2] = x.z; qf[4 * v + 3] = x.w;
+        }
+    }
+    while (item < n_items) {  // workgroup-uniform
+        const int b = item / heads, head = item - b * heads;
+        if (!AHEAD) fetch(item);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int e = threadIdx.x + u * NW * 64;
+            if (e < total) {
+                const int key = e / C4, c4 = e - key * C4;
+                const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                *(f32x4*)&Ks[key * LDK + c4 * 4] = e < real ? kk[u] : zero;
+                *(f32x4*)&Vs[key * LDK + c4 * 4] = e < real ? vv[u] : zero;
+            }
+        }
+        if ((int)threadIdx.x < Lp) Ms[threadIdx.x] = mk * kLog2e;
+#pragma unroll
+        for (int e = 0; e < KS; ++e) qf[e] *= scale;
+        __syncthreads();
+        const int next = item + gridDim.x;
+        const int ahead = next < n_items ? next : item;  // (the last item re-requests itself: no branch around loads)
+        if (AHEAD) fetch(ahead);
+        if (qb * 32 < L)
+            attn_wave<HD, true, TPC, true>(qf, q_ptr(ahead), Ks, Vs, Ms, qkv, mask_add, ctx, b, head, qb, L, Lp, H, i, h);
+        __syncthreads();  // every wave is done with this item's K and V
+        item = next;
     }
 }
 
@@ -1971,6 +2081,19 @@ static void launch_attention_staged(hipStream_t st, const float* qkv, const floa
     attention_kernel<HD, true, NW, TPC><<<grid, NW * 64, lds, st>>>(qkv, mask_add, ctx, B, L, Lp, H);
 }
 
+// (batch, head) items walked by as many workgroups as are resident at once
+template <int HD, int NW, int TPC, int PF>
+static void launch_attention_persist(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int Lp,
+                                     int H, int heads, size_t lds) {
+    constexpr bool AHEAD = HD == 64;  // (head_dim 32 would run two workgroups per CU at 128 registers: no room for the pieces in flight)
+    const void* fn = (const void*)attention_persist_kernel<HD, NW, TPC, PF, AHEAD>;
+    allow_dynamic_lds(fn, lds);
+    const int per_cu = std::max(1, std::min<int>(HD == 32 ? 2 : 1, (int)((160 * 1024) / lds)));  // LDS, and 128 / 256 registers
+    const int n_items = B * heads;
+    const int grid = std::min(n_items, current_device_cus() * per_cu);
+    attention_persist_kernel<HD, NW, TPC, PF, AHEAD><<<grid, NW * 64, lds, st>>>(qkv, mask_add, ctx, L, Lp, H, heads, n_items);
+}
+
 void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, float* ctx, int B, int L, int H,
                       int heads) {
     const int Lp = (L + 31) / 32 * 32;
@@ -1979,6 +2102,14 @@ void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, f
     const bool staged = lds <= 150 * 1024;
     if (staged) {  // eight waves + 64-key chunks where the sequence has eight query tiles (13.61 vs 13.93 ms per forward)
         const bool wide = Lp >= 256;
+        static const bool no_persist = getenv("PCV_ATTN_NO_PERSIST") != nullptr;
+        // head_dim 64 at 256 keys (BERT-base): one 139 KB workgroup per CU, 244 registers: the persistent form with the
+        // next item's pieces in flight, 128 -> 117 us per call (64 x 256 tokens).  head_dim 32 (two 75 KB workgroups
+        // per CU, 128 registers: no room for pieces in flight) measured 232 us persistent against 224 us: not used.
+        if (Lp == 256 && HD == 64 && !no_persist) {
+            launch_attention_persist<64, 8, 2, 8>(st, qkv, mask_add, ctx, B, L, Lp, H, heads, lds);
+            return;
+        }
         if (HD == 32) {
             if (wide) launch_attention_staged<32, 8, 2>(st, qkv, mask_add, ctx, B, L, Lp, H, heads, lds);
             else launch_attention_staged<32, 4, 2>(st, qkv, mask_add, ctx, B, L, Lp, H, heads, lds);

@@ -191,7 +191,7 @@ def test_split_precision_modes_are_f32_accurate(ctx, oracle, golden_dir, shape, 
 
 
 @pytest.mark.parametrize("compute", ["f32", "f16x2"])
-@pytest.mark.parametrize("heads,L", [(4, 77), (8, 40), (4, 200), (8, 129), (4, 256), (8, 250)])
+@pytest.mark.parametrize("heads,L", [(4, 77), (8, 40), (4, 200), (8, 129), (4, 256), (8, 250), (4, 250), (4, 225)])
 def test_attention_shapes_head_dim_64_and_32_ragged(ctx, oracle, compute, heads, L):
     # hidden 256: head_dim 64 (4 heads) and 32 (8 heads); sequence lengths that are not multiples of 32,
     # more than one 128-key chunk, ragged masks — both attention kernels (exact f32 and two-term f16)
@@ -235,6 +235,26 @@ def test_wave_specialised_bf16x3_gemm_is_bit_identical(ctx, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCV_GEMM_WS="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-800:]
     np.testing.assert_array_equal(np.load(tmp_path / "out.npy"), ref)
+
+
+def test_persistent_attention_walks_several_items_per_workgroup(ctx, oracle):
+    # head_dim 64 at 225..256 keys runs the persistent attention kernel: (batch, head) items walked by at most one
+    # workgroup per CU.  72 sequences x 4 heads = 288 items > 256 CUs: some workgroups take two items (the next item's
+    # K / V pieces in flight under the first one's MFMAs), ragged masks, a length that is not a multiple of 32.
+    desc = dict(vocab=400, hidden=256, layers=1, heads=4, inter=512, max_pos=256, eps=1e-12, pooling=0, normalize=1)
+    m = make_model(ctx, desc, seed=17)
+    rng = np.random.default_rng(99)
+    B, L = 72, 250
+    ids = rng.integers(1, 400, (B, L)).astype(np.int64)
+    mask = np.ones_like(ids)
+    for bb, n in enumerate(rng.integers(1, L + 1, B)):
+        mask[bb, n:] = 0
+    mask[0, :] = 1
+    ids *= mask
+    out = m.encode_tokens(ids, mask)
+    oout, _ = oracle.encode_tokens(desc, m.state_dict(), ids, mask)
+    assert np.abs(out - oout).max() < 2e-5
+    m.close()
 
 
 @pytest.mark.parametrize("compute", ["f32", "bf16x3", "f16x2"])
