@@ -200,13 +200,15 @@ enum { PCV_SCREEN_COPY_OFF = 0, PCV_SCREEN_COPY_BF16 = 1, PCV_SCREEN_COPY_AUTO =
 pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode);
 
 /* Mid copy: a third, optional representation of the rows — 16-bit fixed point per row, ROW-MAJOR (2 bytes per feature + 4 per
- * row: 76.8 GB for 100M x 384) — read by the fine screen in front of the f32 rows.  Worth its memory on corpora whose
- * coarse (int8) screen lets thousands of rows per query through (clustered embeddings): a coarse survivor then costs 768
- * contiguous bytes instead of 96 cache lines of the blocked f32 layout, and only rows within ~1e-4 of the running threshold
- * go on to their f32 row.  Results are identical with and without it (a certified bound, like the other screens).
- *   PCV_MID_COPY_AUTO (default): built by a search call once the coarse screen has let more than 4096 rows per query through
- *                        for 4 passes in a row over int8 copies, if the memory is there; dropped again — before the
- *                        screening copies — when an allocation for rows fails
+ * row: 76.8 GB for 100M x 384) — read by the fine screen in front of the f32 rows.  Worth its memory where the f32 rows of the
+ * coarse (int8) screen's survivors are a visible share of a pass: corpora that let thousands of rows per query through
+ * (clustered embeddings), wide rows, small shards.  A coarse survivor then costs 2 contiguous bytes per feature instead of
+ * one 128-byte cache line per 4 features of the blocked f32 layout, and only rows within ~1e-4 of the running threshold go on
+ * to their f32 row.  Results are identical with and without it (a certified bound, like the other screens).
+ *   PCV_MID_COPY_AUTO (default): built by a search call after 2 passes in a row over int8 copies in which the coarse screen let
+ *                        more than 4096 rows per query through, or in which the survivors' f32 rows came to more than 1/25 of
+ *                        the bytes streamed — if the memory is there (4 GB stay free); dropped again, before the screening
+ *                        copies, when an allocation for rows or for a screening copy fails
  *   PCV_MID_COPY_ON    : built at the next finalize (an allocation failure is an error)
  *   PCV_MID_COPY_OFF   : never built; an existing one is freed */
 enum { PCV_MID_COPY_OFF = 0, PCV_MID_COPY_AUTO = 1, PCV_MID_COPY_ON = 2 };

@@ -981,10 +981,10 @@ __device__ __forceinline__ void fine_survivors(const ScanParams& p, uint32_t mas
                 const uint32_t row = elb * 32 + (uint32_t)rib;
                 const float s2 = gld(&esc.scale16[row]);
                 float part = 0.0f;
-                if (lane < (Dp >> 3)) {
-                    const uint4 pv = __builtin_bit_cast(uint4, gld4((const float4*)esc.mid16 + (size_t)row * (Dp >> 3) + lane));
-                    const float4 qa = gld4(p.qf32 + (size_t)q * Dp + 8 * lane), qb = gld4(p.qf32 + (size_t)q * Dp + 8 * lane + 4);
-                    part = qa.x * (float)(int16_t)(pv.x & 0xffff);
+                for (int pc = lane; pc < (Dp >> 3); pc += 64) {  // (one trip up to 512-d, two up to 1024-d)
+                    const uint4 pv = __builtin_bit_cast(uint4, gld4((const float4*)esc.mid16 + (size_t)row * (Dp >> 3) + pc));
+                    const float4 qa = gld4(p.qf32 + (size_t)q * Dp + 8 * pc), qb = gld4(p.qf32 + (size_t)q * Dp + 8 * pc + 4);
+                    part = fmaf(qa.x, (float)(int16_t)(pv.x & 0xffff), part);
                     part = fmaf(qa.y, (float)((int32_t)pv.x >> 16), part);
                     part = fmaf(qa.z, (float)(int16_t)(pv.y & 0xffff), part);
                     part = fmaf(qa.w, (float)((int32_t)pv.y >> 16), part);
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
                         for (int i = 0; i < 4; ++i) buf[0][i] = VIA_LDS ? __builtin_bit_cast(float4, stage[i * 64]) : nb0[i];
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) buf[1][i] = VIA_LDS ? nb0[i] : nb1[i];
+                        for (int i = 0; i < 4; ++i) buf[NCH > 1 ? 1 : 0][i] = VIA_LDS ? nb0[i] : nb1[i];  // (NCH == 1: ch < NA = 1 means ch == 0, never here)
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // (the scheduler would fetch all 2 * 4 * NCH query pieces first: 190 registers)

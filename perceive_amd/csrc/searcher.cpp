@@ -237,7 +237,8 @@ void free_segment(Segment& g) {
 }
 
 constexpr int64_t kMidTrigger = 4096;  // coarse survivors per query and pass above which AUTO builds the mid copy ...
-constexpr int kMidPasses = 4;          // ... once that many passes in a row were above it
+constexpr int64_t kMidShare = 25;      // ... or whose f32 rows (32 B per feature: 16-byte pieces in 128-byte lines) come to more than 1/25 of the bytes streamed ...
+constexpr int kMidPasses = 2;          // ... once that many passes in a row were above it
 
 void drop_mid_copies(pcv_searcher* s) {
     s->mids_present = false;
@@ -288,6 +289,20 @@ void build_mid_copies(pcv_searcher* s, bool must) {
     for (const auto& src : s->sources)
         for (const auto& g : src.segs)
             if (g.nrows > 0 && (!g.mid16 || g.mid_rows < g.nrows)) s->mids_present = false;
+}
+
+// AUTO mid copy: called by every search entry point in front of its passes
+void maybe_build_mid_copies(pcv_searcher* s) {
+    if (!(s->mid_copy == PCV_MID_COPY_AUTO && !s->mids_present && !s->mid_gave_way && s->mid_hot_passes >= kMidPasses)) return;
+    // (only if the memory is plainly there: the copy is a convenience, the headroom is for rows)
+    size_t free_b = 0, total_b = 0, need = 0;
+    for (const auto& src : s->sources)
+        for (const auto& g : src.segs) need += (size_t)g.cap_rows * ((size_t)s->Dp * 2 + 4);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + ((size_t)4 << 30))
+        build_mid_copies(s, false);
+    else
+        s->mid_gave_way = true;
+    s->mid_hot_passes = 0;
 }
 
 void drop_screening_copies(pcv_searcher* s) {
@@ -462,6 +477,14 @@ void build_screening_copies(pcv_searcher* s, Source& src) {
             const size_t bytes = kind == 1 ? nblk * (s->D4 / 2) * 32 * sizeof(uint4) : nblk * (size_t)(((s->Dp + 127) & ~127) / 16) * 32 * sizeof(uint4);
             hipError_t e = s->fail_copy_alloc ? hipErrorOutOfMemory  // (PCV_TUNE_FAIL_COPY_ALLOC)
                                               : hipMalloc(kind == 1 ? (void**)&g.blk16 : (void**)&g.blk8, bytes);
+            if (e != hipSuccess && !s->fail_copy_alloc && s->mids_present && s->mid_copy == PCV_MID_COPY_AUTO) {
+                // a mid copy AUTO built by itself gives way to the screening copy the host asked for
+                (void)hipGetLastError();
+                PCV_HIP(hipStreamSynchronize(st));
+                drop_mid_copies(s);
+                s->mid_gave_way = true;
+                e = hipMalloc(kind == 1 ? (void**)&g.blk16 : (void**)&g.blk8, bytes);
+            }
             if (e == hipSuccess && kind == 2) {
                 e = hipMalloc((void**)&g.scale8, (size_t)(g.cap_rows / kBlockRows) * kScale8Stride * sizeof(float));
                 if (e != hipSuccess) {
@@ -868,8 +891,12 @@ bool finish_pass(pcv_searcher* s) {
     s->stats.coarse_survivors += coarse;
     s->stats.mid_copy = s->pending.mid ? 1 : 0;
     // AUTO: a corpus whose coarse screen keeps letting thousands of rows per query through gets its mid copy (built by the
-    // next search call, before its passes: search_hits)
-    if (s->pending.src == 2 && !s->pending.mid && coarse > kMidTrigger * (int64_t)B)
+    // next search call, before its passes: search_hits), and so does one where the survivors' f32 rows are a visible share
+    // of the pass's traffic (a survivor pulls every 128-byte line its 16-byte pieces lie in: 12 KB at 384-d, 24 KB at 768-d;
+    // measured gain of the copy: 12.5M x 384 3.5 %, 50M x 768 3.8 %, nothing at 100M x 384 where the share is 1.2 %)
+    const int64_t fine_bytes = coarse * (int64_t)s->Dp * 32;
+    if (s->pending.src == 2 && !s->pending.mid &&
+        (coarse > kMidTrigger * (int64_t)B || fine_bytes * kMidShare > (int64_t)s->pending.stream_bytes))
         s->mid_hot_passes += 1;
     else
         s->mid_hot_passes = 0;
@@ -963,17 +990,7 @@ void search_hits(pcv_searcher* s, const float* queries, int n_queries, const int
     s->stats.kernel_used = kernel;
     if (segs.empty()) return;
     const int qstep = pass_queries(s, kernel);
-    if (s->mid_copy == PCV_MID_COPY_AUTO && !s->mids_present && !s->mid_gave_way && s->mid_hot_passes >= kMidPasses) {
-        // (only if the memory is plainly there: the copy is a convenience, the headroom is for rows)
-        size_t free_b = 0, total_b = 0, need = 0;
-        for (const auto& src : s->sources)
-            for (const auto& g : src.segs) need += (size_t)g.cap_rows * ((size_t)s->Dp * 2 + 4);
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + ((size_t)4 << 30))
-            build_mid_copies(s, false);
-        else
-            s->mid_gave_way = true;
-        s->mid_hot_passes = 0;
-    }
+    maybe_build_mid_copies(s);
     for (int q0 = 0; q0 < n_queries; q0 += qstep) {
         const int B = std::min(qstep, n_queries - q0);
         run_pass(s, queries + (size_t)q0 * s->D, B, segs.data(), (int)segs.size(), k, kernel, nullptr, true);
@@ -1035,6 +1052,7 @@ void device_begin(pcv_searcher* s, const float* queries, int n_queries, const in
         s->pending.done = true;
         return;
     }
+    maybe_build_mid_copies(s);  // (each rank by its own statistics: the copy changes no result and no protocol)
     enqueue_pass(s, queries, n_queries, segs.data(), (int)segs.size(), k, kernel, out, false, out + n);
 }
 
@@ -1459,6 +1477,7 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
             PCV_HIP(hipStreamSynchronize(s->ctx->stream));  // `hits` dies with this scope
             return;
         }
+        maybe_build_mid_copies(s);
         // results stay on the device: every pass writes its slice of the caller's list
         for (int q0 = 0; q0 < n_queries; q0 += qstep) {
             const int B = std::min(qstep, n_queries - q0);

@@ -1274,7 +1274,7 @@ def _clustered(oracle, n, d, n_clusters, noise, seed, nq, rng):
 def test_mid_copy_is_invisible_in_the_results_and_cuts_the_f32_reads(ctx, oracle, metric):
     """The row-major 16-bit mid copy (scan.h): on a clustered corpus the coarse int8 screen lets a whole cluster through per
     query; with the mid copy nearly all of those are ruled out from 2 bytes per feature and only a few rows have their f32 row
-    read.  Hits and scores are the oracle's with the copy forced on, off, and built by AUTO after four such passes; rows added
+    read.  Hits and scores are the oracle's with the copy forced on, off, and built by AUTO after two such passes; rows added
     later join the copy; a failed allocation switches AUTO off for good and makes ON an error."""
     rng = np.random.default_rng(31)
     n, d, k = 240_000, 128, 10
@@ -1296,7 +1296,7 @@ def test_mid_copy_is_invisible_in_the_results_and_cuts_the_f32_reads(ctx, oracle
     check(ids, sc, sub)
     assert st0["screening_copy"] == 2 and st0["mid_copy"] == 0 and st0["coarse_survivors"] > 4096 * 64, st0
     s.set_mid_copy("auto")
-    for i in range(4):  # four passes above the trigger: the fifth call builds the copy before it searches
+    for i in range(2):  # two passes above the trigger: the third call builds the copy before it searches
         ids, sc, _ = s.search_vectors(None, k, q)
         assert s.last_stats()["mid_copy"] == 0
         check(ids, sc, sub)
@@ -1368,3 +1368,36 @@ def test_mid_copy_on_rows_that_quantise_badly(ctx, oracle):
         np.testing.assert_array_equal(cnt, ocnt)
         np.testing.assert_array_equal(ids, opos)
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [520, 768, 1024])
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_mid_copy_on_rows_wider_than_512_features(ctx, oracle, metric, dim):
+    """A mid row wider than 512 features is more than one 16-byte piece per lane: the mid screen has to sum all of them
+    (a build that read 64 pieces only scored the first 512 features, dropped rows of the top-k and let the thresholds
+    stand still: 11 700 coarse survivors per query instead of 1 100 on the 768-d bench corpus).  Rows of unequal norm as in
+    the product's default model (768-d, dot metric); forced on, against the oracle, and against the pass without the copy."""
+    rng = np.random.default_rng(dim)
+    n, k = 30_000, 10
+    rows = rng.standard_normal((n, dim)).astype(np.float32) * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+    rows[:, dim - 40:] *= 3.0  # weight in the features past the first 512: a partial sum would rank differently
+    q = rng.standard_normal((40, dim)).astype(np.float32)
+    q[:, dim - 40:] *= 3.0
+    s = pa.Searcher(ctx, dim, metric)
+    s.set_mid_copy("on")
+    s.add_rows(1, rows)
+    s.finalize()
+    ids, sc, cnt = s.search_vectors(None, k, q)
+    st = s.last_stats()
+    assert st["mid_copy"] == 1 and st["screening_copy"] == 2
+    opos, osc, ocnt = oracle.topk(q, rows, k, 1 if metric == "dot" else 0)
+    np.testing.assert_array_equal(cnt, ocnt)
+    np.testing.assert_array_equal(ids, opos)
+    s.set_mid_copy("off")
+    ids2, _, _ = s.search_vectors(None, k, q)
+    st2 = s.last_stats()
+    np.testing.assert_array_equal(ids2, opos)
+    # the thresholds rise as fast with the copy as without it: about as many rows pass the coarse screen
+    assert st["coarse_survivors"] < 2 * st2["coarse_survivors"] + 1000, (st["coarse_survivors"], st2["coarse_survivors"])
+    s.close()

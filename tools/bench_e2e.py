@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--seq", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--pass-queries", type=int, default=128, help="queries per corpus pass (<= 128 at 384-d)")
     ap.add_argument("--compute", default="f32", choices=["f32", "bf16x3", "f16x2"])
     a = ap.parse_args()

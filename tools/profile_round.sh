@@ -14,6 +14,18 @@ run() {  # run <dir under gpurun_out> <rocprof args...> -- <program...>
   d=$1; shift
   rm -rf $G/$d
   timeout -k 10 400 rocprofv3 "$@" > $G/$d.log 2>&1 || { echo "FAILED: $d"; tail -5 $G/$d.log; exit 1; }
+  # the per-dispatch trace is large: keep, per kernel, the durations in dispatch order (the summary averages the timed
+  # launches of a leg, i.e. the last `steps` of them: the --stats table also counts the warm-up passes)
+  python3 - $G/$d <<'PY'
+import csv, glob, json, sys, collections
+d = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    for r in rows:
+        if "scan_" in r["Kernel_Name"] or "attention" in r["Kernel_Name"]:
+            d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+json.dump(d, open(sys.argv[1] + "/durations.json", "w"))
+PY
   echo "ok $d"
   sleep 7  # the driver clears the ~190 GB the run gave back at ~34 GB/s in the background: 2.6 % of HBM bandwidth meanwhile
 }
@@ -49,6 +61,6 @@ else
   done
 fi
 # keep only the summaries (the traces themselves are large)
-find $G/prof_* $G/pmc_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" -delete 2>/dev/null
+find $G/prof_* $G/pmc_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" ! -name "durations.json" -delete 2>/dev/null
 find $G/prof_* $G/pmc_* -name "*.csv" | wc -l
 echo done

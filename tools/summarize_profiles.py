@@ -76,6 +76,17 @@ def pick_kernel(rows, base, kernel_ms):
     return min(cand, key=lambda r: abs(float(r["AverageNs"]) / 1e6 - kernel_ms))
 
 
+def timed_avg_ms(dirname, kernel_name, n):
+    """Average duration of the last n dispatches of a kernel in a run (the timed steps of the leg; --stats also counts the
+    warm-up passes, which run before a guess has been learned and, on the clustered corpus, before the mid copy exists)."""
+    for f in newest(os.path.join(GO, dirname, "*", "durations.json")):
+        d = json.load(open(f)).get(kernel_name)
+        if d:
+            d = d[-n:]
+            return sum(d) / len(d) / 1e6, len(d)
+    return None, 0
+
+
 def pmc_mean(dirname, counter, kernel_name):
     vals = []
     for f in newest(os.path.join(GO, dirname, "*", "*_counter_collection.csv")):
@@ -105,20 +116,25 @@ def main():
         if key is None:
             rec = {"kernel": out["roofline"]["kernel"], "kernel_ms": out["roofline"]["kernel_ms"],
                    "bytes_per_launch": out["roofline"]["bytes_per_launch"], "workload": out["config"]["workload"],
-                   "ms_per_step": out["ms_per_step"], "candidates_per_query": out["candidates_per_query"]}
+                   "ms_per_step": out["ms_per_step"], "candidates_per_query": out["candidates_per_query"], "steps": out["steps"]}
         else:
             e = out["extra"][key]
             rec = {"kernel": e["kernel"], "kernel_ms": e["kernel_ms"], "bytes_per_launch": e["roofline"]["bytes_per_launch"],
-                   "workload": e["workload"], "ms_per_step": e["ms_per_step"], "candidates_per_query": e["candidates_per_query"]}
+                   "workload": e["workload"], "ms_per_step": e["ms_per_step"], "candidates_per_query": e["candidates_per_query"],
+                   "steps": e["steps"] + e["overflow_reruns"] + e["speculation_reruns"]}
         row = pick_kernel(rows, rec["kernel"], rec["kernel_ms"])
         if row is None:
             print(f"(kernel {rec['kernel']} not in {f})")
             continue
-        prof_ms = float(row["AverageNs"]) / 1e6
+        all_ms = float(row["AverageNs"]) / 1e6
+        prof_ms, n_timed = timed_avg_ms("prof_" + suffix, row["Name"], rec["steps"])
+        if prof_ms is None:
+            prof_ms, n_timed = all_ms, int(row["Calls"])
         entry = {
             "workload": rec["workload"], "command": "bench.py --no-cpu-baseline " + ("--only " + key if key else "--no-extra") + " (tools/profile_round.sh)",
             "kernel": short(row["Name"]), "bytes_per_launch": rec["bytes_per_launch"],
-            "rocprof_avg_kernel_ms": prof_ms, "rocprof_calls": int(row["Calls"]),
+            "rocprof_avg_kernel_ms": prof_ms, "rocprof_timed_launches": n_timed,
+            "rocprof_avg_kernel_ms_all_launches": all_ms, "rocprof_calls": int(row["Calls"]),
             "bench_hip_event_kernel_ms": rec["kernel_ms"], "rocprof_over_bench": prof_ms / rec["kernel_ms"],
             "frac_of_8TBps_rocprof": rec["bytes_per_launch"] / (prof_ms * 1e-3) / 1e9 / PEAK,
             "frac_of_8TBps_bench": rec["bytes_per_launch"] / (rec["kernel_ms"] * 1e-3) / 1e9 / PEAK,
