@@ -1563,7 +1563,9 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 // Measured and not kept (100M x 384, 256 queries, same box each): the query pieces read from LDS three or five multiplies
 // ahead, order pinned with scheduling barriers: 12.18 against 12.28 ms (the waves do not wait on LDS); two held blocks per
 // wave at 2 waves per SIMD, the whole next block in flight: 11.27 against 11.10 ms (a third wave per SIMD hides as much);
-// the waves of a SIMD started a third of a half apart: 9.83 against 9.80 ms.  With no test at all the pass takes 8.7 ms,
+// the waves of a SIMD started a third of a half apart: 9.83 against 9.80 ms.  (385..768 features at 65..128 queries in this
+// form — one 768-thread workgroup per CU around the 98 KB tile, a 24 KB block held in 96 registers — does not fit 168 registers:
+// 42 spilled, the chunk buffers among them.  Those shapes stay on scan_mfma8_kernel<4, .., 8>.)  With no test at all the pass takes 8.7 ms,
 // and 7.3 ms with the rows coming from L2: the multiplies themselves, at the clock the chip holds under them (1.6 GHz).
 template <bool NTL, int NCH, int NH>
 __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel(const ScanParams* __restrict__ pp) {
