@@ -99,7 +99,18 @@ def pmc_mean(dirname, counter, kernel_name):
 
 
 def short(name):
-    return name.replace("void (anonymous namespace)::", "").split("(")[0]
+    """`void pcv::(anonymous namespace)::scan_mfma8_kernel<2, true, 4, 3>(pcv::ScanParams const*)` -> `scan_mfma8_kernel<2, true, 4, 3>`"""
+    n = name.replace("void ", "").replace("pcv::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    depth, out = 0, []
+    for ch in n:  # cut at the argument list: the first '(' outside the template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out).replace("pcv::", "")
 
 
 def main():
