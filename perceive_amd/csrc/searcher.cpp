@@ -654,6 +654,15 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
         blk0 += g.nblocks();
         rows += g.nrows;
     }
+    if (src_kind != 2) {
+        // the mid screen's bound uses |q'|_1, which only the int8 path's quantize_queries_kernel computes: passes that stream
+        // the bf16 copy or the f32 rows (few coarse survivors anyway) go straight to the f32 row
+        for (int i = 0; i < nseg; ++i) {
+            tab[i].mid16 = nullptr;
+            tab[i].scale16 = nullptr;
+        }
+        have_mid = false;
+    }
     PCV_REQUIRE(B <= 128 || (kernel == PCV_KERNEL_MFMA && src_kind == 2 && src_wanted == 2), "search: %d queries in one pass without int8 copies of every selected row", B);
     p.seg = reinterpret_cast<const SegDesc*>(s->d_pass + L.off_seg);
     p.nseg = nseg;

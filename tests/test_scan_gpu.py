@@ -1401,3 +1401,37 @@ def test_mid_copy_on_rows_wider_than_512_features(ctx, oracle, metric, dim):
     # the thresholds rise as fast with the copy as without it: about as many rows pass the coarse screen
     assert st["coarse_survivors"] < 2 * st2["coarse_survivors"] + 1000, (st["coarse_survivors"], st2["coarse_survivors"])
     s.close()
+
+
+@pytest.mark.gpu
+def test_mid_copy_is_used_only_by_passes_that_stream_the_int8_copy(ctx, oracle):
+    """The mid screen's bound needs |q'|_1 of the pass's queries, which only the int8 path computes.  A pass that streams the
+    bf16 copy or the f32 rows must not take the mid rows (it used to, with whatever constants the last int8 pass had left:
+    here that pass has one-hot queries, |q'|_1 = 1, fifteen times smaller than that of the dense queries that follow).
+    Near-tie data: many rows within 1e-5 of each query's k-th best."""
+    rng = np.random.default_rng(77)
+    n, d, k = 60_000, 384, 10
+    base = rng.standard_normal((n // 200, d)).astype(np.float32)
+    rows = (np.repeat(base, 200, axis=0) + 2e-5 * rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    q = (base[:48] + 1e-5 * rng.standard_normal((48, d)).astype(np.float32)).astype(np.float32)
+    onehot = np.zeros((48, d), np.float32)
+    onehot[np.arange(48), np.arange(48)] = 1.0
+    opos, osc, ocnt = oracle.topk(q, rows, k, 0)
+    s = pa.Searcher(ctx, d, "cosine")
+    s.set_mid_copy("on")
+    s.add_rows(1, rows)
+    s.finalize()
+    s.search_vectors(None, k, onehot)  # an int8 pass with the mid copy: leaves |q'|_1 = 1 behind
+    assert s.last_stats()["mid_copy"] == 1 and s.last_stats()["screening_copy"] == 2
+    ids, sc, cnt = s.search_vectors(None, k, q)  # int8 + mid copy, its own constants
+    np.testing.assert_array_equal(ids, opos)
+    for mode, copy in (("bf16", 1), ("off", 0)):
+        s.search_vectors(None, k, onehot) if mode == "bf16" else None
+        s.set_screening_copy(mode)
+        s.finalize()
+        ids, sc, cnt = s.search_vectors(None, k, q)
+        st = s.last_stats()
+        assert st["screening_copy"] == copy and st["mid_copy"] == 0 and st["mid_survivors"] == 0, st
+        np.testing.assert_array_equal(cnt, ocnt)
+        np.testing.assert_array_equal(ids, opos)
+    s.close()
