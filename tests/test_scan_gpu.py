@@ -1435,3 +1435,31 @@ def test_mid_copy_is_used_only_by_passes_that_stream_the_int8_copy(ctx, oracle):
         np.testing.assert_array_equal(cnt, ocnt)
         np.testing.assert_array_equal(ids, opos)
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,B", [(384, 100), (384, 256), (256, 200), (768, 100)])
+def test_mid_copy_under_the_block_holding_and_128_query_forms(ctx, oracle, dim, B):
+    """The mid screen sits in the fine screen all int8 scans share; the tests above reach it from the 64-query tile kernel.
+    Here: the block-holding form at 128 and 256 queries (384-d, 256-d) and the eight-wave 128-query tile (768-d), on a
+    clustered corpus where most coarse survivors end at the mid screen, against the oracle and against the pass without the copy."""
+    rng = np.random.default_rng(dim + B)
+    n, k = 96_000, 10
+    rows, q = _clustered(oracle, n, dim, 12, 0.004, 0xC7, B, rng)
+    opos, osc, ocnt = oracle.topk(q, rows, k, 0)
+    s = pa.Searcher(ctx, dim, "cosine")
+    s.set_mid_copy("on")
+    s.add_rows(1, rows)
+    s.finalize()
+    ids, sc, cnt = s.search_vectors(None, k, q)
+    st = s.last_stats()
+    assert st["mid_copy"] == 1 and st["screening_copy"] == 2, st  # (a pass may be repeated: lists that overflow on 8 000-row clusters)
+    assert 0 < st["mid_survivors"] < st["coarse_survivors"] // 4, st
+    np.testing.assert_array_equal(cnt, ocnt)
+    np.testing.assert_array_equal(ids, opos)
+    np.testing.assert_allclose(sc, osc.astype(np.float32), rtol=0, atol=1e-6)
+    s.set_mid_copy("off")
+    ids2, _, _ = s.search_vectors(None, k, q)
+    assert s.last_stats()["mid_copy"] == 0
+    np.testing.assert_array_equal(ids2, opos)
+    s.close()
