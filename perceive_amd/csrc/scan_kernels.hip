@@ -1000,6 +1000,11 @@ __device__ __forceinline__ void fine_survivors(const ScanParams& p, uint32_t mas
                 const float quant = gld(&p.q8c[4 * q + 2]) * 0.5003f / s2;  // |q'|_1 * 0.5002 / s2, rounded up
                 if (!(part / s2 >= taum - (quant + 1.5f * m32))) continue;  // (NaN scale: dropped)
                 if (lane == 0) g_atomic_add(&p.cand_cnt[q * kHot + 33], 1u);  // statistics: pairs the mid screen let through
+                // (measured and dropped: coarse survivors noted in a 16-entry LDS queue per wave and worked off four at a time,
+                // 16 lanes per mid row, one round trip for the four: clustered corpus 6.86 against 6.84 ms — the waves of a SIMD
+                // cover each other's round trips already; Gaussian rows slower, 0.973 against 0.941 ms at 12.5M rows and 7.43
+                // against 7.03 at 768-d / 128 queries: the deferred rows are the ones whose offers raise the thresholds,
+                // coarse survivors per query went from 500 to 850)
             }
             const float dot = wave_dot_f32(p.qf32 + (size_t)q * Dp, bbase + rib, D4, lane);
             if (sc == 0.0f) continue;  // padding / unsearchable row
