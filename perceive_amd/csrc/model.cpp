@@ -19,7 +19,7 @@ using namespace pcv;
 namespace {
 
 constexpr int64_t kDebugTokenLimit = 16384;
-constexpr int kGraphTokens = 128;  // forwards up to this many tokens are replayed as hipGraphs
+constexpr int kGraphTokens = 128;  // forwards up to this many tokens are replayed as hipGraphs (256 x 256 tokens replayed: 12.90 against 12.53 ms)
 
 void drop_graphs(pcv_model* m) {
     for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
