@@ -1504,7 +1504,8 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         PCV_STAMP(3)     // (the last one stays: the wave's end)
         // (measured and dropped, against the older workgroups of a CU finishing 4 % before the younger ones: s_setprio rotating
         // block by block through the three workgroups of a CU, 0.946 -> 0.939 ms at 12.5M rows, 6.251 -> 6.227 at 100M; the last
-        // 3.6 % of the blocks dealt out 2 : 1 : 0 to the thirds of the launch, 0.941 against 0.936 ms and 6.291 against 6.289)
+        // 3.6 % of the blocks dealt out 2 : 1 : 0 to the thirds of the launch, 0.941 against 0.936 ms and 6.291 against 6.289.
+        // Nor does it matter how much a wave reads in one piece: 2, 4 or 8 consecutive blocks per visit instead of one, 6.30 ms each.)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
