@@ -330,7 +330,7 @@ typedef struct pcv_scan_stats {
     float host_enqueue_ms;       /* host time spent queueing the passes (copies + launches)      */
     float host_wait_ms;          /* host time blocked until the stream had drained               */
     int64_t bytes_streamed;      /* bytes the scan kernel(s) had to read from HBM, layout padding included: per 32-row block
-                                    the f32 pieces + 32 row scales, or the bf16 pieces, or the int8 pieces + 36 scale floats */
+                                    the f32 pieces + 32 row scales, or the bf16 pieces, or the int8 pieces + the block's scale */
     int32_t speculation_reruns;  /* passes repeated because a speculative start threshold (a guess taken from the seed
                                     rows and checked at the end of the pass) did not hold; results are exact either way */
     int32_t mid_copy;            /* 1 if the last pass had the mid copy of every selected segment (pcv_searcher_set_mid_copy) */

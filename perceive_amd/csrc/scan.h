@@ -14,13 +14,15 @@
 // The coarse screen then streams 2 bytes per feature instead of 4; the f32 rows are read only for the coarse
 // survivors (fine screen) and the finalists (exact rescoring), so results are unchanged.
 //
-// Int8 screening copy (PCV_SCREEN_COPY_INT8): y = row x scale quantised per row, x^_i = rint(y_i * s_row) in [-127, 127],
-// s_row = 127 / max|y_i|, in 16-byte pieces of 16 features (feature dimension padded to a multiple of 128):
-//       blk8[(b * D16 + f16) * 32 + r]         D16 = roundup(Dp, 128) / 16;      scale8[row] = s_row
+// Int8 screening copy (PCV_SCREEN_COPY_INT8): y = row x scale quantised per 32-row block, x^_i = rint(y_i * s_row) in [-127, 127],
+// s_row = s_blk = 127 / max|y_i| over the block's searchable rows, in 16-byte pieces of 16 features (feature dimension padded
+// to a multiple of 128):
+//       blk8[(b * D16 + f16) * 32 + r]         D16 = roundup(Dp, 128) / 16;      scale8[b] = s_blk
 // The screen is then an exact integer dot product (v_mfma_i32_32x32x32_i8) of quantised row and quantised query,
 // 384 B per 384-d vector, with the certified bound
 //       |c - acc / (s_row s_q)| <= |q'|_1 * 0.5 / s_row  +  |x^|_1 / s_row * 0.5 / s_q        (+ the f32 term eps32)
-// and |x^|_1 <= sqrt(D) (s_row |y|_2 + 0.5 sqrt(D)), so one float per row (s_row) is all the test needs.
+// and |x^|_1 <= sqrt(D) (s_row |y|_2 + 0.5 sqrt(D)), so one float per block is all the test needs (any s_row <= 127 / max|y_i|
+// of the row keeps both |x^_i| <= 127 and |y_i - x^_i / s_row| <= 0.5 / s_row).
 //
 // Mid copy (optional, built when the coarse screen of a corpus lets many rows through: clustered embeddings): y = row x scale
 // quantised per row to int16, Y_i = rint(y_i * s2), s2 = 32766 / max|y_i|, stored ROW-MAJOR, Dp int16 per row:
@@ -45,7 +47,7 @@ constexpr int kMaxWaveQueries = 4;  // wave-reduction kernel handles 1..4 querie
 constexpr int kHot = 256;            // uint32 words between per-query hot words (tau, cand_cnt): 1 KB apart,
                                      // so the device-wide atomics on them do not queue on one HBM channel
 constexpr int kMfmaQueries = 256;   // most queries of one pass (the int8 scan up to 384-d: 256; the other MFMA scans 128)
-constexpr int kScale8Stride = 36;   // floats per block in SegDesc::scale8: 32 row scales + (min, max) of its two 16-row sets
+constexpr int kScale8Stride = 1;    // floats per block in SegDesc::scale8: the block's quantisation scale
 
 // One corpus segment as a scan launch sees it.  A launch walks any number of them: the table lives in
 // device memory next to the ScanParams (one source of the reference = one or more segments,
@@ -64,9 +66,7 @@ struct SegDesc {
     const uint4* blk8;   // int8 screening copy, or nullptr
     const uint4* mid16;  // row-major 16-bit copy (see below), or nullptr
     const float* scale16;
-    const float* scale8; // [nblocks][kScale8Stride] quantisation scales of the int8 copy's rows (NaN = row not searchable), within a
-                         // block in the order of the MFMA accumulators (row 8g + 4h + j at 16h + 4g + j), then the smallest
-                         // and largest scale of set h = 0 and of set h = 1
+    const float* scale8; // [nblocks] quantisation scale of the int8 copy's blocks (NaN = no searchable row in the block)
 };
 
 struct pcv_hit_dev {

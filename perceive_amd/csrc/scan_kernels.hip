@@ -296,9 +296,14 @@ __global__ __launch_bounds__(256) void coarse_pack_kernel(const float4* __restri
 
 
 // Int8 screening copy of blocks [first_block, nblocks), one wave per block: lane (r, h) owns row r and every
-// other 16-feature piece.  Pass 1: max |y_i| of the row (y = x * scale); pass 2: x^_i = rint(y_i * s_row),
-// s_row = 127 / max.  Rows that are not searchable get zeros and scale8 = NaN (no comparison with a NaN
-// threshold succeeds, so the scan drops them without looking); an all-zero searchable row (dot metric) gets s_row = 1.
+// other 16-feature piece.  Pass 1: max |y_i| over the BLOCK's searchable rows (y = x * scale); pass 2: x^_i = rint(y_i * s_blk),
+// s_blk = 127 / max: one scale for the 32 rows, so the scan's test of a block needs one float and its right-hand side is the same
+// for every row (per row scales made the block pre-test loose — the smallest scale of 16 rows stood for all of them, a third
+// of the blocks of a 12.5M-row pass went on to the row-by-row test at ~2 us each — and cost 144 B per block).  A row
+// quantised with a smaller scale than its own 127 / max|y_i| keeps |x^_i| <= 127 and |y_i - x^_i / s| <= 0.5 / s: the bound of
+// scan.h holds with s = s_blk; on Gaussian rows the margin grows by ~7 %.  Rows that are not searchable are stored as zeros (they
+// reach the fine screen only under a non-positive right-hand side and end there: scale 0); a block without a searchable row
+// gets s_blk = NaN (no comparison succeeds); all-zero searchable rows (dot metric) alone: s_blk = 1.
 __global__ __launch_bounds__(256) void coarse_pack8_kernel(const float4* __restrict__ blk, const float* __restrict__ scale,
                                                            uint4* __restrict__ blk8, float* __restrict__ scale8, uint32_t first_block,
                                                            uint32_t nblocks, int D4) {
@@ -317,7 +322,11 @@ __global__ __launch_bounds__(256) void coarse_pack8_kernel(const float4* __restr
                 }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const bool searchable = sc != 0.0f && mx < __builtin_inff();  // (NaN features: fmaxf ignores them; such rows have scale 0)
-        const float s_row = !searchable ? 0.0f : (mx > 0.0f ? 127.0f / mx : 1.0f);
+        float bm = searchable ? mx : 0.0f;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) bm = fmaxf(bm, __shfl_xor(bm, off));
+        const bool any_row = __any(searchable);
+        const float s_blk = !any_row ? __builtin_nanf("") : (bm > 0.0f ? 127.0f / bm : 1.0f);
         for (int g = h; g < D16; g += 2) {
             uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -327,33 +336,13 @@ __global__ __launch_bounds__(256) void coarse_pack8_kernel(const float4* __restr
                     const float y[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int qv = max(-127, min(127, (int)rintf(y[j] * s_row)));
+                        const int qv = max(-127, min(127, (int)rintf(y[j] * s_blk)));
                         w[e] |= (uint32_t)(qv & 0xff) << (8 * j);
                     }
                 }
             blk8[((size_t)b * D16 + g) * 32 + r] = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        // kScale8Stride floats per block: the 32 scales in the order the scan's accumulators hold the rows of a block
-        // (row 8g + 4h' + j at 16h' + 4g + j, so that a lane of the scan finds the 16 scales it tests next to each other),
-        // then the smallest and the largest scale of each of the two 16-row sets (NaN: the set has no searchable row)
-        const int set = (r >> 2) & 1;
-        if (h == 0) scale8[(size_t)b * kScale8Stride + 16 * set + 4 * (r >> 3) + (r & 3)] = searchable ? s_row : __builtin_nanf("");
-        float mn[2], mx2[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            mn[k] = (searchable && set == k) ? s_row : __builtin_inff();
-            mx2[k] = (searchable && set == k) ? s_row : -__builtin_inff();
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                mn[k] = fminf(mn[k], __shfl_xor(mn[k], off));
-                mx2[k] = fmaxf(mx2[k], __shfl_xor(mx2[k], off));
-            }
-        }
-        if (lane < 4) {
-            const int k = lane >> 1;
-            const float v = (lane & 1) ? mx2[k] : mn[k];
-            scale8[(size_t)b * kScale8Stride + 32 + lane] = (mn[k] <= mx2[k]) ? v : __builtin_nanf("");
-        }
+        if (lane == 0) scale8[b] = s_blk;
     }
 }
 
@@ -1426,20 +1415,14 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         if (prod.gb < p.total_blocks && ++prod.ch == NCH) enter_block(prod, prod.gb + total_waves);  // (the descriptor stays when the stream is over)
     };
 
-    // thresholds and the quantisation scales of the block being finished, requested one chunk ahead of the epilogue:
+    // thresholds and the quantisation scale of the block being finished, requested one chunk ahead of the epilogue:
     // lane (c, h) tests rows 4h + {0..3, 8..11, 16..19, 24..27} of the block
     uint32_t tauk[NT];
-    // every 16-lane row of the wave holds, lane i of the row, the scale of the row that accumulator i of those lanes tests
-    // (scale8 is stored in that order): the epilogue gets it with one row broadcast per accumulator
-    float srv = 0.0f;
-    float2 smm = make_float2(0.0f, 0.0f);  // smallest / largest scale among the 16 rows this lane tests
+    float sblk = 0.0f;
     auto prefetch = [&]() {  // (before the step's row loads and untouched until the epilogue: see scan_mfma_kernel)
 #pragma unroll
         for (int t = 0; t < NT; ++t) tauk[t] = ld_relaxed(&p.tau[(32 * t + c) * kHot]);
-        const float* s8 = cons.sc.scale8 + (size_t)cons.lb * kScale8Stride;
-        srv = gld(s8 + 16 * h + (lane & 15));
-        smm.x = gld(s8 + 32 + 2 * h);
-        smm.y = gld(s8 + 33 + 2 * h);
+        sblk = gld(cons.sc.scale8 + cons.lb);
     };
 
     auto epilogue = [&](const SegCursor& esc, uint32_t elb) {
@@ -1455,35 +1438,26 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
             const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
             U[t] = (q < p.B) ? (sq[t] != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
         }
-        // First the 16 rows of a lane at once: the largest accumulator against the smallest right-hand side any of them can
-        // have (s_row U - V is monotone in s_row: the extreme scale of the set on U's side).  Nearly every block ends here.
-        // (-6 % in the 128-query form, -4.5 % in the 64-query form — there with three chunk buffers instead of four: with
-        // four it spills 16 registers into the streaming loop at 3 waves per SIMD and costs 8 %.)
+        // One scale per block: the right-hand side s_blk U - V is the same for the 16 rows a lane tests, so the largest
+        // accumulator decides whether the block has a survivor at all.  Nearly every block ends here.
+        float rhs[NT];
         bool hot = false;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             int m = acc[t][0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
-            hot |= (float)m >= fmaf(U[t] >= 0.0f ? smm.x : smm.y, U[t], -vq[t]);
+            rhs[t] = fmaf(sblk, U[t], -vq[t]);  // (NaN scale: a block without a searchable row, no comparison succeeds)
+            hot |= (float)m >= rhs[t];
         }
-        // (srv is only read on the branch below; "used" here — beside the thresholds, which came with it — so that the compiler
-        // knows its load has landed: a register whose load may still be pending makes the next request for it wait vmcnt(0))
-        asm volatile("" : "+v"(srv));
         if (__any(hot)) {
-        // accumulator I tests the row whose scale sits in lane I of this lane's 16-lane row: DPP row_newbcast:I (the
-        // control word is an immediate; the value is used at once, so no 16 registers are held)
         uint32_t mask[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mask[t] = 0;
-#define PCV_TEST(I)                                                                                                            \
-    {                                                                                                                          \
-        const float s_row = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, srv), 0x150 + I, 0xf, 0xf, false)); \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) mask[t] |= ((float)acc[t][I] >= fmaf(s_row, U[t], -vq[t])) ? (1u << I) : 0u;  \
-    }
-        PCV_TEST(0) PCV_TEST(1) PCV_TEST(2) PCV_TEST(3) PCV_TEST(4) PCV_TEST(5) PCV_TEST(6) PCV_TEST(7)
-        PCV_TEST(8) PCV_TEST(9) PCV_TEST(10) PCV_TEST(11) PCV_TEST(12) PCV_TEST(13) PCV_TEST(14) PCV_TEST(15)
-#undef PCV_TEST
+        for (int t = 0; t < NT; ++t) {
+            mask[t] = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mask[t] |= ((float)acc[t][i] >= rhs[t]) ? (1u << i) : 0u;
+        }
         bool any = false;
 #pragma unroll
         for (int t = 0; t < NT; ++t) any |= mask[t] != 0;
@@ -1629,8 +1603,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
     uint32_t renew = wave % (uint32_t)(TQ / 32);  // tile whose U this wave renews at its next block
 
     float4 buf[NCH][4];
-    float srv = 0.0f;
-    float2 smm = make_float2(0.0f, 0.0f);
+    float sblk = 0.0f;  // quantisation scale of the block held (scan.h)
     __amdgpu_buffer_rsrc_t rows;  // the block's bytes (see ld_piece)
     const uint32_t lane_off = (uint32_t)(h * 32 + c) * 16u;
     auto enter = [&]() {  // the block `cur` points at
@@ -1642,11 +1615,8 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
 #pragma unroll
         for (int i = 0; i < 4; ++i) buf[ch][i] = ld_piece<NTL>(rows, lane_off + (uint32_t)i * 1024u, (uint32_t)ch * 4096u);
     };
-    auto load_scales = [&]() {  // of the block's rows (see scan_mfma8_kernel)
-        const float* s8 = cur.sc.scale8 + (size_t)cur.lb * kScale8Stride;
-        srv = gld(s8 + 16 * h + (lane & 15));
-        smm.x = gld(s8 + 32 + 2 * h);
-        smm.y = gld(s8 + 33 + 2 * h);
+    auto load_scales = [&]() {  // of the block (see scan_mfma8_kernel)
+        sblk = gld(cur.sc.scale8 + cur.lb);
     };
     enter();
 #pragma unroll
@@ -1666,8 +1636,7 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
     while (true) {
         const SegCursor esc = cur.sc;  // the block held: where its survivors live, and the scales of its rows
         const uint32_t elb = cur.lb;
-        const float srv_e = srv;
-        const float2 smm_e = smm;
+        const float sblk_e = sblk;
         cur.gb += total_waves;  // the next block: its cursor and descriptor now
         const bool more = cur.gb < p.total_blocks;
         if (more) enter();
@@ -1733,29 +1702,24 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
                 lU[32 * renew + c] = u_of(32 * (int)renew + c, rtau);
                 renew = renew + 1 == (uint32_t)(TQ / 32) ? 0u : renew + 1;
             }
+            float rhs[2];
             bool hot = false;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 int m = acc[t][0];
 #pragma unroll
                 for (int i = 1; i < 16; ++i) m = max(m, acc[t][i]);
-                hot |= (float)m >= fmaf(U[t] >= 0.0f ? smm_e.x : smm_e.y, U[t], -vq[t]);
+                rhs[t] = fmaf(sblk_e, U[t], -vq[t]);
+                hot |= (float)m >= rhs[t];
             }
-            asm volatile("" ::"v"(srv_e));  // (see scan_mfma8_kernel)
-            if (__any(hot)) {
+            if (__any(hot)) {  // (one scale per block: a block that gets here has a survivor)
                 uint32_t mask[2] = {0u, 0u};
-#define PCV_TEST(I)                                                                                                            \
-    {                                                                                                                          \
-        const float s_row = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, srv_e), 0x150 + I, 0xf, 0xf, false)); \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) mask[t] |= ((float)acc[t][I] >= fmaf(s_row, U[t], -vq[t])) ? (1u << I) : 0u;  \
-    }
-                PCV_TEST(0) PCV_TEST(1) PCV_TEST(2) PCV_TEST(3) PCV_TEST(4) PCV_TEST(5) PCV_TEST(6) PCV_TEST(7)
-                PCV_TEST(8) PCV_TEST(9) PCV_TEST(10) PCV_TEST(11) PCV_TEST(12) PCV_TEST(13) PCV_TEST(14) PCV_TEST(15)
-#undef PCV_TEST
-                if (__any((mask[0] | mask[1]) != 0)) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) fine_survivors(p, mask[t], 2 * half + t, esc, elb, ltau0, lane, D4);
-                }
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mask[t] |= ((float)acc[t][i] >= rhs[t]) ? (1u << i) : 0u;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fine_survivors(p, mask[t], 2 * half + t, esc, elb, ltau0, lane, D4);
             }
         }
         if (!more) return;

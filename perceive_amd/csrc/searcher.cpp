@@ -828,8 +828,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     s->pending.rows = rows;
     s->pending.src = src_kind;
     s->pending.mid = have_mid && nseg > 0;
-    // what the scan kernel of this pass must pull from HBM, per 32-row block: the int8 pieces + the 36 floats of scales and
-    // set extremes; the bf16 pieces; or the f32 pieces + the 32 row scales
+    // what the scan kernel of this pass must pull from HBM, per 32-row block: the int8 pieces + the block's scale; the bf16 pieces; or the f32 pieces + the 32 row scales
     const int64_t Dp8 = (s->Dp + 127) & ~127;
     s->pending.stream_bytes = (int64_t)blk0 * (src_kind == 2 ? Dp8 * kBlockRows + (int64_t)kScale8Stride * 4
                                                : src_kind == 1 ? (int64_t)s->Dp * 2 * kBlockRows

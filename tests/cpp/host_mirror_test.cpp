@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
     EXPECT(s->search_vector({}, 10, q).empty());
     {  // a screening copy (int8) is kept by default and changes nothing but the bytes streamed
         auto with = s->search_vector({1, 2}, 10, q);
-        const int64_t streamed8 = s->last_stats().bytes_streamed;  // per 32-row block: the int8 pieces (padded to 128 features) + 36 scale floats
+        const int64_t streamed8 = s->last_stats().bytes_streamed;  // per 32-row block: the int8 pieces (padded to 128 features) + the block's scale
         EXPECT(s->last_stats().screening_copy == 2 && streamed8 >= (int64_t)N * D && streamed8 < (int64_t)N * D * 2);
         s->set_screening_copy(PCV_SCREEN_COPY_OFF);
         auto without = s->search_vector({1, 2}, 10, q);

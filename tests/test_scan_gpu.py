@@ -58,8 +58,8 @@ def test_golden_1000(ctx, oracle, g1000, kernel, B, screen):
     mfma = kernel == "mfma" or (kernel == "auto" and (B > 4 or screen != "off"))  # with copies the MFMA kernel streams fewer bytes
     assert st["kernel_used"] == (2 if mfma else 1)
     assert st["screening_copy"] == ({"int8": 2, "bf16": 1, "off": 0}[screen] if mfma else 0)
-    nblk = st["scan_launches"] * ((1000 + 31) // 32)  # per 32-row block: f32 pieces + 32 scales | bf16 pieces | int8 pieces + 36 scale floats
-    assert st["bytes_streamed"] == nblk * {0: 384 * 4 * 32 + 128, 1: 384 * 2 * 32, 2: 384 * 32 + 144}[st["screening_copy"]]
+    nblk = st["scan_launches"] * ((1000 + 31) // 32)  # per 32-row block: f32 pieces + 32 scales | bf16 pieces | int8 pieces + the block's scale
+    assert st["bytes_streamed"] == nblk * {0: 384 * 4 * 32 + 128, 1: 384 * 2 * 32, 2: 384 * 32 + 4}[st["screening_copy"]]
     assert st["rows_scanned"] >= 1000 and st["overflow_reruns"] == 0
     s.close()
 
