@@ -195,7 +195,7 @@ pcv_status pcv_searcher_set_tuning(pcv_searcher* s, uint32_t flags);
  *                          allocation for rows or for a copy fails (the f32 rows are scanned then)
  *   PCV_SCREEN_COPY_OFF  : never built; existing copies are freed
  * BF16 / INT8 asked for explicitly: a failed copy allocation is an error at finalize.  Takes effect at the next
- * finalize (OFF: at once).  100M x 384: 153.6 GB of rows + 38.8 GB (INT8) or 76.8 GB (BF16). */
+ * finalize (OFF: at once).  100M x 384: 153.6 GB of rows + 38.4 GB (INT8) or 76.8 GB (BF16). */
 enum { PCV_SCREEN_COPY_OFF = 0, PCV_SCREEN_COPY_BF16 = 1, PCV_SCREEN_COPY_AUTO = 2, PCV_SCREEN_COPY_INT8 = 3 };
 pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode);
 
