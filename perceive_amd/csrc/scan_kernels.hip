@@ -1425,6 +1425,9 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         sblk = gld(cons.sc.scale8 + cons.lb);
     };
 
+#ifdef PCV_STAMPS
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memrealtime();
+#endif
     auto epilogue = [&](const SegCursor& esc, uint32_t elb) {
         if (NCH < 2) prefetch();
         float U[NT];
@@ -1475,6 +1478,16 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         PCV_COUNT(7, 1)  // blocks that passed the pre-test
         }
         PCV_COUNT(4, 1)  // blocks
+#ifdef PCV_STAMPS
+        {   // time since the previous block's end, booked by what this block did: low word of slot 2 = blocks that ended at
+            // the block test, high word = blocks with a survivor
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long dt = now - stamp_prev;
+            stamp_prev = now;
+            const bool past = __any(hot);  // (all lanes: PCV_COUNT runs on lane 0 only)
+            PCV_COUNT(2, past ? (dt << 32) : dt)
+        }
+#endif
         PCV_STAMP(3)     // (the last one stays: the wave's end)
         // (measured and dropped, against the older workgroups of a CU finishing 4 % before the younger ones: s_setprio rotating
         // block by block through the three workgroups of a CU, 0.946 -> 0.939 ms at 12.5M rows, 6.251 -> 6.227 at 100M; the last

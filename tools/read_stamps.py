@@ -2,7 +2,8 @@
 """Where the waves of scan_mfma8_kernel spent their time (diagnostic build, tools/build_stamps.sh).
     python tools/read_stamps.py stamps.bin [pass index, default last]
 Words per wave: 0 entry, 1 tile staged, 3 end of its last block (100 MHz clock); 4 blocks, 5 ticks inside the fine screen,
-6 blocks that reached the fine screen, 7 blocks that passed the pre-test."""
+6 blocks that reached the fine screen, 7 blocks that passed the block test; 2: ticks of the blocks that ended at the block test
+(low word) and of those with a survivor (high word), each block booked from the end of the one before it."""
 import sys
 
 import numpy as np
@@ -25,6 +26,12 @@ print("blocks per wave   ", q(w[:, 4].astype(float)))
 print("fine screen us    ", q(w[:, 5].astype(float) / 100.0))
 print("blocks w/ survivor", q(w[:, 6].astype(float)))
 print("blocks past pretest", q(w[:, 7].astype(float)))
+cold_t, hot_t = (w[:, 2] & 0xffffffff).astype(float) / 100.0, (w[:, 2] >> 32).astype(float) / 100.0
+nhot = w[:, 7].astype(float)
+ncold = w[:, 4].astype(float) - nhot
+print("us per block that ended at the block test", q(cold_t / np.maximum(ncold, 1)))
+print("us per block with a survivor              ", q(hot_t / np.maximum(nhot, 1)), " (fine screen included)")
+print("  of which outside the fine screen        ", q((hot_t - w[:, 5].astype(float) / 100.0) / np.maximum(nhot, 1)))
 # when do the slowest waves lose their time: stream duration against fine-screen time
 d = end - staged
 f = w[:, 5].astype(float) / 100.0
