@@ -148,7 +148,7 @@ def roofline_of(st, launches, kernel_ms, rows, dim):
 
 
 def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, clustered=False, searcher=None, dim=384, metric="cosine",
-             amplitude=None, tuning=0, keep=False):
+             amplitude=None, tuning=0, keep=False, leg=None):
     """One single-GPU scan measurement: `steps` exact top-k searches of `batch` fresh queries over `rows`
     synthetic rows resident in HBM.  Returns the record that goes under `extra` (same fields as the headline)."""
     own = searcher is None
@@ -205,7 +205,8 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
         "mid_copy": bool(st["mid_copy"]), "mid_survivors_per_query": float(np.mean(mids)) / batch,
         "overflow_reruns": reruns, "speculation_reruns": spec_reruns, "steps": steps,
     }
-    rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = measured_traffic(kname, streamed / max(launches, 1), clustered)
+    rec["roofline"]["traffic"], rec["roofline"]["traffic_source"] = measured_traffic(leg, kname, streamed / max(launches, 1))
+    rec["roofline"]["traffic_measured_in_this_run"] = False  # (a kept PMC pass of the same command: profiles/)
     if tuning:
         searcher.set_tuning(env_flags)
     if own and not keep:
@@ -280,16 +281,16 @@ def e2e_leg(pa, ctx, searcher, rows, steps=5, warmup=4, batch=256, seq=256, k=10
     }
 
 
-def measured_traffic(kernel, required_bytes, clustered=False):
+def measured_traffic(leg, kernel, required_bytes):
     """HBM bytes per launch from the committed PMC passes of this file's legs (profiles/traffic.json, written by
-    tools/summarize_profiles.py; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 guide): the leg of the same kernel whose
-    required bytes per launch are this run's (within 2 %).  bench.py cannot collect PMC counters on itself; None when
-    no pass covers this kernel and size."""
+    tools/summarize_profiles.py; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 guide): the entry of THIS leg, and only if
+    it was taken on the same kernel with the same required bytes per launch (within 2 %).  bench.py cannot collect PMC
+    counters on itself, so this is a figure of the kept profile run of the same command, not of this run; None when
+    the leg has no pass, or the pass was of another kernel or size."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        for t in table.values():
-            if t["kernel"].split("<")[0] == kernel and bool(t.get("clustered")) == bool(clustered) and abs(t["required_bytes_per_launch"] / required_bytes - 1.0) < 0.02:
-                return t["bytes_per_launch"] * required_bytes / t["required_bytes_per_launch"], t["source"]
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(leg)
+        if t and t["kernel"].split("<")[0] == kernel and abs(t["required_bytes_per_launch"] / required_bytes - 1.0) < 0.02:
+            return t["bytes_per_launch"] * required_bytes / t["required_bytes_per_launch"], t["source"]
     except Exception:
         pass
     return None, None
@@ -448,10 +449,10 @@ def main():
         ids, scores, counts = last
         kname = scan_kernel_name(st_last, B, args.dim)
         roof = roofline_of({"bytes_streamed": per_launch_streamed}, 1, mean_scan_ms, hi - lo, args.dim)
-        traffic, traffic_src = measured_traffic(kname, per_launch_streamed, args.clustered)
+        traffic, traffic_src = measured_traffic("headline" if not args.clustered else "clustered_b64", kname, per_launch_streamed)
         roof.update({
-            "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "streams": {None: "f32 rows + row scales", "bf16": "bf16 screening copy",
-                                                                                          "int8": "int8 screening copy + row scales"}[copy],
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_this_run": False, "kernel": kname, "streams": {None: "f32 rows + row scales", "bf16": "bf16 screening copy",
+                                                                                          "int8": "int8 screening copy + one quantisation scale per 32-row block"}[copy],
             "algorithmic_f32_bytes_per_launch": float(np.mean(scan_bytes)),  # N*D*4 of SURVEY 8d: what `effective_f32_pass_GBps` prices
             "kernel_ms_median": float(np.median(scan_ms)), "kernel_ms_min": float(np.min(scan_ms)),
             "read_ceiling_measured": measured_read_ceiling(),  # GB/s, profiles/r01_ubench_hbm_read*.txt
@@ -471,8 +472,9 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "screen": ({"int8": "coarse screen = exact integer dot product of per-row int8-quantised rows (resident screening copy, 384 B/vector "
-                                "+ 4.5 B of scales) and the int8-quantised query on v_mfma_i32_32x32x32_i8, with a certified quantisation margin; ",
+            "screen": ({"int8": "coarse screen = exact integer dot product of int8-quantised rows (resident screening copy, one quantisation scale per "
+                                "32-row block: 384 B/vector + 4 B per block) and the int8-quantised query on v_mfma_i32_32x32x32_i8, with a certified "
+                                "quantisation margin; ",
                         "bf16": "coarse screen = bf16 MFMA over the resident bf16 screening copy of the rows (768 B/vector); ",
                         None: "rows are read as f32 (1536 B/vector), bf16 MFMA coarse screen; "}[copy]
                        + "the f32 rows are read for the coarse survivors only: exact-f32 fine screen with certified margins, survivors "
@@ -512,6 +514,8 @@ def main():
             if want("no_guess"):
                 ng = scan_leg(pa, ctx, total_rows, B, k, args.kernel, max(3, es // 2), ew, searcher=searcher, dim=args.dim, tuning=32)
                 out["roofline"]["no_guess"] = {"kernel_ms": ng["kernel_ms"], "frac": ng["roofline"]["frac"], "candidates_per_query": ng["candidates_per_query"]}
+                out["roofline"]["no_guess_kernel_ms"] = ng["kernel_ms"]  # (scalars beside the records: a reader that keeps scalars only sees them)
+                out["roofline"]["no_guess_frac"] = ng["roofline"]["frac"]
             if args.dim == 384 and want("config5_end_to_end"):
                 extra["config5_end_to_end"] = e2e_leg(pa, ctx, searcher, total_rows)
             searcher.set_kernel(args.kernel)
@@ -519,21 +523,24 @@ def main():
                 # larger batches on the same corpus (the block-holding form of the int8 scan up to 384-d: 128 queries; 256 in one pass)
                 for nq in (128, 256):
                     if want(f"batch{nq}"):
-                        extra[f"batch{nq}"] = scan_leg(pa, ctx, total_rows, nq, k, args.kernel, max(3, es // 2), ew, searcher=searcher, dim=args.dim)
+                        extra[f"batch{nq}"] = scan_leg(pa, ctx, total_rows, nq, k, args.kernel, max(3, es // 2), ew, searcher=searcher, dim=args.dim, leg=f"batch{nq}")
             if copy is not None and want("f32_rows_b64", "bf16_copy_b64"):
                 # the same corpus and queries' shape without the int8 copy: the scan streams the f32 rows themselves
                 # (1536 B/vector, the SURVEY 8d / north_star workload) or the bf16 copy; results are the same exact top-k
-                held = {"int8": args.dim + 5, "bf16": 2 * args.dim}  # bytes per row of a copy
+                held = {"int8": ((args.dim + 127) // 128) * 128 + 0.125, "bf16": 2 * args.dim}  # bytes per row of a copy
                 for mode, key in (("off", "f32_rows_b64"), ("bf16", "bf16_copy_b64")):
                     searcher.set_screening_copy(mode)
                     searcher.finalize()
                     if mode == "off":
                         settle(total_rows * held[copy])
-                    extra[key] = scan_leg(pa, ctx, total_rows, B, k, args.kernel, es, ew, searcher=searcher, dim=args.dim)
+                    extra[key] = scan_leg(pa, ctx, total_rows, B, k, args.kernel, es, ew, searcher=searcher, dim=args.dim, leg=key)
                 # the north_star's own workload ("coalesced HBM reads of the corpus f32 rows", >= 70 % of the HBM roofline): beside the headline
                 f = extra["f32_rows_b64"]
                 out["roofline"]["f32_rows"] = {"kernel": f["kernel"], "kernel_ms": f["kernel_ms"], "achieved": f["roofline"]["achieved"],
                                                "frac": f["roofline"]["frac"], "vectors_per_s": f["vectors_per_s"]}
+                out["roofline"]["f32_rows_frac"] = f["roofline"]["frac"]
+                out["roofline"]["f32_rows_kernel_ms"] = f["kernel_ms"]
+                out["roofline"]["f32_rows_achieved"] = f["roofline"]["achieved"]
             if not args.clustered and args.rows >= 1_000_000 and want("clustered_b64", "d768_dot_b64", "d768_dot_b128", "d768_dot_b1"):
                 searcher.close()  # two 153.6 GB corpora do not fit: the clustered one replaces the headline one
                 searcher = None
@@ -541,22 +548,22 @@ def main():
                 # (the searcher's AUTO policy builds the row-major 16-bit mid copy after two passes in a row with more than 4096
                 # coarse survivors per query — pcv_searcher_set_mid_copy — and the steady state is what is timed)
                 if want("clustered_b64"):
-                    extra["clustered_b64"] = scan_leg(pa, ctx, args.rows, B, k, "auto" if token_headline else args.kernel, es, max(ew, 6), clustered=True, dim=args.dim)
+                    extra["clustered_b64"] = scan_leg(pa, ctx, args.rows, B, k, "auto" if token_headline else args.kernel, es, max(ew, 6), clustered=True, dim=args.dim, leg="clustered_b64")
                 # the reference's default model (MsMarcoBertBaseDotV5, perceive-cli/state.rs:24): 768-d, dot metric
                 # (search.rs:266-279), rows not normalised — norms spread over x[0.5, 2)
                 big = max(1_000_000, args.rows // 2)  # as many bytes of rows as the headline corpus
                 if want("d768_dot_b64", "d768_dot_b128"):
-                    rec, s768 = scan_leg(pa, ctx, big, 64, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0), keep=True)
+                    rec, s768 = scan_leg(pa, ctx, big, 64, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0), keep=True, leg="d768_dot_b64")
                     extra["d768_dot_b64"] = rec
-                    extra["d768_dot_b128"] = scan_leg(pa, ctx, big, 128, k, "auto", max(3, es // 2), ew, searcher=s768, dim=768, metric="dot", amplitude=(0.5, 2.0))
+                    extra["d768_dot_b128"] = scan_leg(pa, ctx, big, 128, k, "auto", max(3, es // 2), ew, searcher=s768, dim=768, metric="dot", amplitude=(0.5, 2.0), leg="d768_dot_b128")
                     s768.close()
                     settle(big * (768 * 4 + 768 + 8))
                 if want("d768_dot_b1"):
-                    extra["d768_dot_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0))
+                    extra["d768_dot_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew, dim=768, metric="dot", amplitude=(0.5, 2.0), leg="d768_dot_b1")
             if want("config2_10m_b1"):
-                extra["config2_10m_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew)
+                extra["config2_10m_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew, leg="config2_10m_b1")
             if want("shard_12p5m_b64"):
-                extra["shard_12p5m_b64"] = scan_leg(pa, ctx, max(100_000, args.rows // 8), 64, k, "auto", es, ew)
+                extra["shard_12p5m_b64"] = scan_leg(pa, ctx, max(100_000, args.rows // 8), 64, k, "auto", es, ew, leg="shard_12p5m_b64")
             if want("encoder_256x256"):
                 extra["encoder_256x256"] = encoder_leg(pa, ctx, "f32")
             if want("encoder_256x256_split_precision"):

@@ -97,6 +97,8 @@ struct ScanParams {
     float* margin;           // [B]  coarse screen: rows with s16 < tau - margin are dropped       (eps16 + eps32)
     float* margin32;         // [B]  fine screen:   rows with s32 < tau - margin32 are dropped     (2 * eps32)
     uint32_t* tau;           // [B*kHot]  ordered key of the running k-th best f32 score (word q*kHot)
+    uint32_t* tau_c;         // [256]     the same keys side by side (raised right after tau, so never above it): one load instead of a
+                             //           64-line gather for a wave that wants all thresholds of the pass (the DRAIN form of scan_mfma8_kernel)
     uint32_t* slots;         // [B][kMaxK] ordered keys of k distinct rows' f32 scores
     uint32_t* cand_cnt;      // [B*kHot]  survivors emitted per query (word q*kHot); word q*kHot + 32: rows that passed the COARSE screen
                              //           (statistics only: pcv_scan_stats.coarse_survivors)

@@ -15,11 +15,16 @@
 // HBM traffic = one pass over the rows (+ one extra row read per coarse survivor).
 #include <algorithm>
 #include <cstdlib>
+#include <numeric>
+#include <type_traits>
 
 #include "common.h"
 #include "scan.h"
 #include "synth.h"
 
+#ifndef PCV_EXP
+#define PCV_EXP 0
+#endif
 namespace pcv {
 namespace {
 
@@ -161,6 +166,7 @@ __device__ __forceinline__ void offer_slot(const ScanParams& p, int q, float s) 
             uint32_t nm = 0xffffffffu;
             for (int i = 0; i < p.k; ++i) nm = min(nm, ld_relaxed(&sl[i]));
             g_atomic_max(&p.tau[q * kHot], nm);
+            g_atomic_max(&p.tau_c[q], nm);
             return;
         }
     }
@@ -192,7 +198,10 @@ __device__ __forceinline__ void offer_slot_wave(const ScanParams& p, int q, floa
             for (int i = lane; i < p.k; i += 64) nm = min(nm, ld_relaxed(&sl[i]));
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) nm = min(nm, (uint32_t)__shfl_xor(nm, off));
-            if (lane == 0) g_atomic_max(&p.tau[q * kHot], nm);
+            if (lane == 0) {
+                g_atomic_max(&p.tau[q * kHot], nm);
+                g_atomic_max(&p.tau_c[q], nm);
+            }
             return;
         }
     }
@@ -471,6 +480,7 @@ __global__ __launch_bounds__(256) void reset_scan_state_kernel(uint32_t* __restr
     if (t < kMfmaQueries * kMaxK) slots[t] = kKeyNegInf;
     if (t < kMfmaQueries) {
         tau[t * kHot] = kKeyNegInf;
+        tau[kMfmaQueries * kHot + t] = kKeyNegInf;  // (ScanParams::tau_c)
         cand_cnt[t * kHot] = 0;
         cand_cnt[t * kHot + 32] = 0;
         cand_cnt[t * kHot + 33] = 0;
@@ -1259,7 +1269,10 @@ __device__ __forceinline__ void set_guess(const ScanParams& p, int q, int lane, 
             const bool alike = fabsf((ft - fm) - p.spec_spread) <= 0.5f * p.spec_spread;
             if (alike && isfinite(g)) guess = max(guess, f32_key(g));
         }
-        if (lane == 0 && guess != kKeyNegInf) g_atomic_max(&p.tau[q * kHot], guess);
+        if (lane == 0 && guess != kKeyNegInf) {
+            g_atomic_max(&p.tau[q * kHot], guess);
+            g_atomic_max(&p.tau_c[q], guess);
+        }
     }
     if (lane == 0 && have && p.spec_base_host) {
         p.spec_base_host[q] = med != kKeyNegInf ? key_f32(med) : __builtin_nanf("");
@@ -1328,30 +1341,407 @@ __global__ __launch_bounds__(256) void quantize_queries_kernel(const ScanParams*
 // nearly all loads in flight — 6.239; with plain global loads and 64-bit vector addresses 6.268; both 6.281.  At 3 waves per
 // SIMD and 12 per CU the other waves hide what one wave's chunk buffers would; the pass runs at the read rate the memory
 // system gives this pattern.)
+// f(integral_constant<int, I>) for I = FROM .. TO-1, until one returns true (a loop written out at compile time)
+template <int FROM, int TO, class F>
+__device__ __forceinline__ bool static_for_until(F&& f) {
+    if constexpr (FROM < TO) {
+        if (f(std::integral_constant<int, FROM>{})) return true;
+        return static_for_until<FROM + 1, TO>(f);
+    } else {
+        return false;
+    }
+}
+
+// ---- the survivor ring of scan_mfma8_kernel's DRAIN form -------------------------------------------------------------------
+// A coarse survivor used to be handled on the spot by the wave that found it: mid row, f32 row, list append, slot offer — up to
+// four dependent memory round trips during which the wave's chunk pipeline stood still, and an s_waitcnt vmcnt(0) in front of
+// them that emptied it (profiles/r03_stamps_12p5m_b64_blockscale.txt: 18.7 us for a block with a survivor against 6.2 us; 8 of a
+// wave's 127 blocks at 12.5M rows).  In the DRAIN form a streaming wave only WRITES the survivor — two LDS words, no global
+// memory access, nothing for vmcnt to wait on — into a ring in LDS, and the last wave of the workgroup (the drain wave) does
+// nothing but work the ring off, four survivors at a time with all their loads in flight together.  It owns the list appends
+// and the slot offers, so the thresholds keep rising during the pass as before.
+//   entry = lo: block inside the segment;  hi: bit 31 valid | segment << 13 | query << 5 | row inside the block
+//   producer: reserve with one LDS atomic (ring.tail), wait — the whole wave together — until the ring has room up to its last
+//             entry (ring.head, written by the drain wave), write lo, then hi;
+//   drain wave: wait for hi of the entry at its head to turn valid, read, clear hi, advance head.
+// No deadlock: the oldest unwritten entry belongs to a wave that waits for room for at most kRing / 2 entries beyond it (one
+// reservation spans at most 64 lanes x 16 rows = 1024 entries), and the drain wave consumes everything in front of it without
+// needing anyone.  The drain wave ends when every streaming wave has signed off (ring.done) and the ring is empty.
+constexpr uint32_t kRing = 2048;
+constexpr int kRingSegBits = 18;  // segments a launch in this form can address
+struct SurvRing {
+    uint32_t lo[kRing], hi[kRing];
+    int acc[kRing];      // the survivor's integer dot product and
+    float sblk[kRing];   // its block's quantisation scale: the drain wave repeats the coarse test against the thresholds of ITS time
+    uint32_t tail, head, done, pad;
+};
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// LDS operations of one wave execute in order; this keeps the compiler from reordering them
+#define PCV_LDS_ORDER() asm volatile("" ::: "memory")
+
+// The survivors of one lane (`m`: its surviving accumulators `acc` of query q, see fine_survivors) go into the ring.  Called by
+// all lanes of a streaming wave together.
+__device__ __forceinline__ void ring_push(SurvRing& ring, uint32_t m, const i32x16& acc, float sblk, uint32_t q, uint32_t hh, uint32_t si,
+                                          uint32_t elb) {
+    const uint32_t n = (uint32_t)__builtin_popcount(m);
+    uint32_t pos = 0;
+    if (m) pos = lds_add(&ring.tail, n);
+    while (__any(m != 0 && (pos + n - 1u) - lds_ld(&ring.head) >= kRing)) __builtin_amdgcn_s_sleep(2);
+    const uint32_t hib = 0x80000000u | (si << 13) | (q << 5) | (4u * hh);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {  // (unrolled: acc is indexed by constants and stays in registers)
+        if (m & (1u << i)) {
+            const uint32_t slot = pos & (kRing - 1);
+            lds_st(&ring.lo[slot], elb);
+            ring.acc[slot] = acc[i];
+            ring.sblk[slot] = sblk;
+            PCV_LDS_ORDER();
+            lds_st(&ring.hi[slot], hib + (uint32_t)((i & 3) + 8 * (i >> 2)));  // row of the block this accumulator holds
+            ++pos;
+        }
+    }
+}
+
+// The drain wave.  Up to 64 entries leave the ring at a time, one per lane, and meet the coarse test again — same formula, but
+// against the thresholds as they stand now (tau of the 64 queries sits on the 64 lanes, renewed every round): what queued up
+// while the thresholds rose is shed here at LDS speed, without a memory access.  What is left is worked off eight at a time,
+// eight lanes each, all loads of the eight in flight together: mid screen (if the segment has the mid copy), exact-f32 score
+// from the f32 row, fine test, list append; then the offers to the running top-k, one after the other by the whole wave.
+// Same tests, same constants as fine_survivors.
+// Order: the thresholds rise through the offers of rows that score above them, and while they are loose (the first blocks of
+// every wave) survivors arrive faster than one wave can look at them.  The int8 estimate acc / (s_blk s_q) is within ~1e-3 of
+// the score, the certified margin of the coarse test is 0.024 (384-d): an entry whose estimate clears the threshold by less
+// than a quarter of the margin is a LIKELY candidate and is worked on at once; the others — four in five, nearly none of
+// which ends up a candidate — wait on a stack of the drain wave's own (LDS, nobody else touches it) until the ring is empty,
+// and meet the coarse test a third time then: most never cost a memory access.
+// `streaming` = waves that sign off in ring.done; NQ = queries of the tile.
+constexpr uint32_t kStack = 2048;
+struct DrainStack {
+    uint32_t lo[kStack], hi[kStack];
+    int acc[kStack];
+    float sblk[kStack];
+};
+template <int NQ>
+__device__ __forceinline__ void drain_survivors(const ScanParams& p, SurvRing& ring, DrainStack& stk, const uint32_t* ltau0, const float* lsq,
+                                                const float* lvq, float* lU, int lane, int D4, uint32_t streaming, unsigned long long* stamp) {
+    static_assert(NQ <= 64, "one query per lane");
+    // diagnostic build (-DPCV_STAMPS; stamp = this wave's 8 words): 0 entry, 3 end, 4 entries out of the ring, 5 ticks at work,
+    // 6 rounds of eight worked, 7 entries shed by a repeated coarse test, 2 most entries waiting (ring: high word, stack: low word)
+#ifdef PCV_STAMPS
+#define PCV_DSTAMP(slot) if (stamp && lane == 0) stamp[slot] = __builtin_amdgcn_s_memrealtime();
+#define PCV_DCOUNT(slot, n) if (stamp && lane == 0) stamp[slot] += (n);
+#define PCV_DMAX(hi, lo_) if (stamp && lane == 0) { const unsigned long long o = stamp[2]; \
+        stamp[2] = (max(o >> 32, (unsigned long long)(hi)) << 32) | max(o & 0xffffffffull, (unsigned long long)(lo_)); }
+#else
+#define PCV_DSTAMP(slot)
+#define PCV_DCOUNT(slot, n)
+#define PCV_DMAX(hi, lo_)
+#endif
+    PCV_DSTAMP(0)
+#ifdef PCV_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();  // shader clock: slot 1 = its ticks over the wave's life
+#endif
+    const int Dp = D4 * 4, Dp8 = (Dp + 127) & ~127;
+    const uint32_t g = (uint32_t)lane >> 3;
+    const int sub = lane & 7;
+    // this lane's query (lane < NQ): constants of the coarse test (scan_mfma8_kernel's epilogue)
+    const int ql = lane < NQ ? lane : NQ - 1;
+    const float my_sq = lsq[ql], my_vq = lvq[ql];
+    const uint32_t my_tau0 = ltau0[ql];
+    const float my_e32 = ql < p.B ? 0.5f * gld(&p.margin32[ql]) : 0.0f;
+    const float nrm = (p.metric == PCV_METRIC_DOT) ? p.max_norm : 1.0f;
+    const float c1 = 0.5002f * sqrtf((float)Dp8) * nrm;
+    const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
+    uint32_t my_tau = ld_relaxed(&p.tau_c[ql]);
+    uint32_t head = 0, sp = 0, idle = 0;
+    int c_si = -1;  // the segment this lane last worked on (its table entry stays in registers)
+    const float4* c_blk = nullptr;
+    const float* c_scale = nullptr;
+    const uint4* c_mid = nullptr;
+    const float* c_s16 = nullptr;
+    __builtin_amdgcn_s_setprio(3);
+
+    // one entry per lane group of eight (`on`: the group has one): everything after the coarse test
+    auto work = [&](bool on, uint32_t hi, uint32_t lo) {
+#if PCV_EXP == 10  // timing experiment (wrong results): the drain wave throws the survivors away
+        return;
+#endif
+#ifdef PCV_STAMPS
+        const unsigned long long ts = __builtin_amdgcn_s_memrealtime();
+#endif
+        const int q = (int)((hi >> 5) & 0xffu), rib = (int)(hi & 31u), si = (int)((hi >> 13) & ((1u << kRingSegBits) - 1u));
+        const uint32_t lb = lo, row = lb * 32u + (uint32_t)rib;
+        if (on && si != c_si) {
+            c_si = si;
+            c_blk = gld(&p.seg[si].blk);
+            c_scale = gld(&p.seg[si].scale);
+            c_mid = gld(&p.seg[si].mid16);
+            c_s16 = gld(&p.seg[si].scale16);
+        }
+        float sc = 0.0f, m32 = 0.0f, s2 = 1.0f, l1 = 0.0f, part = 0.0f;
+        uint32_t tkey = kKeyNegInf;
+        const bool has_mid = on && c_mid != nullptr;
+        const float* qf = p.qf32 + (size_t)q * Dp;
+        if (on) {
+            sc = gld(&c_scale[row]);
+            tkey = ld_relaxed(&p.tau[q * kHot]);
+            m32 = gld(&p.margin32[q]);
+        }
+        if (has_mid) {  // mid screen (scan.h): Dp * 2 contiguous bytes, 16-byte pieces dealt round the 8 lanes
+            s2 = gld(&c_s16[row]);
+            l1 = gld(&p.q8c[4 * q + 2]);
+            const float4* mrow = (const float4*)c_mid + (size_t)row * (Dp >> 3);
+            for (int pc0 = sub; pc0 < (Dp >> 3); pc0 += 24) {  // (three pieces a round: the kernel's register count is the larger
+                uint4 pv[3];                                    //  of this wave's and the streaming waves')
+                float4 qa[3], qb[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int pc = pc0 + 8 * j;
+                    if (pc < (Dp >> 3)) {
+                        pv[j] = __builtin_bit_cast(uint4, gld4(mrow + pc));
+                        qa[j] = gld4(qf + 8 * pc);
+                        qb[j] = gld4(qf + 8 * pc + 4);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (pc0 + 8 * j < (Dp >> 3)) {
+                        part = fmaf(qa[j].x, (float)(int16_t)(pv[j].x & 0xffff), part);
+                        part = fmaf(qa[j].y, (float)((int32_t)pv[j].x >> 16), part);
+                        part = fmaf(qa[j].z, (float)(int16_t)(pv[j].y & 0xffff), part);
+                        part = fmaf(qa[j].w, (float)((int32_t)pv[j].y >> 16), part);
+                        part = fmaf(qb[j].x, (float)(int16_t)(pv[j].z & 0xffff), part);
+                        part = fmaf(qb[j].y, (float)((int32_t)pv[j].z >> 16), part);
+                        part = fmaf(qb[j].z, (float)(int16_t)(pv[j].w & 0xffff), part);
+                        part = fmaf(qb[j].w, (float)((int32_t)pv[j].w >> 16), part);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        bool go = on && sc != 0.0f;  // (0: padding / unsearchable row)
+        if (has_mid) {
+            const float taum = key_f32(max(ltau0[q], tkey));
+            const float quant = l1 * 0.5003f / s2;  // |q'|_1 * 0.5002 / s2, rounded up
+            go = go && (part / s2 >= taum - (quant + 1.5f * m32));  // (NaN scale: dropped)
+            if (go && sub == 0) g_atomic_add(&p.cand_cnt[q * kHot + 33], 1u);  // statistics: pairs the mid screen let through
+        }
+        // exact-f32 score of what is left: the row's pieces are 32 float4 apart in the blocked layout
+        float dot = 0.0f;
+        if (go) {
+            const float4* rowbase = c_blk + (size_t)lb * D4 * 32 + rib;
+            for (int f0 = sub; f0 < D4; f0 += 32) {
+                float4 v[4], qv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f4 = f0 + 8 * j;
+                    if (f4 < D4) {
+                        v[j] = gld4(rowbase + (size_t)f4 * 32);
+                        qv[j] = gld4(qf + 4 * f4);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (f0 + 8 * j < D4) {
+                        dot = fmaf(qv[j].x, v[j].x, dot);
+                        dot = fmaf(qv[j].y, v[j].y, dot);
+                        dot = fmaf(qv[j].z, v[j].z, dot);
+                        dot = fmaf(qv[j].w, v[j].w, dot);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        const float s32 = dot * sc;
+        const float taun = key_f32(max(ltau0[q], tkey));
+        const bool cand = go && !(s32 < taun - m32);
+        if (cand && sub == 0) {
+            const uint32_t at = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
+            if (at < p.cand_cap) {
+                gst(&p.cand[(size_t)q * p.cand_cap + at], ((uint64_t)(uint32_t)si << 32) | row);
+                gst(&p.cand_s[(size_t)q * p.cand_cap + at], s32);
+            }
+        }
+        const bool offer = cand && sub == 0 && !is_seed_block(p, si, lb) && isfinite(s32) && s32 > taun;
+        unsigned long long ob = __ballot(offer);
+        while (ob) {
+            const int osrc = __builtin_ctzll(ob);
+            ob &= ob - 1;
+            const int oq = __builtin_amdgcn_readlane(q, osrc);
+            const float os = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s32), osrc));
+            offer_slot_wave(p, oq, os, lane);
+        }
+        PCV_DCOUNT(5, __builtin_amdgcn_s_memrealtime() - ts)
+        PCV_DCOUNT(6, 1)
+    };
+    // the entries of the lanes in `set` (one per lane: ehi, elo), eight at a time
+    auto work_set = [&](unsigned long long set, uint32_t ehi, uint32_t elo) {
+        while (set) {
+            int src = -1;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                if (set) {
+                    const int s0 = __builtin_ctzll(set);
+                    set &= set - 1;
+                    if (g == j) src = s0;
+                }
+            }
+            const bool on = src >= 0;
+            work(on, (uint32_t)__shfl((int)ehi, on ? src : 0), (uint32_t)__shfl((int)elo, on ? src : 0));
+        }
+    };
+
+    for (;;) {
+        // U of this lane's query from the threshold as it stands, for this wave's repeat of the coarse test and — through lU —
+        // for the streaming waves' tests.  The thresholds are fetched after every round of work and every eighth idle poll
+        // (~1 us), from their side-by-side copy: one 256-byte load.  (Every streaming wave used to fetch them for every
+        // block, a 64-line gather each — agent-scope loads that go past the L2 to the memory side: 2816 waves x 64 requests
+        // per ~6 us beside the row stream.)
+        const uint32_t tau_now = my_tau;
+        if ((idle & 7u) == 0) my_tau = ld_relaxed(&p.tau_c[ql]);  // (for the next round: nobody waits for it here)
+        const float T = (key_f32(max(my_tau0, tau_now)) - my_e32) * my_sq;
+        const float myU = ql < p.B ? (my_sq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
+        const float myT = ql < p.B && my_sq != 0.0f ? T : -__builtin_inff();
+        if (lane < NQ) __hip_atomic_store(&lU[lane], myU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+        uint32_t tail = lds_ld(&ring.tail);
+        bool over = false;
+        if (tail == head) {
+            over = lds_ld(&ring.done) == streaming;
+            if (over) {
+                PCV_LDS_ORDER();
+                tail = lds_ld(&ring.tail);  // (a wave signs off after its last reservation)
+            }
+        }
+        if (tail != head) {
+            idle = 0;
+            const uint32_t n = min(tail - head, 64u);
+            const bool have = (uint32_t)lane < n;
+            uint32_t ehi = 0, elo = 0;
+            int eacc = 0;
+            float esb = 0.0f;
+            if (have) {
+                const uint32_t slot = (head + (uint32_t)lane) & (kRing - 1);
+                do ehi = lds_ld(&ring.hi[slot]);
+                while (!(ehi & 0x80000000u));
+                PCV_LDS_ORDER();
+                elo = lds_ld(&ring.lo[slot]);
+                eacc = ring.acc[slot];
+                esb = ring.sblk[slot];
+                PCV_LDS_ORDER();
+                lds_st(&ring.hi[slot], 0u);
+            }
+            head += n;
+            PCV_LDS_ORDER();
+            if (lane == 0) lds_st(&ring.head, head);  // the producers may go on while these entries are worked on
+            const int eq = (int)((ehi >> 5) & 0xffu);
+            const float U = __shfl(myU, eq), vq = __shfl(my_vq, eq), Tq = __shfl(myT, eq);
+            const float rhs = fmaf(esb, U, -vq);
+            const bool keep = have && (float)eacc >= rhs;
+            // likely: the estimate clears the threshold by less than a quarter of the margin (margin = s_blk T - rhs)
+            const bool likely = keep && (float)eacc >= fmaf(0.25f, rhs, 0.75f * esb * Tq);
+#if PCV_EXP != 11
+            if (have) g_atomic_add(&p.cand_cnt[eq * kHot + 32], 1u);  // statistics: coarse survivors
+#endif
+            const unsigned long long wait = __ballot(keep && !likely);
+            const uint32_t nw = (uint32_t)__builtin_popcountll(wait);
+            PCV_DCOUNT(4, n)
+            PCV_DCOUNT(7, n - (uint32_t)__builtin_popcountll(__ballot(keep)))
+            PCV_DMAX(tail - (head - n), sp + nw)
+            if (sp + nw <= kStack) {
+                if (keep && !likely) {
+                    const uint32_t at = sp + (uint32_t)__builtin_popcountll(wait & ((1ull << lane) - 1ull));
+                    stk.lo[at] = elo;
+                    stk.hi[at] = ehi;
+                    stk.acc[at] = eacc;
+                    stk.sblk[at] = esb;
+                }
+                sp += nw;
+                work_set(__ballot(likely), ehi, elo);
+            } else {
+                work_set(__ballot(keep), ehi, elo);
+            }
+        } else if (sp > 0) {
+            // nothing new: the eight youngest waiting entries, against the thresholds of now
+            idle = 0;
+            const uint32_t n = min(sp, 8u);
+            sp -= n;
+            const bool have = g < n;
+            const uint32_t at = sp + (have ? g : 0u);
+            const uint32_t ehi = stk.hi[at], elo = stk.lo[at];
+            const int eacc = stk.acc[at];
+            const float esb = stk.sblk[at];
+            const int eq = (int)((ehi >> 5) & 0xffu);
+            const float U = __shfl(myU, eq), vq = __shfl(my_vq, eq);
+            const bool keep = have && (float)eacc >= fmaf(esb, U, -vq);
+            PCV_DCOUNT(7, n - (uint32_t)__builtin_popcountll(__ballot(keep && sub == 0)))
+            if (__any(keep)) work(keep, ehi, elo);
+        } else if (over) {
+            break;
+        } else {
+            ++idle;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    PCV_DSTAMP(3)
+    PCV_DCOUNT(1, __builtin_amdgcn_s_memtime() - clk0)
+#undef PCV_DSTAMP
+#undef PCV_DCOUNT
+#undef PCV_DMAX
+}
+
 #ifdef PCV_STAMPS  // diagnostic build (tools/build_stamps.sh): where a wave's time goes; the 100 MHz constant clock
 #define PCV_STAMP(slot)                                                                                            \
     if (p.stamps && lane == 0) p.stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();
+#ifdef PCV_STAMPS_TIMELINE  // slots 5, 6, 7 = time at the end of the wave's 8th, 32nd, 96th block instead of the fine-screen counts
+#define PCV_COUNT(slot, n) \
+    if ((slot) < 5 && p.stamps && lane == 0) p.stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + (slot)] += (n);
+#else
 #define PCV_COUNT(slot, n) \
     if (p.stamps && lane == 0) p.stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + (slot)] += (n);
+#endif
 #else
 #define PCV_STAMP(slot)
 #define PCV_COUNT(slot, n)
 #endif
-template <int NT, bool NTL, int WPB, int NBUF>
+// DRAIN: the last of the workgroup's WPB waves is the drain wave of the survivor ring above, the others stream.
+// NCHT: chunks per block as a compile-time constant (0: taken from the pass's dimension at run time).  With the chunk count known
+// the loop below is written out over lcm(NCHT, NBUF) steps, and every request has its place in program order: the thresholds
+// and the scale of a block are asked for two steps before its test, 8 row loads behind them — the test waits with
+// s_waitcnt vmcnt(8).  In the run-time form the compiler cannot relate `cons.ch == NCH - 2` (where the request is made) to
+// `++cons.ch == NCH` (where it is used), has to allow for the one-chunk case that asks inside the test, and ends EVERY block
+// with s_waitcnt vmcnt(0): each block then waited for the chunk requested a moment before.
+template <int NT, bool NTL, int WPB, int NBUF, bool DRAIN, int NCHT>
 __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
+    constexpr uint32_t SW = DRAIN ? WPB - 1 : WPB;  // streaming waves of a workgroup
     extern __shared__ uint4 lq8[];  // [NT*32][LDQ] pieces of 16 int8
     const int D4 = p.D4;
     const int Dp = D4 * 4;
     const int Dp8 = (Dp + 127) & ~127;
-    const int P16 = Dp8 >> 4;   // pieces per row
+    const int P16 = NCHT ? NCHT * 8 : Dp8 >> 4;   // pieces per row
     const int LDQ = P16 + 1;    // odd
-    const int NCH = Dp8 >> 7;   // chunks of 128 features
+    const int NCH = NCHT ? NCHT : Dp8 >> 7;   // chunks of 128 features
     __shared__ uint32_t ltau0[NT * 32];
     __shared__ float lsq[NT * 32], lvq[NT * 32];
+    __shared__ uint32_t ring_words[DRAIN ? sizeof(SurvRing) / 4 : 4];
+    SurvRing& ring = *(SurvRing*)ring_words;  // (touched in the DRAIN form only)
+    __shared__ uint32_t stack_words[DRAIN ? sizeof(DrainStack) / 4 : 4];
+    DrainStack& stack = *(DrainStack*)stack_words;
+    __shared__ float lU[NT * 32];  // DRAIN form: U_q of the test (below) from the thresholds as the drain wave last saw them
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     PCV_STAMP(0)
+    if constexpr (DRAIN) {
+        for (uint32_t i = threadIdx.x; i < kRing; i += WPB * 64) ring.hi[i] = 0u;
+        if (threadIdx.x < 4) (&ring.tail)[threadIdx.x] = 0u;
+    }
     for (int i = threadIdx.x; i < NT * 32 * P16; i += WPB * 64) {  // the tile quantize_queries_kernel prepared
         const int q = i / P16, pc = i - q * P16;
         lq8[(size_t)q * LDQ + pc] = __builtin_bit_cast(uint4, gld4((const float4*)p.q8 + i));
@@ -1368,6 +1758,15 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     const int c = lane & 31, h = lane >> 5;
     const float nrm = (p.metric == PCV_METRIC_DOT) ? p.max_norm : 1.0f;
     const float c1 = 0.5002f * sqrtf((float)Dp8) * nrm;
+    if constexpr (DRAIN) {  // the first U of every query (the drain wave keeps them fresh from here on)
+        for (int q = threadIdx.x; q < NT * 32; q += WPB * 64) {
+            const float sqq = lsq[q];
+            const float T = (key_f32(max(ltau0[q], ld_relaxed(&p.tau_c[q]))) - (q < p.B ? 0.5f * gld(&p.margin32[q]) : 0.0f)) * sqq;
+            const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
+            lU[q] = (q < p.B) ? (sqq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
+        }
+        __syncthreads();
+    }
     float sq[NT], vq[NT], e32[NT];
     uint32_t tau0[NT];
 #pragma unroll
@@ -1379,8 +1778,24 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         tau0[t] = ltau0[32 * t + c];
     }
 
-    const uint32_t total_waves = gridDim.x * WPB;
-    if (blockIdx.x * WPB + wave >= p.total_blocks) return;
+    if constexpr (DRAIN) {
+        if (wave == SW) {
+            drain_survivors<NT * 32>(p, ring, stack, ltau0, lsq, lvq, lU, lane, D4, SW,
+                                     p.stamps ? p.stamps + (size_t)(blockIdx.x * WPB + wave) * 8 : nullptr);
+            return;
+        }
+    }
+    // a streaming wave's last act in the DRAIN form: sign off (after its last ring entry: LDS operations stay in order)
+#define PCV_WAVE_DONE()                               \
+    {                                                 \
+        if constexpr (DRAIN) {                        \
+            PCV_LDS_ORDER();                          \
+            if (lane == 0) lds_add(&ring.done, 1u);   \
+        }                                             \
+        return;                                       \
+    }
+    const uint32_t total_waves = gridDim.x * SW;
+    if (blockIdx.x * SW + wave >= p.total_blocks) PCV_WAVE_DONE()
     PCV_STAMP(1)
 
     i32x16 acc[NT];
@@ -1389,23 +1804,27 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0;
 
-    auto enter_block = [&](BlockCursor& k, uint32_t gb) {
+    auto enter_block = [&](BlockCursor& k, uint32_t gb) __attribute__((always_inline)) {
         k.gb = gb;
         k.ch = 0;
         if (gb < p.total_blocks) {
             seek_seg(p, k.sc, gb);
             k.lb = gb - k.sc.begin;
+#if PCV_EXP == 7 || PCV_EXP == 9  // timing experiment (wrong results): the rows of 256 blocks over and over — they come out of the L2
+            k.rows = row_rsrc((const float4*)k.sc.blk8 + (size_t)(k.lb & 255u) * P16 * 32, (uint32_t)P16 * 512u);
+#else
             k.rows = row_rsrc((const float4*)k.sc.blk8 + (size_t)k.lb * P16 * 32, (uint32_t)P16 * 512u);
+#endif
         }
     };
     const uint32_t lane_off = (uint32_t)(h * 32 + c) * 16u;
     BlockCursor cons, prod;
-    enter_block(cons, blockIdx.x * WPB + wave);
+    enter_block(cons, blockIdx.x * SW + wave);
     prod = cons;
 
     float4 buf[NBUF][4];
     // lane's piece of k-step ks of a chunk: f16 = chunk*8 + ks*2 + h  (h folded into base)
-    auto produce = [&](float4 (&b)[4]) {
+    auto produce = [&](float4 (&b)[4]) __attribute__((always_inline)) {
         // ALWAYS issues its loads — past the end of the wave's stream they re-read a chunk of its last block (two or three
         // chunks per wave and launch).  With an early return here the compiler has to place every s_waitcnt for the case that
         // the younger chunks were never requested: each multiply then waited for (nearly) all loads in flight, the ones just
@@ -1418,21 +1837,34 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     // thresholds and the quantisation scale of the block being finished, requested one chunk ahead of the epilogue:
     // lane (c, h) tests rows 4h + {0..3, 8..11, 16..19, 24..27} of the block
     uint32_t tauk[NT];
+    float Uk[NT];  // DRAIN form: U_q as the drain wave last wrote it (LDS) instead of the thresholds themselves
     float sblk = 0.0f;
-    auto prefetch = [&]() {  // (before the step's row loads and untouched until the epilogue: see scan_mfma_kernel)
+    auto prefetch = [&]() __attribute__((always_inline)) {  // (before the step's row loads and untouched until the epilogue: see scan_mfma_kernel)
+        if constexpr (DRAIN) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) tauk[t] = ld_relaxed(&p.tau[(32 * t + c) * kHot]);
+            for (int t = 0; t < NT; ++t) Uk[t] = __hip_atomic_load(&lU[32 * t + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) tauk[t] = ld_relaxed(&p.tau[(32 * t + c) * kHot]);
+        }
         sblk = gld(cons.sc.scale8 + cons.lb);
     };
 
 #ifdef PCV_STAMPS
     unsigned long long stamp_prev = __builtin_amdgcn_s_memrealtime();
+    uint32_t stamp_nblk = 0;
 #endif
-    auto epilogue = [&](const SegCursor& esc, uint32_t elb) {
-        if (NCH < 2) prefetch();
+    auto epilogue = [&](const SegCursor& esc, uint32_t elb) __attribute__((always_inline)) {
+        if constexpr (NCHT == 0) {
+            if (NCH < 2) prefetch();
+        }
         float U[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if constexpr (DRAIN) {
+                U[t] = Uk[t];
+                continue;
+            }
             const int q = 32 * t + c;
             const float T = (key_f32(max(tau0[t], tauk[t])) - e32[t]) * sq[t];
             // lowered by 2e-6 relative (f32 rounding of T and of the product with s_row) and by the |x^|_1 term
@@ -1453,7 +1885,12 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
             rhs[t] = fmaf(sblk, U[t], -vq[t]);  // (NaN scale: a block without a searchable row, no comparison succeeds)
             hot |= (float)m >= rhs[t];
         }
+#if PCV_EXP == 8 || PCV_EXP == 9  // timing experiment (wrong results): every block ends at its test
+        asm volatile("" ::"s"(__ballot(hot)));
+        if (false) {
+#else
         if (__any(hot)) {
+#endif
         uint32_t mask[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1468,8 +1905,14 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
 #ifdef PCV_STAMPS
             const unsigned long long ts = __builtin_amdgcn_s_memrealtime();
 #endif
+            if constexpr (DRAIN) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) fine_survivors(p, mask[t], t, esc, elb, ltau0, lane, D4);
+                for (int t = 0; t < NT; ++t)
+                    if (__any(mask[t] != 0)) ring_push(ring, mask[t], acc[t], sblk, (uint32_t)(32 * t + c), (uint32_t)h, (uint32_t)esc.si, elb);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fine_survivors(p, mask[t], t, esc, elb, ltau0, lane, D4);
+            }
 #ifdef PCV_STAMPS
             PCV_COUNT(5, __builtin_amdgcn_s_memrealtime() - ts)  // time inside the fine screen
             PCV_COUNT(6, 1)                                      // blocks that reached it
@@ -1486,6 +1929,13 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
             stamp_prev = now;
             const bool past = __any(hot);  // (all lanes: PCV_COUNT runs on lane 0 only)
             PCV_COUNT(2, past ? (dt << 32) : dt)
+#ifdef PCV_STAMPS_TIMELINE
+            ++stamp_nblk;  // (low word: the 100 MHz clock; high word: the low 32 bits of the shader clock)
+            if (stamp_nblk == 1 || stamp_nblk == 8 || stamp_nblk == 32 || stamp_nblk == 96) {
+                const unsigned long long both = (now & 0xffffffffull) | (__builtin_amdgcn_s_memtime() << 32);
+                if (p.stamps && lane == 0) p.stamps[(size_t)(blockIdx.x * WPB + wave) * 8 + (stamp_nblk == 1 ? 1 : stamp_nblk == 8 ? 5 : stamp_nblk == 32 ? 6 : 7)] = both;
+            }
+#endif
         }
 #endif
         PCV_STAMP(3)     // (the last one stays: the wave's end)
@@ -1499,7 +1949,7 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
             for (int i = 0; i < 16; ++i) acc[t][i] = 0;
     };
 
-    auto consume = [&](const float4 (&b)[4]) {
+    auto consume = [&](const float4 (&b)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const i32x4 a = __builtin_bit_cast(i32x4, b[ks]);
@@ -1516,11 +1966,90 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         }
     };
 
+    if constexpr (NCHT > 0) {
+        // chunk count known: lcm(NCHT, NBUF) steps written out; step s consumes chunk s % NCHT of its block out of buffer
+        // s % NBUF while chunk (s + NBUF - 1) % NCHT of a later block is requested into the buffer consumed a step ago
+        constexpr int PERIOD = NCHT * NBUF / std::gcd(NCHT, NBUF);
+#pragma unroll
+        for (int i = 0; i < NBUF - 1; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) buf[i][j] = ld_piece<NTL>(prod.rows, lane_off + (uint32_t)j * 1024u, (uint32_t)(i % NCHT) * 4096u);
+            if ((i % NCHT) == NCHT - 1 && prod.gb < p.total_blocks) enter_block(prod, prod.gb + total_waves);
+        }
+#if PCV_EXP == 6
+        i32x16 dummy;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dummy[i] = 0;
+#endif
+#if PCV_EXP == 1
+        i32x4 qfix[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) qfix[t] = *(const i32x4*)&lq8[(size_t)(32 * t + c) * LDQ + h];
+#endif
+        auto step = [&](auto S) __attribute__((always_inline)) -> bool {  // true: the wave's stream is over
+                constexpr int s = decltype(S)::value;
+                constexpr int ch = s % NCHT, pch = (s + NBUF - 1) % NCHT;
+                if constexpr (NCHT >= 2 ? ch == NCHT - 2 : true) prefetch();
+                {   // produce (always: see `produce`)
+                    float4(&b)[4] = buf[(s + NBUF - 1) % NBUF];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[j] = ld_piece<NTL>(prod.rows, lane_off + (uint32_t)j * 1024u, (uint32_t)pch * 4096u);
+                    if constexpr (pch == NCHT - 1) {
+                        if (prod.gb < p.total_blocks) enter_block(prod, prod.gb + total_waves);
+                    }
+                }
+                {   // consume
+                    const float4(&b)[4] = buf[s % NBUF];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const i32x4 a = __builtin_bit_cast(i32x4, b[ks]);
+                        const int pc = 2 * (ch * 4 + ks) + h;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+#if PCV_EXP == 1  // timing experiment (wrong results): no LDS reads in the loop
+                            const i32x4 q8 = qfix[t];
+#else
+                            const i32x4 q8 = *(const i32x4*)&lq8[(size_t)(32 * t + c) * LDQ + pc];
+#endif
+#if PCV_EXP == 2  // timing experiment: half the multiplies
+                            if (t == 0) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
+                            else asm volatile("" ::"v"(q8));
+#else
+                            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
+#endif
+#if PCV_EXP == 5  // timing experiment (results unchanged): half as many LDS reads again
+                            if (t == 0) {
+                                const i32x4 extra = *(const volatile i32x4*)&lq8[(size_t)(32 + c) * LDQ + (pc ^ 1)];
+                                asm volatile("" ::"v"(extra));
+                            }
+#endif
+#if PCV_EXP == 6  // timing experiment (results unchanged): half as many multiplies again
+                            if (t == 0) dummy = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, dummy, 0, 0, 0);
+#endif
+                        }
+                    }
+                    if constexpr (ch == NCHT - 1) {
+                        epilogue(cons.sc, cons.lb);
+                        enter_block(cons, cons.gb + total_waves);
+                        if (cons.gb >= p.total_blocks) return true;
+                    }
+                }
+                return false;
+        };
+        while (true) {
+            if (static_for_until<0, PERIOD>(step)) {
+#if PCV_EXP == 6
+                asm volatile("" ::"v"(dummy));
+#endif
+                PCV_WAVE_DONE()
+            }
+        }
+    }
 #define PCV_STEP(REFILL, CONS)                          \
     if (NCH >= 2 && cons.ch == NCH - 2) prefetch();     \
     produce(buf[REFILL]);                               \
     consume(buf[CONS]);                                 \
-    if (cons.gb >= p.total_blocks) return;
+    if (cons.gb >= p.total_blocks) PCV_WAVE_DONE()
     produce(buf[0]);
     if constexpr (NBUF == 3) {
         produce(buf[1]);
@@ -1541,6 +2070,7 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         }
     }
 #undef PCV_STEP
+#undef PCV_WAVE_DONE
 }
 
 // 65..256 queries over rows of at most 384 features: the 128-query tile above needs 232 registers (64 accumulators, four
@@ -1974,6 +2504,7 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
         st_relaxed(&p.cand_cnt[q * kHot + 33], 0u);
         if ((raw_cnt > p.cand_cap || failed) && p.flag_rec) p.flag_rec->pos = 1;
         st_relaxed(&p.tau[q * kHot], kKeyNegInf);
+        st_relaxed(&p.tau_c[q], kKeyNegInf);
         st_relaxed(&p.cand_cnt[q * kHot], 0u);
     }
     for (int j = tid; j < p.k; j += 256) st_relaxed(&p.slots[(size_t)q * kMaxK + j], kKeyNegInf);
@@ -2256,10 +2787,23 @@ int mfma8_pass_queries(int Dp) {
 
 // 64 queries: three chunk buffers (150 registers).  Since the row loads go through a buffer descriptor a fourth fits without
 // spilling (166 registers) and changes nothing: 6.259 against 6.251 ms at 100M x 384, 0.933 / 0.943 at 12.5M, 5.999 / 5.989 at 768-d.
-template <int NT, bool NTL, int WPB = 4, int NBUF = (NT == 2 ? 3 : 4)>
+template <int NT, bool NTL, int WPB = 4, int NBUF = (NT == 2 ? 3 : 4), bool DRAIN = false, int NCHT = 0>
 static void launch_mfma8_variant(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds) {
-    allow_dynamic_lds((const void*)scan_mfma8_kernel<NT, NTL, WPB, NBUF>, lds);
-    scan_mfma8_kernel<NT, NTL, WPB, NBUF><<<grid, WPB * 64, lds, st>>>(dp);
+    allow_dynamic_lds((const void*)scan_mfma8_kernel<NT, NTL, WPB, NBUF, DRAIN, NCHT>, lds);
+    scan_mfma8_kernel<NT, NTL, WPB, NBUF, DRAIN, NCHT><<<grid, WPB * 64, lds, st>>>(dp);
+}
+// the DRAIN form, chunk count (dimension / 128, rounded up) as a template argument
+template <int NT, bool NTL, int NBUF>
+static void launch_mfma8_drain(hipStream_t st, const ScanParams* dp, unsigned grid, size_t lds, int nch) {
+    switch (nch) {
+        case 1: launch_mfma8_variant<NT, NTL, 12, NBUF, true, 1>(st, dp, grid, lds); break;
+        case 2: launch_mfma8_variant<NT, NTL, 12, NBUF, true, 2>(st, dp, grid, lds); break;
+        case 3: launch_mfma8_variant<NT, NTL, 12, NBUF, true, 3>(st, dp, grid, lds); break;
+        case 4: launch_mfma8_variant<NT, NTL, 12, NBUF, true, 4>(st, dp, grid, lds); break;
+        case 6: launch_mfma8_variant<NT, NTL, 12, NBUF, true, 6>(st, dp, grid, lds); break;
+        case 8: launch_mfma8_variant<NT, NTL, 12, NBUF, true, 8>(st, dp, grid, lds); break;
+        default: launch_mfma8_variant<NT, NTL, 12, NBUF, true, 0>(st, dp, grid, lds); break;  // (640-d, 896-d: the run-time form)
+    }
 }
 
 void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus) {
@@ -2303,6 +2847,27 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
         return;
     }
     if (NT == 8) PCV_FAIL(PCV_ERR_UNSUPPORTED, "int8 screen: %d queries in one pass need rows of at most 384 features", p.B);
+    // Up to 64 queries: ONE 12-wave workgroup per CU, eleven waves stream and the twelfth works off their coarse survivors
+    // (the survivor ring above).  Flag bit 28: the older form, three 4-wave workgroups per CU, every wave handling its own.
+    if (NT <= 2 && !(p.flags & (1u << 28)) && p.nseg < (1 << kRingSegBits) && lds + 68 * 1024 <= 156 * 1024) {
+        constexpr unsigned kW = 12;
+        unsigned g12 = (unsigned)num_cus * (gm ? gm : 1u);
+        g12 = std::min(g12, (p.total_blocks + (kW - 2)) / (kW - 1));
+        if (NT == 1) {
+            if (ntl) launch_mfma8_drain<1, true, 4>(st, dp, g12, lds, nch);
+            else launch_mfma8_drain<1, false, 4>(st, dp, g12, lds, nch);
+        } else {
+            if ((p.flags >> 24 & 0xf) == 3) {
+                if (ntl) launch_mfma8_drain<2, true, 3>(st, dp, g12, lds, nch);
+                else launch_mfma8_drain<2, false, 3>(st, dp, g12, lds, nch);
+            } else {
+                if (ntl) launch_mfma8_drain<2, true, 4>(st, dp, g12, lds, nch);
+                else launch_mfma8_drain<2, false, 4>(st, dp, g12, lds, nch);
+            }
+        }
+        PCV_LAUNCHED();
+        return;
+    }
     if (NT == 1) {
         if (ntl) launch_mfma8_variant<1, true>(st, dp, grid, lds);
         else launch_mfma8_variant<1, false>(st, dp, grid, lds);

@@ -584,7 +584,7 @@ void ensure_workspace(pcv_searcher* s) {
     s->d_spec.ensure(Q);
     s->d_margin.ensure(Q);
     s->d_margin32.ensure(Q);
-    s->d_tau.ensure(Q * kHot);
+    s->d_tau.ensure((Q + 1) * kHot);  // (+ the side-by-side copy of the thresholds: ScanParams::tau_c)
     s->d_slots.ensure(Q * kMaxK);
     s->d_cnt.ensure(Q * kHot);
     s->d_cand.ensure(Q * s->cand_cap);
@@ -682,6 +682,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.margin = s->d_margin.p;
     p.margin32 = s->d_margin32.p;
     p.tau = s->d_tau.p;
+    p.tau_c = s->d_tau.p + (size_t)kMfmaQueries * kHot;
     p.slots = s->d_slots.p;
     p.cand_cnt = s->d_cnt.p;
     p.cand = s->d_cand.p;
