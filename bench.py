@@ -564,8 +564,14 @@ def main():
                 extra["config2_10m_b1"] = scan_leg(pa, ctx, max(100_000, args.rows // 10), 1, k, "auto", es, ew, leg="config2_10m_b1")
             if want("shard_12p5m_b64"):
                 extra["shard_12p5m_b64"] = scan_leg(pa, ctx, max(100_000, args.rows // 8), 64, k, "auto", es, ew, leg="shard_12p5m_b64")
+            if want("shard_12p5m_b256"):  # one rank's scan of configs[4]: its 12.5M-row shard against all 256 embeddings in one pass
+                extra["shard_12p5m_b256"] = scan_leg(pa, ctx, max(100_000, args.rows // 8), 256, k, "auto", max(3, es // 2), ew, leg="shard_12p5m_b256")
             if want("encoder_256x256"):
                 extra["encoder_256x256"] = encoder_leg(pa, ctx, "f32")
+            if want("encoder_32x256"):  # one rank's share of configs[4]'s 256 documents (data-parallel encode)
+                extra["encoder_32x256"] = encoder_leg(pa, ctx, "f32", batch=32, seq=256, steps=10, warmup=3)
+            if want("encoder_64x256"):  # all-MiniLM-L6-v2 at the batch the reference's pipeline forms (sources/pipeline.rs:76)
+                extra["encoder_64x256"] = encoder_leg(pa, ctx, "f32", batch=64, seq=256, steps=10, warmup=3)
             if want("encoder_256x256_split_precision"):
                 extra["encoder_256x256_split_precision"] = [encoder_leg(pa, ctx, "bf16x3"), encoder_leg(pa, ctx, "f16x2")]
             if want("encoder_bertbase_64x256"):

@@ -98,7 +98,10 @@ struct ScanParams {
     float* margin32;         // [B]  fine screen:   rows with s32 < tau - margin32 are dropped     (2 * eps32)
     uint32_t* tau;           // [B*kHot]  ordered key of the running k-th best f32 score (word q*kHot)
     uint32_t* tau_c;         // [256]     the same keys side by side (raised right after tau, so never above it): one load instead of a
-                             //           64-line gather for a wave that wants all thresholds of the pass (the DRAIN form of scan_mfma8_kernel)
+                             //           64-line gather for a wave that wants all thresholds of the pass — for FEW readers (the one drain
+                             //           wave per CU of scan_mfma8_kernel's DRAIN form, about once a microsecond).  Read by every wave at
+                             //           every block these 256 bytes are one hot spot in one memory channel: the 4-waves-a-workgroup form
+                             //           went from 0.94 to 1.04 ms at 12.5M rows with it, which is what the 1 KB spacing of `tau` is for
     uint32_t* slots;         // [B][kMaxK] ordered keys of k distinct rows' f32 scores
     uint32_t* cand_cnt;      // [B*kHot]  survivors emitted per query (word q*kHot); word q*kHot + 32: rows that passed the COARSE screen
                              //           (statistics only: pcv_scan_stats.coarse_survivors)

@@ -1580,9 +1580,27 @@ __device__ __forceinline__ void drain_survivors(const ScanParams& p, SurvRing& r
         PCV_DCOUNT(5, __builtin_amdgcn_s_memrealtime() - ts)
         PCV_DCOUNT(6, 1)
     };
+    // U of this lane's query from the threshold as it stands, for this wave's repeat of the coarse test and — through lU — for
+    // the streaming waves' tests.  The thresholds are fetched before every round of work and every eighth idle poll (~1 us),
+    // from their side-by-side copy: one 256-byte load, used at the NEXT call (nobody waits for it here).  (Every streaming
+    // wave used to fetch them for every block, a 64-line gather each — agent-scope loads that go past the L2 to the memory
+    // side: 2816 waves x 64 requests per ~6 us beside the row stream.  That, not the survivors' round trips, was what set a
+    // 64-query pass apart from a one-query pass: 0.94 -> 0.78 ms at 12.5M rows.)
+    float myU = __builtin_inff(), myT = -__builtin_inff();
+    auto refresh = [&](bool fetch) {
+        const uint32_t tau_now = my_tau;
+        if (fetch) my_tau = ld_relaxed(&p.tau_c[ql]);
+        const float T = (key_f32(max(my_tau0, tau_now)) - my_e32) * my_sq;
+        myU = ql < p.B ? (my_sq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
+        myT = ql < p.B && my_sq != 0.0f ? T : -__builtin_inff();
+        if (lane < NQ) __hip_atomic_store(&lU[lane], myU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     // the entries of the lanes in `set` (one per lane: ehi, elo), eight at a time
     auto work_set = [&](unsigned long long set, uint32_t ehi, uint32_t elo) {
+        bool first = true;
         while (set) {
+            if (!first) refresh(true);  // (a round takes microseconds: the streaming waves get the thresholds it raised)
+            first = false;
             int src = -1;
 #pragma unroll
             for (uint32_t j = 0; j < 8; ++j) {
@@ -1598,17 +1616,7 @@ __device__ __forceinline__ void drain_survivors(const ScanParams& p, SurvRing& r
     };
 
     for (;;) {
-        // U of this lane's query from the threshold as it stands, for this wave's repeat of the coarse test and — through lU —
-        // for the streaming waves' tests.  The thresholds are fetched after every round of work and every eighth idle poll
-        // (~1 us), from their side-by-side copy: one 256-byte load.  (Every streaming wave used to fetch them for every
-        // block, a 64-line gather each — agent-scope loads that go past the L2 to the memory side: 2816 waves x 64 requests
-        // per ~6 us beside the row stream.)
-        const uint32_t tau_now = my_tau;
-        if ((idle & 7u) == 0) my_tau = ld_relaxed(&p.tau_c[ql]);  // (for the next round: nobody waits for it here)
-        const float T = (key_f32(max(my_tau0, tau_now)) - my_e32) * my_sq;
-        const float myU = ql < p.B ? (my_sq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
-        const float myT = ql < p.B && my_sq != 0.0f ? T : -__builtin_inff();
-        if (lane < NQ) __hip_atomic_store(&lU[lane], myU, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        refresh((idle & 7u) == 0);
 
         uint32_t tail = lds_ld(&ring.tail);
         bool over = false;
