@@ -214,7 +214,11 @@ pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode);
 enum { PCV_MID_COPY_OFF = 0, PCV_MID_COPY_AUTO = 1, PCV_MID_COPY_ON = 2 };
 pcv_status pcv_searcher_set_mid_copy(pcv_searcher* s, int mode);
 
-/* Most hits one search call ranks per query (num_results of search.rs:160; the reference's callers ask for 10 and 20). */
+/* Most hits ONE PASS over the rows ranks per query.  pcv_searcher_search takes any num_results (search.rs:157-182 has no limit;
+ * the reference's callers ask for 10 and 20, perceive-cli's --num-results is user input): beyond this many it goes over the rows
+ * again for the next PCV_MAX_RESULTS below the last hit of the pass before, and so on — every pass exact, results as from one
+ * ranking.  The entry points that exchange fixed-size hit lists (pcv_searcher_search_device*, pcv_searcher_search_sharded,
+ * pcv_merge_topk*) take at most this many. */
 enum { PCV_MAX_RESULTS = 128 };
 
 /* Searcher::search_vector (search.rs:157-182), batched over `n_queries` query vectors.

@@ -545,6 +545,140 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
     }
 }
 
+// The same fusion for FEW tokens (round 4): 8 192 tokens — one rank's share of BASELINE configs[4]'s 256 documents — are 128
+// tiles of 64 rows: half the chip ran one eight-wave workgroup per CU and the other half nothing (gemm_f32_ln8_kernel: 119 us per
+// call on average, 0.32 of the f32-MFMA peak; profiles/r04_encoder_32x256_before_kernel_stats.csv).  Here a workgroup owns 32
+// whole rows (256 tiles: every CU has one) and its eight waves split each 64-wide K step in two halves x four column quarters
+// (32 x N/4 per wave and K half), so a CU still runs two waves per SIMD and the K loop has half as many barrier-separated steps.
+// The two K halves meet in LDS in the epilogue (two row-major 32 x N tiles in the staging buffers), which adds them with bias
+// and residual.  Same v_mfma_f32_32x32x2_f32 arithmetic; the sum over K is formed as two partial sums.
+// ------------------------------------------------------------------------------------------------
+constexpr int L32M = 32, L32K = 64, L32T = L32K + 4;
+template <int CT>
+__global__ __launch_bounds__(512, 2) void gemm_f32_ln32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, const float* __restrict__ resid,
+                                                               const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                               float eps, float* __restrict__ C, int M, int K) {
+    constexpr int N = CT * 128;
+    constexpr int LDR = N + 4;
+    constexpr int Q = N / 64;       // float4 per lane and row in the epilogue (16 lanes per row)
+    constexpr int WU = N / 32;      // float4 of W per thread and K step: N rows x 16 float4 over 512 threads
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    float* As = lsm;                // [32][L32T]
+    float* Ws = lsm + L32M * L32T;  // [N][L32T]
+    static_assert(2 * 32 * LDR <= (L32M + N) * L32T, "the epilogue's two partial tiles fit the staging buffers");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int kh = wave & 1, wc = wave >> 1;
+    const int srow = tid >> 4, c4 = tid & 15;  // staging: float4 (row srow [+ 32u], 16-byte column c4 of the 64-wide step)
+    const int erow = tid >> 4, ej = tid & 15;  // epilogue: 16 lanes per row, float4 columns ej + 16t
+    const int tiles = (M + L32M - 1) / L32M;
+    const int nk = K / L32K;
+    int tile = blockIdx.x;
+    if (tile >= tiles) return;
+
+    const float* wg = W + (size_t)srow * K + c4 * 4;
+    const float* ag = A + (size_t)min(tile * L32M + srow, M - 1) * K + c4 * 4;
+    f32x4 ra = *(const f32x4*)ag, rw[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) rw[u] = *(const f32x4*)(wg + (size_t)32 * u * K);
+    const float* ap0 = &As[i * L32T + 32 * kh + 16 * kk];
+    const float* bp0 = &Ws[(wc * CT * 32 + i) * L32T + 32 * kh + 16 * kk];
+    float* tile_lds = lsm;
+
+    for (; tile < tiles; tile += gridDim.x) {
+        const int m0 = tile * L32M;
+        f32x16 acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+        auto to_lds = [&]() {
+            __syncthreads();  // the previous step's fragment reads / the previous tile's row reads are done
+            *(f32x4*)&As[srow * L32T + c4 * 4] = ra;
+#pragma unroll
+            for (int u = 0; u < WU; ++u) *(f32x4*)&Ws[(srow + 32 * u) * L32T + c4 * 4] = rw[u];
+            __syncthreads();
+        };
+        auto mfma_step = [&]() {
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {  // four k per lane half at a time
+                const f32x4 x = *(const f32x4*)(ap0 + 4 * hh);
+                f32x4 y[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) y[c] = *(const f32x4*)(bp0 + c * 32 * L32T + 4 * hh);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s], y[c][s], acc[c], 0, 0, 0);
+            }
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            to_lds();
+            const size_t koff = (size_t)(kt + 1) * L32K;  // the next step's operands fly under this step's MFMAs
+            ra = *(const f32x4*)(ag + koff);
+#pragma unroll
+            for (int u = 0; u < WU; ++u) rw[u] = *(const f32x4*)(wg + (size_t)32 * u * K + koff);
+            mfma_step();
+        }
+        to_lds();
+        f32x4 rv[Q];  // under the last step: the residual rows of the epilogue
+        {
+            const float* rrow = resid + (size_t)min(m0 + erow, M - 1) * N;
+#pragma unroll
+            for (int t = 0; t < Q; ++t) rv[t] = *(const f32x4*)(rrow + 4 * (ej + 16 * t));
+        }
+        mfma_step();
+
+        // epilogue: both K halves row-major into LDS, then 16 lanes per row add them up with bias and residual
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile_lds[(kh * 32 + acc_row(r, kk)) * LDR + (wc * CT + c) * 32 + i] = acc[c][r];
+        __syncthreads();
+        const int row = m0 + erow;
+        f32x4 v[Q];
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < Q; ++t) {
+            const int col = 4 * (ej + 16 * t);
+            v[t] = (*(const f32x4*)(tile_lds + erow * LDR + col) + *(const f32x4*)(tile_lds + (32 + erow) * LDR + col)) +
+                   *(const f32x4*)(bias + col) + rv[t];
+            sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+        }
+        // the next tile's first operands fly under the reductions and the stores
+        ag = A + (size_t)min(min(tile + (int)gridDim.x, tiles - 1) * L32M + srow, M - 1) * K + c4 * 4;
+        ra = *(const f32x4*)ag;
+#pragma unroll
+        for (int u = 0; u < WU; ++u) rw[u] = *(const f32x4*)(wg + (size_t)32 * u * K);
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 8);
+        const float mean = sum / (float)N;
+        float sq = 0.0f;
+#pragma unroll
+        for (int t = 0; t < Q; ++t) {
+            const f32x4 d = v[t] - mean;
+            sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+        sq += __shfl_xor(sq, 1);
+        sq += __shfl_xor(sq, 2);
+        sq += __shfl_xor(sq, 4);
+        sq += __shfl_xor(sq, 8);
+        const float rstd = 1.0f / sqrtf(sq / (float)N + eps);
+        if (row < M) {
+#pragma unroll
+            for (int t = 0; t < Q; ++t) {
+                const int col = 4 * (ej + 16 * t);
+                *(f32x4*)(C + (size_t)row * N + col) = (v[t] - mean) * rstd * *(const f32x4*)(ln_w + col) + *(const f32x4*)(ln_b + col);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Skinny GEMM for M <= 128 (a single query, a few highlight chunks): the 128x128 tiling would run
 // N/128 workgroups through K/32 barrier-separated steps each (30-115 us per layer GEMM, launch- and
@@ -1759,28 +1893,35 @@ __global__ __launch_bounds__(NW * 64, HD == 32 ? 4 : 2) void attention_persist_k
 // ------------------------------------------------------------------------------------------------
 // pooling + normalisation (worker.rs:88-103), one workgroup per sequence
 // ------------------------------------------------------------------------------------------------
+template <int NWV = 4>
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    const float r = red[0] + red[1] + red[2] + red[3];
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) r += red[w];
     __syncthreads();
     return r;
 }
 
-__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hidden, const float* __restrict__ mask01,
-                                                   int L, int H, int mode, int normalize, float* __restrict__ out) {
-    // The four waves split the tokens (wave w: l = w, w + 4, ...), every lane owning H/64 columns, and meet in
-    // LDS; one column per thread walking all L tokens left three quarters of the loads un-issued (124 us for
-    // 256 documents of 256 tokens).
-    __shared__ float red[4];
-    __shared__ float part[4][1024];  // H <= 1024
+// NWV waves, TG tokens requested together per wave, MPL columns per lane (H <= 64 * MPL)
+template <int NWV, int TG, int MPL>
+__global__ __launch_bounds__(NWV * 64) void pool_kernel(const float* __restrict__ hidden, const float* __restrict__ mask01,
+                                                        int L, int H, int mode, int normalize, float* __restrict__ out) {
+    // The waves split the tokens (wave w: l = w, w + NWV, ...), every lane owning H/64 columns, and meet in LDS.  The
+    // walk over the tokens is a chain of memory round trips: what counts is how many tokens a workgroup has in flight
+    // (one column per thread walking all L tokens: 124 us for 256 documents of 256 tokens; four waves x four tokens:
+    // 46 us whatever the batch — a fortieth of a 32 x 256 forward; eight waves x eight tokens at MiniLM's width: ~10 us).
+    constexpr int kMaxPerLane = MPL;
+    __shared__ float red[NWV];
+    __shared__ float part[NWV][64 * MPL];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* hb = hidden + (size_t)b * L * H;
     const float* mb = mask01 + (size_t)b * L;
     float msum = 0.0f;
-    for (int l = tid; l < L; l += 256) msum += mb[l];
-    msum = block_sum(msum, red);
+    for (int l = tid; l < L; l += NWV * 64) msum += mb[l];
+    msum = block_sum<NWV>(msum, red);
     const float den = fmaxf(msum, 1e-9f);  // clamp_min(1e-9) of rust-bert's mean pooling
     const int npl = (H + 63) / 64;
     if (mode != PCV_POOL_CLS) {
@@ -1789,12 +1930,11 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hid
         for (int j = 0; j < kMaxPerLane; ++j) acc[j] = mode == PCV_POOL_MAX ? -__builtin_inff() : 0.0f;
         // four tokens' loads are requested together (one token per iteration ran at one memory round trip per
         // token: 124 us for 256 documents of 256 tokens); accumulation order unchanged
-        constexpr int TG = 4;
-        for (int l0 = wave; l0 < L; l0 += 4 * TG) {
+        for (int l0 = wave; l0 < L; l0 += NWV * TG) {
             float m[TG], x[TG][kMaxPerLane];
 #pragma unroll
             for (int g = 0; g < TG; ++g) {
-                const int l = l0 + 4 * g;
+                const int l = l0 + NWV * g;
                 const bool live = l < L;
                 m[g] = live ? mb[l] : 0.0f;
                 const float* row = hb + (size_t)(live ? l : 0) * H;
@@ -1806,7 +1946,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hid
             }
 #pragma unroll
             for (int g = 0; g < TG; ++g) {
-                if (l0 + 4 * g >= L) break;
+                if (l0 + NWV * g >= L) break;
 #pragma unroll
                 for (int j = 0; j < kMaxPerLane; ++j) {
                     const int c = lane + 64 * j;
@@ -1822,18 +1962,24 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hid
         }
         __syncthreads();
     }
-    float vals[4];
+    constexpr int VPT = (MPL + NWV - 1) / NWV;  // output columns per thread
+    float vals[VPT];
     float ss = 0.0f;
-    for (int j = 0; j < 4; ++j) {
-        const int c = tid + 256 * j;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int c = tid + NWV * 64 * j;
         float v = 0.0f;
         if (c < H) {
             if (mode == PCV_POOL_CLS) {
                 v = hb[c];
             } else if (mode == PCV_POOL_MAX) {
-                v = fmaxf(fmaxf(part[0][c], part[1][c]), fmaxf(part[2][c], part[3][c]));
+                v = part[0][c];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) v = fmaxf(v, part[w][c]);
             } else {
-                const float s = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+                float s = part[0][c];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) s += part[w][c];
                 v = mode == PCV_POOL_MEAN_SQRT_LEN ? s / sqrtf(den) : s / den;
             }
         }
@@ -1842,11 +1988,12 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ hid
     }
     float inv = 1.0f;
     if (normalize) {  // x / clamp_min(||x||, 1e-12), worker.rs:95-103
-        const float nrm = sqrtf(block_sum(ss, red));
+        const float nrm = sqrtf(block_sum<NWV>(ss, red));
         inv = 1.0f / fmaxf(nrm, 1e-12f);
     }
-    for (int j = 0; j < 4; ++j) {
-        const int c = tid + 256 * j;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int c = tid + NWV * 64 * j;
         if (c < H) out[(size_t)b * H + c] = normalize ? vals[j] * inv : vals[j];
     }
 }
@@ -1916,6 +2063,16 @@ bool launch_gemm_f32_ln(hipStream_t st, const float* A, const float* W, const fl
     if (M <= 128 || (N != 128 && N != 256 && N != 384) || K % BK != 0 || bias == nullptr || resid == nullptr) return false;
     const size_t lds = (size_t)(LBM + N) * LDT * sizeof(float);
     const dim3 grid((M + LBM - 1) / LBM);
+    static const bool no32 = getenv("PCV_NO_LN32") != nullptr;  // (comparison switch)
+    static const int max32 = getenv("PCV_LN32_MAX_M") ? atoi(getenv("PCV_LN32_MAX_M")) : -1;  // (tuning)
+    if (N == 384 && K % L32K == 0 && (max32 >= 0 ? M <= max32 : M < 64 * current_device_cus()) && !no32) {
+        // fewer 64-row tiles than CUs: 32-row tiles, eight waves that split K (gemm_f32_ln32_kernel)
+        const size_t lds32 = (size_t)(L32M + N) * L32T * sizeof(float);
+        allow_dynamic_lds((const void*)gemm_f32_ln32_kernel<3>, lds32);  // 113 KB of dynamic LDS: one workgroup per CU
+        const int tiles = (M + L32M - 1) / L32M;
+        gemm_f32_ln32_kernel<3><<<dim3(std::min<int>(tiles, current_device_cus())), 512, lds32, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
+        return true;
+    }
     if (N == 384) {  // persistent eight-wave form: 1 % of a 256 x 256 forward over the four-wave one
         allow_dynamic_lds((const void*)gemm_f32_ln8_kernel<3>, lds);  // 64.5 KB of dynamic LDS
         const int resident = 2 * 256;  // two workgroups per CU
@@ -2129,7 +2286,10 @@ void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, f
 
 void launch_pool(hipStream_t st, const float* hidden, const float* mask01, int B, int L, int H, int mode,
                  int normalize, float* out) {
-    pool_kernel<<<B, 256, 0, st>>>(hidden, mask01, L, H, mode, normalize, out);
+    if (H <= 512)
+        pool_kernel<8, 8, 8><<<B, 512, 0, st>>>(hidden, mask01, L, H, mode, normalize, out);
+    else
+        pool_kernel<8, 4, 16><<<B, 512, 0, st>>>(hidden, mask01, L, H, mode, normalize, out);
 }
 
 void launch_dense(hipStream_t st, const float* x, const float* W, const float* b, int B, int in, int out, int act,

@@ -75,6 +75,22 @@ struct pcv_hit_dev {
     int64_t id;
 };
 
+// More results than a pass ranks (num_results > kMaxK): pcv_searcher_search goes over the rows again for the next kMaxK, and
+// again, each pass counting only the rows that rank strictly AFTER the last hit of the pass before it — the pass's ceiling, one
+// per query (the reference has no limit on num_results: search.rs:157-182; perceive-cli's --num-results is user input).
+//   score, pos : the canonical score and position of that hit; +inf / -1: no ceiling for this query; -inf / INT64_MAX: nothing
+//                ranks after it (the query has all the rows there are)
+//   lo, hi     : the same boundary in units of the f32 screening score, one fine margin below and above it.  A row with
+//                screening score s < lo certainly ranks after the boundary: it counts and may raise the running thresholds;
+//                lo <= s <= hi: it counts (the exact ranking decides) but must not raise them; s > hi: it ranks at or before
+//                the boundary and is not listed.  The thresholds thus rest on k rows that count, and the argument for the
+//                screens (scan_kernels.hip) holds among the rows that count.
+struct CeilRec {
+    double score;
+    int64_t pos;
+    float lo, hi;
+};
+
 // Everything one pass needs, resident in device memory (uploaded with the segment table and the
 // queries in ONE copy): the kernels index p.seg[] at run time, which a by-value kernel argument would
 // force through scratch memory.
@@ -88,6 +104,7 @@ struct ScanParams {
     int k;
     int metric;
     uint32_t tile_rows;      // rows of the bf16 query tile the scan kernel stages (rows >= B are zeroed)
+    const CeilRec* ceil;     // [B] the pass's ceilings, or nullptr (the first kMaxK results: every row counts)
     const float* queries;    // [B][D]    raw queries as the caller passed them
     float* qf32;             // [B][Dp]   scan-side query (normalised for cosine), zero padded
     uint16_t* qbf16;         // [128][Dp] same, rounded to bf16

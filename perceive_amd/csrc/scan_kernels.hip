@@ -207,10 +207,21 @@ __device__ __forceinline__ void offer_slot_wave(const ScanParams& p, int q, floa
     }
 }
 
+// Where a row with screening score s stands to the pass's ceiling for query q (scan.h, CeilRec): 0 = it counts and may raise
+// the thresholds, 1 = it counts but must not raise them, 2 = it does not count.  No ceiling: 0.
+__device__ __forceinline__ int ceil_class(const ScanParams& p, int q, float s) {
+    if (!p.ceil) return 0;
+    const float lo = gld(&p.ceil[q].lo), hi = gld(&p.ceil[q].hi);
+    return s < lo ? 0 : (s > hi ? 2 : 1);
+}
+
 // A surviving (query,row) pair of the wave kernel: append to the query's candidate list and, unless the
 // row was already ranked by the seed kernel, try to raise the running k-th best.
 __device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint32_t row, float s,
                                       bool feeds_slots) {
+    const int cc = ceil_class(p, q, s);
+    if (cc == 2) return;
+    feeds_slots = feeds_slots && cc == 0;
     uint32_t idx = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
     if (idx < p.cand_cap) {
         gst(&p.cand[(size_t)q * p.cand_cap + idx], ((uint64_t)(uint32_t)seg << 32) | row);
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(256) void prep_seed_kernel(const ScanParams* __rest
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
             const float s = acc[g] * sc;
-            if (sc != 0.0f && isfinite(s)) atomicMax(&gmax[g * kMaxK + grp], f32_key(s));
+            if (sc != 0.0f && isfinite(s) && (q0 + g >= p.B || ceil_class(p, q0 + g, s) == 0)) atomicMax(&gmax[g * kMaxK + grp], f32_key(s));
         }
     }
     __syncthreads();
@@ -774,11 +785,12 @@ __global__ __launch_bounds__(256) void prep_seed_mfma_kernel(const ScanParams* _
             const uint32_t row = lb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
             sc[i] = row < nseed ? gld(&seg0_scale[row]) : 0.0f;
         }
+        const float clo = (p.ceil && q0 + r < p.B) ? gld(&p.ceil[q0 + r].lo) : __builtin_inff();  // (scan.h, CeilRec: only rows that count)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float s = acc[i] * sc[i];
             const uint32_t sr = sb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;  // position in the sample: its group (every group gets rows whatever the stride)
-            if (sc[i] != 0.0f && isfinite(s)) atomicMax(&gmax[r * p.k + sr % (uint32_t)p.k], f32_key(s));
+            if (sc[i] != 0.0f && isfinite(s) && s < clo) atomicMax(&gmax[r * p.k + sr % (uint32_t)p.k], f32_key(s));
         }
     }
     __syncthreads();
@@ -1010,6 +1022,8 @@ __device__ __forceinline__ void fine_survivors(const ScanParams& p, uint32_t mas
             const float s32 = dot * sc;
             const float taun = key_f32(max(ltau0[q], tkey));
             if (s32 < taun - m32) continue;
+            const int cc = ceil_class(p, q, s32);
+            if (cc == 2) continue;
             if (lane == 0) {
                 const uint32_t at = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
                 if (at < p.cand_cap) {
@@ -1017,7 +1031,7 @@ __device__ __forceinline__ void fine_survivors(const ScanParams& p, uint32_t mas
                     gst(&p.cand_s[(size_t)q * p.cand_cap + at], s32);
                 }
             }
-            if (feeds && isfinite(s32) && s32 > taun) offer_slot_wave(p, q, s32, lane);
+            if (feeds && cc == 0 && isfinite(s32) && s32 > taun) offer_slot_wave(p, q, s32, lane);
         }
     }
 }
@@ -1560,7 +1574,8 @@ __device__ __forceinline__ void drain_survivors(const ScanParams& p, SurvRing& r
         for (int off = 4; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
         const float s32 = dot * sc;
         const float taun = key_f32(max(ltau0[q], tkey));
-        const bool cand = go && !(s32 < taun - m32);
+        const int cc = on ? ceil_class(p, q, s32) : 2;
+        const bool cand = go && !(s32 < taun - m32) && cc != 2;
         if (cand && sub == 0) {
             const uint32_t at = g_atomic_add(&p.cand_cnt[q * kHot], 1u);
             if (at < p.cand_cap) {
@@ -1568,7 +1583,7 @@ __device__ __forceinline__ void drain_survivors(const ScanParams& p, SurvRing& r
                 gst(&p.cand_s[(size_t)q * p.cand_cap + at], s32);
             }
         }
-        const bool offer = cand && sub == 0 && !is_seed_block(p, si, lb) && isfinite(s32) && s32 > taun;
+        const bool offer = cand && cc == 0 && sub == 0 && !is_seed_block(p, si, lb) && isfinite(s32) && s32 > taun;
         unsigned long long ob = __ballot(offer);
         while (ob) {
             const int osrc = __builtin_ctzll(ob);
@@ -2353,9 +2368,13 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(const ScanParams* _
         }
         return __builtin_nan("");
     };
+    // the pass's ceiling for this query (scan.h, CeilRec): only rows that rank strictly after it count
+    const double ceil_s = p.ceil ? p.ceil[q].score : __builtin_inf();
+    const int64_t ceil_p = p.ceil ? p.ceil[q].pos : -1;
     auto keep = [&](uint64_t e, double score) {  // one survivor's canonical score
         if (!(score == score)) return;  // NaN: undefined score
         const int64_t pos = p.seg[(int)(e >> 32)].pos0 + (int64_t)(uint32_t)e;
+        if (!better(ceil_s, ceil_p, score, pos)) return;  // at or before the ceiling
         if (!better(score, pos, t_s, t_p)) return;  // k rows seen earlier are all ahead of it
         const uint32_t slot = atomicAdd(&n_valid, 1u);  // < kSelCap: the buffer had room for a whole slice
         c_s[slot] = score;

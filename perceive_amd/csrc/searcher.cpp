@@ -597,17 +597,20 @@ void ensure_workspace(pcv_searcher* s) {
 
 // offsets inside the pass block
 struct PassLayout {
-    size_t off_seg, off_q, total;
+    size_t off_seg, off_ceil, off_q, total;
 };
-PassLayout pass_layout(const pcv_searcher* s, size_t nseg) {
+// `with_ceil`: the pass has ceilings (scan.h, CeilRec: a search for more than kMaxK results) — their records sit between the
+// segment table and the queries, so that they travel with every attempt of the pass
+PassLayout pass_layout(const pcv_searcher* s, size_t nseg, bool with_ceil) {
     PassLayout L;
     L.off_seg = align_up(sizeof(ScanParams));
-    L.off_q = align_up(L.off_seg + nseg * sizeof(SegDesc));
+    L.off_ceil = align_up(L.off_seg + nseg * sizeof(SegDesc));
+    L.off_q = with_ceil ? align_up(L.off_ceil + (size_t)kMfmaQueries * sizeof(CeilRec)) : L.off_ceil;
     L.total = L.off_q + (size_t)kMfmaQueries * s->D * sizeof(float);
     return L;
 }
 void ensure_pass_block(pcv_searcher* s, size_t nseg) {
-    const size_t want = pass_layout(s, nseg).total;
+    const size_t want = pass_layout(s, nseg, true).total;
     if (want <= s->pass_cap) return;
     PCV_HIP(hipStreamSynchronize(s->ctx->stream));
     if (s->pin_pass) (void)hipHostFree(s->pin_pass);
@@ -626,14 +629,14 @@ void ensure_pass_block(pcv_searcher* s, size_t nseg) {
 // into pinned host memory as well; the survivor counts always come back that way.  `d_flag` != nullptr
 // receives the overflow record (scan.h).
 void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel,
-                  pcv_hit_dev* d_out, bool download, pcv_hit_dev* d_flag) {
+                  pcv_hit_dev* d_out, bool download, pcv_hit_dev* d_flag, const CeilRec* ceil_host = nullptr) {
     const auto t_begin = std::chrono::steady_clock::now();
     hipStream_t st = s->ctx->stream;
     ensure_workspace(s);
     ensure_pass_block(s, (size_t)nseg);
     if (!s->state_clean) launch_reset_scan_state(st, s->d_tau.p, s->d_slots.p, s->d_cnt.p);
     s->state_clean = false;  // until finish_pass has seen the pass through
-    const PassLayout L = pass_layout(s, (size_t)nseg);
+    const PassLayout L = pass_layout(s, (size_t)nseg, ceil_host != nullptr);
     ScanParams& p = *reinterpret_cast<ScanParams*>(s->pin_pass);
     SegDesc* tab = reinterpret_cast<SegDesc*>(s->pin_pass + L.off_seg);
     p = ScanParams{};
@@ -674,6 +677,10 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.metric = s->metric;
     p.tile_rows = kernel == PCV_KERNEL_MFMA ? mfma_tile_rows(B) : 0u;
     p.queries = reinterpret_cast<const float*>(s->d_pass + L.off_q);
+    if (ceil_host) {
+        std::memcpy(s->pin_pass + L.off_ceil, ceil_host, (size_t)B * sizeof(CeilRec));
+        p.ceil = reinterpret_cast<const CeilRec*>(s->d_pass + L.off_ceil);
+    }
     p.qf32 = s->d_qf32.p;
     p.qbf16 = s->d_qbf16.p;
     p.q8 = s->d_q8.p;
@@ -715,7 +722,8 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
         s->gap_nseg = nseg;
         s->gaps.reset();
     }
-    if (kernel == PCV_KERNEL_MFMA && !s->spec_hold && s->spec_rest == 0 && !(s->scan_flags & 32u) && k >= 2) {
+    // (no guess under a ceiling: the check at the end of the pass counts survivors, not survivors that count)
+    if (kernel == PCV_KERNEL_MFMA && !s->spec_hold && s->spec_rest == 0 && !(s->scan_flags & 32u) && k >= 2 && !ceil_host) {
         if (!(s->scan_flags & 128u)) p.spec_gap = s->gaps.gap();
         p.spec_spread = (float)s->gaps.spread;
         const double r = (double)std::min<int64_t>(tab[0].nrows, (int64_t)p.seed_blocks * kBlockRows) / (double)std::max<int64_t>(rows, 1);  // (seed rows) / rows
@@ -780,7 +788,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     shape.seg0_scale = tab[0].scale;
     // only where queueing is a visible share of the pass: up to kGraphRows rows (a longer pass is launched plainly and
     // timed kernel by kernel, which is what the roofline figures are taken from)
-    const bool small = rows <= kGraphRows && s->use_graph;
+    const bool small = rows <= kGraphRows && s->use_graph && !ceil_host;
     bool replayed = false;
     if (small && s->graph_exec && shape == s->graph_shape) {
         PCV_HIP(hipEventRecord(s->ev[0], st));
@@ -948,9 +956,9 @@ bool finish_pass(pcv_searcher* s) {
 
 // One pass, synchronously.  Leaves [B][k] hits in `d_out` (nullptr = s->d_hits) and, if `download`, in s->pin->hits.
 void run_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel,
-              pcv_hit_dev* d_out, bool download) {
+              pcv_hit_dev* d_out, bool download, const CeilRec* ceil_host = nullptr) {
     for (int attempt = 0;; ++attempt) {
-        enqueue_pass(s, attempt == 0 ? queries_host : nullptr, B, segs, nseg, k, kernel, d_out, download, nullptr);
+        enqueue_pass(s, attempt == 0 ? queries_host : nullptr, B, segs, nseg, k, kernel, d_out, download, nullptr, ceil_host);
         if (!finish_pass(s)) return;
         PCV_REQUIRE(attempt < 7, "candidate lists still overflow after %d reruns", attempt + 1);
     }
@@ -980,16 +988,41 @@ int pass_queries(const pcv_searcher* s, int kernel, bool among_ranks = false) {
     return mfma_pass_queries(s->Dp);
 }
 
-void check_search_args(const pcv_searcher* s, const float* queries, int n_queries, int k, const char* who) {
+void check_search_args(const pcv_searcher* s, const float* queries, int n_queries, int k, const char* who, int k_max = kMaxK) {
     PCV_REQUIRE(!s->dirty, "%s: rows were added or cleared without pcv_searcher_finalize", who);
     PCV_REQUIRE(queries != nullptr && n_queries > 0, "%s: no queries", who);
-    PCV_REQUIRE(k > 0 && k <= kMaxK, "%s: num_results %d outside [1,%d]", who, k, kMaxK);
+    PCV_REQUIRE(k > 0 && k <= k_max, "%s: num_results %d outside [1,%d]", who, k, k_max);
+}
+
+// The ceilings of the pass that follows one whose last hits are `last` (one per query; pos < 0: that pass came back short —
+// the query has all the rows there are): scan.h, CeilRec.  The band around the boundary is the fine screen's margin,
+// 2 eps32 relative to |q||x| (x <= the largest row norm for the dot metric; 1 for cosine), plus the rounding of the f64 score to f32.
+void next_ceilings(const pcv_searcher* s, const float* queries, int B, const pcv_hit_dev* last, CeilRec* out) {
+    const float eps32 = (float)(s->Dp + 16) * 1.2e-7f;
+    for (int q = 0; q < B; ++q) {
+        CeilRec& c = out[q];
+        if (last[q].pos < 0) {
+            c = CeilRec{-INFINITY, INT64_MAX, -INFINITY, -INFINITY};
+            continue;
+        }
+        double unit = 1.0;
+        if (s->metric == PCV_METRIC_DOT) {
+            double nq = 0.0;
+            for (int i = 0; i < s->D; ++i) nq += (double)queries[(size_t)q * s->D + i] * (double)queries[(size_t)q * s->D + i];
+            unit = std::sqrt(nq) * (double)s->max_norm;
+        }
+        const double band = 2.5 * (double)eps32 * unit + std::fabs(last[q].score) * 2.4e-7 + 1e-37;
+        c.score = last[q].score;
+        c.pos = last[q].pos;
+        c.lo = std::nextafterf((float)(last[q].score - band), -INFINITY);
+        c.hi = std::nextafterf((float)(last[q].score + band), INFINITY);
+    }
 }
 
 // Full search: any number of queries / segments; result [n_queries][k] hits on the host.
 void search_hits(pcv_searcher* s, const float* queries, int n_queries, const int64_t* source_ids, int n_sources,
                  int k, std::vector<pcv_hit_dev>& out) {
-    check_search_args(s, queries, n_queries, k, "search");
+    check_search_args(s, queries, n_queries, k, "search", 1 << 24);
     PCV_HIP(hipSetDevice(s->ctx->device));
     std::vector<SelSeg> segs = select_segments(s, source_ids, n_sources);
     const pcv_hit_dev none{NAN, -1, -1};
@@ -1000,10 +1033,29 @@ void search_hits(pcv_searcher* s, const float* queries, int n_queries, const int
     if (segs.empty()) return;
     const int qstep = pass_queries(s, kernel);
     maybe_build_mid_copies(s);
+    std::vector<CeilRec> ceil;
+    std::vector<pcv_hit_dev> last;
     for (int q0 = 0; q0 < n_queries; q0 += qstep) {
         const int B = std::min(qstep, n_queries - q0);
-        run_pass(s, queries + (size_t)q0 * s->D, B, segs.data(), (int)segs.size(), k, kernel, nullptr, true);
-        std::memcpy(out.data() + (size_t)q0 * k, s->pin->hits, (size_t)B * k * sizeof(pcv_hit_dev));  // came down with the pass
+        const float* qs = queries + (size_t)q0 * s->D;
+        // One pass ranks up to kMaxK results.  More (search.rs:157-182 has no limit): the next kMaxK below the last hit of the
+        // pass before, and so on — each pass exact among the rows that rank after its ceiling (the statistics add up over the passes).
+        for (int got = 0; got < k; got += kMaxK) {
+            const int kk = std::min(kMaxK, k - got);
+            if (got > 0) {
+                ceil.resize((size_t)B);
+                next_ceilings(s, qs, B, last.data(), ceil.data());
+            }
+            run_pass(s, qs, B, segs.data(), (int)segs.size(), kk, kernel, nullptr, true, got > 0 ? ceil.data() : nullptr);
+            last.resize((size_t)B);
+            bool more = false;
+            for (int q = 0; q < B; ++q) {  // (the hits came down with the pass)
+                std::memcpy(out.data() + (size_t)(q0 + q) * k + got, s->pin->hits + (size_t)q * kk, (size_t)kk * sizeof(pcv_hit_dev));
+                last[(size_t)q] = s->pin->hits[(size_t)q * kk + kk - 1];  // pos < 0: fewer than kk rows counted — nothing is left
+                more = more || last[(size_t)q].pos >= 0;
+            }
+            if (!more) break;
+        }
     }
 }
 

@@ -152,14 +152,8 @@ impl Searcher {
         let mut dim: i32 = 0;
         hip::check(unsafe { ffi::pcv_searcher_dim(self.handle, &mut dim) }).expect("searcher_dim failed");
         assert_eq!(vector.len(), dim as usize, "search_vector: the query has {} values, the index is {}-d", vector.len(), dim);
-        // One call returns at most PCV_MAX_RESULTS (128) hits.  The reference has no such limit; its callers ask for 10
-        // (perceive-tauri main.rs:48) or 20 (perceive-cli cmd/search.rs:35-36).  More is not truncated silently:
-        assert!(
-            num_results <= ffi::PCV_MAX_RESULTS as usize,
-            "search_vector: num_results {} is above the {} hits one exact scan pass ranks",
-            num_results,
-            ffi::PCV_MAX_RESULTS
-        );
+        // num_results is not limited (search.rs:157-182; perceive-cli's --num-results is user input): beyond the
+        // PCV_MAX_RESULTS (128) hits one pass over the rows ranks, the library goes over them again for the next 128.
         let k = num_results;
         let mut ids = vec![-1i64; k];
         let mut scores = vec![f32::NAN; k];

@@ -121,6 +121,36 @@ def test_minilm_shape_synthetic_weights(ctx, oracle):
     m.close()
 
 
+@pytest.mark.parametrize("shape", [(32, 256), (40, 200), (9, 100)])
+def test_minilm_shape_few_tokens_32_row_layernorm_tiles(ctx, oracle, shape):
+    # One rank's share of BASELINE configs[4] (32 documents x 256 tokens = 8 192 tokens) and other token counts below 64 x CUs:
+    # the projection + LayerNorm fusion runs on 32-row tiles whose eight waves split K (gemm_f32_ln32_kernel); (40, 200) ends
+    # in a partial tile, (9, 100) is a handful of tiles.  Sampled documents against the C oracle (padding invariance makes
+    # single-row oracle runs valid), and the whole batch against the 64-row form of the same fusion (PCV_NO_LN32 is read once
+    # per process, so the comparison model is the all-in-one-batch run of the documents one by one).
+    B, L = shape
+    m = pa.Model(ctx, synthetic_seed=7)
+    rng = np.random.default_rng(B * 1000 + L)
+    lens = rng.integers(max(8, L // 8), L + 1, B)
+    lens[0] = L
+    toks = [list(rng.integers(1000, 30000, int(n))) for n in lens]
+    ids, mask = m.generate_token_tensors(toks)
+    assert ids.shape == (B, L)
+    emb = m.encode_tokens(ids, mask)
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
+    desc = dict(vocab=30522, hidden=384, layers=6, heads=12, inter=1536, max_pos=512, eps=1e-12, pooling=0, normalize=1)
+    sd = m.state_dict()
+    for i in sorted({0, 1, B // 2, B - 1}):
+        ids1, mask1 = m.generate_token_tensors([toks[i]])
+        oout, ohid = oracle.encode_tokens(desc, sd, ids1, mask1, want_hidden=True)
+        assert np.abs(emb[i] - oout[0]).max() < TOL, i
+    # the last layer's hidden states of document 0 (full length): every token row of a tile, not only the pooled vector
+    ids1, mask1 = m.generate_token_tensors([toks[0]])
+    _, ohid = oracle.encode_tokens(desc, sd, ids1, mask1, want_hidden=True)
+    assert np.abs(m.debug_hidden(6, B, L)[0] - ohid[-1][0]).max() < 5e-4
+    m.close()
+
+
 def test_head_dim_64_and_long_sequence(ctx, oracle):
     # bert-base-like heads (64 wide) and L = 300 > one 128-key chunk: exercises the online softmax
     desc = dict(vocab=500, hidden=256, layers=1, heads=4, inter=512, max_pos=512, eps=1e-12, pooling=0, normalize=1)

@@ -89,6 +89,19 @@ def test_ties_zero_rows_and_k_larger_than_valid(ctx, oracle, g1000):
     assert (counts == 128).all() and 500 not in ids
     opos, _, _ = oracle.topk(g1000["queries"][:2], corpus, 128)
     np.testing.assert_array_equal(ids, opos)
+    # more results than one pass ranks (128): the library goes over the rows again below the last hit of the pass before
+    # (the reference has no limit on num_results, search.rs:157-182).  k = 1000 covers the whole 1000-row corpus: the zero
+    # row has no score and is not returned, 999 hits; the order is the oracle's, duplicates (equal scores) by position.
+    for kernel in ("wave", "mfma"):
+        s.set_kernel(kernel)
+        for k in (129, 300, 1000):
+            ids, scores, counts = s.search_vectors(None, k, g1000["queries"][:3])
+            opos, osc, ocnt = oracle.topk(g1000["queries"][:3], corpus, k)
+            np.testing.assert_array_equal(counts, ocnt)
+            np.testing.assert_array_equal(ids, opos)
+            live = opos >= 0
+            assert np.abs(scores[live] - osc.astype(np.float32)[live]).max() < 1e-6
+            assert counts[0] == min(k, 999) and 500 not in ids
     s.close()
     # fewer valid rows than k
     m = np.zeros((5, 8), np.float32)
@@ -102,6 +115,46 @@ def test_ties_zero_rows_and_k_larger_than_valid(ctx, oracle, g1000):
     # zero query: cosine undefined for every row -> nothing returned (reference: NaN then panic)
     ids, scores, counts = s.search_vectors(None, 2, np.zeros((1, 8), np.float32))
     assert counts[0] == 0
+    s.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("screen", ["int8", "bf16", "off"])
+def test_more_results_than_one_pass_ranks(ctx, oracle, metric, screen):
+    # num_results > PCV_MAX_RESULTS (128): passes below the previous pass's last hit (scan.h, CeilRec), every screen form, both
+    # metrics, two sources with rows of unequal norm, duplicated rows that straddle a pass boundary (equal scores: by position),
+    # and a query whose rows run out before num_results.
+    rng = np.random.default_rng(11)
+    N, D, k = 40_000, 96, 300
+    m = (rng.standard_normal((N, D)) * rng.uniform(0.5, 2.0, (N, 1))).astype(np.float32)
+    q = rng.standard_normal((5, D)).astype(np.float32)
+    # rows 1000..1009 are copies of the row that ranks 126th for query 0 under this metric: ranks 126..136 are one score
+    s0 = build(ctx, m, metric=metric, screen=screen)
+    first, _, _ = s0.search_vectors(None, 128, q[:1])
+    s0.close()
+    m[1000:1010] = m[first[0, 125]]
+    s = pa.Searcher(ctx, D, metric)
+    s.set_screening_copy(screen)
+    s.add_rows(1, m[:25_000], np.arange(25_000, dtype=np.int64))
+    s.add_rows(2, m[25_000:], np.arange(25_000, N, dtype=np.int64))
+    s.finalize()
+    om = {"cosine": 0, "dot": 1}[metric]
+    for kernel in ("auto", "wave"):
+        s.set_kernel(kernel)
+        ids, scores, counts = s.search_vectors(None, k, q)
+        opos, osc, ocnt = oracle.topk(q, m, k, metric=om)
+        np.testing.assert_array_equal(ids, opos)
+        assert (counts == k).all()
+        assert s.last_stats()["scan_launches"] >= 3  # 128 + 128 + 44
+    # one source only, and more results than it has rows
+    sub = m[25_000:25_000 + 200]
+    s2 = build(ctx, sub, metric=metric, screen=screen)
+    ids, scores, counts = s2.search_vectors(None, 260, q[:2])
+    opos, _, ocnt = oracle.topk(q[:2], sub, 260, metric=om)
+    np.testing.assert_array_equal(ids, opos)
+    np.testing.assert_array_equal(counts, ocnt)
+    assert (counts == 200).all()
+    s2.close()
     s.close()
 
 
@@ -721,8 +774,10 @@ def test_error_paths(ctx):
     s.finalize()
     with pytest.raises(pa.PcvError):
         s.search_vectors(None, 0, np.ones((1, 16), np.float32))
+    ids, _, counts = s.search_vectors(None, 1000, np.ones((1, 16), np.float32))  # more than one pass ranks: fine (4 rows, 4 hits)
+    assert counts[0] == 4 and sorted(ids[0][:4]) == [0, 1, 2, 3] and (ids[0][4:] == -1).all()
     with pytest.raises(pa.PcvError):
-        s.search_vectors(None, 1000, np.ones((1, 16), np.float32))
+        s.search_vectors(None, (1 << 24) + 1, np.ones((1, 16), np.float32))
     with pytest.raises(ValueError):
         s.search_vectors(None, 3, np.ones((1, 8), np.float32))
     s.close()
