@@ -270,6 +270,11 @@ pcv_status pcv_searcher_search_device(pcv_searcher* s, const float* queries, int
  *   begin -> all-gather of (n*k+1)*24 bytes -> pcv_merge_topk_flagged -> end -> repeat if any_overflow. */
 pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* queries, int n_queries,
                                             const int64_t* source_ids, int n_sources, int k, void* d_out);
+/* `begin` with the queries in DEVICE memory ([n_queries][dim] f32 at d_queries, valid until `end`): embeddings that
+ * pcv_model_encode_tokens_device left on the GPU (and an all-gather put together) go into the scan without a host hop —
+ * the chain of BASELINE configs[4], model.rs:176 -> search.rs:157 with nothing in between. */
+pcv_status pcv_searcher_search_device_begin_dq(pcv_searcher* s, const void* d_queries, int n_queries,
+                                               const int64_t* source_ids, int n_sources, int k, void* d_out);
 pcv_status pcv_searcher_search_device_end(pcv_searcher* s, int* out_overflowed);
 /* A step of a sharded search is about to be repeated because SOME rank's pass was incomplete (any_overflow of
  * pcv_merge_topk_flagged): the repeat on THIS rank runs without a speculative start threshold as well.  Every rank
@@ -309,6 +314,14 @@ pcv_status pcv_comm_destroy(pcv_comm* c);
 pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float* queries, int n_queries,
                                        const int64_t* source_ids, int n_sources, int k, int64_t* out_ids,
                                        float* out_scores, int* out_counts);
+/* The same with the queries in DEVICE memory (the same on every rank), and the all-gather that puts them there: every rank
+ * contributes bytes_per_rank bytes at d_send and receives world_size x bytes_per_rank at d_recv (rank order; d_send may be
+ * this rank's slot of d_recv), on the context stream — data-parallel pcv_model_encode_tokens_device output -> all ranks hold
+ * all embeddings -> pcv_searcher_search_sharded_dq, nothing passing through host memory. */
+pcv_status pcv_searcher_search_sharded_dq(pcv_searcher* s, pcv_comm* c, const void* d_queries, int n_queries,
+                                          const int64_t* source_ids, int n_sources, int k, int64_t* out_ids,
+                                          float* out_scores, int* out_counts);
+pcv_status pcv_comm_all_gather(pcv_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank);
 
 /* Brute-force similarity matrices of lib.rs:63-77 for small inputs (tests, highlight.rs:109):
  *   out[b][n] = dot(a_b, m_n)                       pcv_dot_product            (lib.rs:63-65)

@@ -128,6 +128,7 @@ SYMBOLS = {
     "pcv_searcher_set_shard_offset": (C.c_int, [_P, C.c_int64]),
     "pcv_searcher_search_device": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _P, C.c_int]),
     "pcv_searcher_search_device_begin": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _P]),
+    "pcv_searcher_search_device_begin_dq": (C.c_int, [_P, _P, C.c_int, _I64P, C.c_int, C.c_int, _P]),
     "pcv_searcher_search_device_end": (C.c_int, [_P, _INTP]),
     "pcv_searcher_repeat_without_guess": (C.c_int, [_P]),
     "pcv_merge_topk_flagged": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I64P, _F32P, _INTP, _INTP]),
@@ -137,6 +138,8 @@ SYMBOLS = {
     "pcv_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _U8P, C.POINTER(_P)]),
     "pcv_comm_destroy": (C.c_int, [_P]),
     "pcv_searcher_search_sharded": (C.c_int, [_P, _P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
+    "pcv_searcher_search_sharded_dq": (C.c_int, [_P, _P, _P, C.c_int, _I64P, C.c_int, C.c_int, _I64P, _F32P, _INTP]),
+    "pcv_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "pcv_dot_product": (C.c_int, [_P, _F32P, C.c_int, _F32P, C.c_int64, C.c_int, _F32P]),
     "pcv_cosine_similarity": (C.c_int, [_P, _F32P, C.c_int, _F32P, C.c_int64, C.c_int, _F32P]),
     "pcv_searcher_last_stats": (C.c_int, [_P, C.POINTER(ScanStats)]),

@@ -193,7 +193,10 @@ void launch_coarse_pack8(hipStream_t st, const float4* blk, const float* scale, 
 void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp, int num_cus);  // quantises the queries first
 int mfma8_pass_queries(int Dp);  // queries one int8 MFMA pass can take (LDS-limited)
 // mid copy + its scales of rows [first_row, nrows) of a segment
-void launch_mid_pack(hipStream_t st, const float4* blk, const float* scale, uint4* mid16, float* scale16, uint32_t first_row, uint32_t nrows, int D4);
+// (scale8: the quantisation scales of the segment's int8 copy if it covers these rows — the copy is then made block by block with
+// the blocks' scales — or nullptr: row by row, each with its own)
+void launch_mid_pack(hipStream_t st, const float4* blk, const float* scale, const float* scale8, uint4* mid16, float* scale16,
+                     uint32_t first_row, uint32_t nrows, int D4);
 void launch_synth_fill(hipStream_t st, float4* blk, uint32_t nrows, uint32_t row0, int D, int D4, uint64_t seed,
                        int64_t first_row, int normalize, uint32_t n_clusters, float noise, float amp_lo = 0.0f, float amp_hi = 0.0f);
 void launch_gather_rows(hipStream_t st, const SegDesc* d_segs, int nseg, const int64_t* d_pos, int64_t n, int D,

@@ -402,6 +402,52 @@ __global__ __launch_bounds__(256) void mid_pack_kernel(const float4* __restrict_
     }
 }
 
+// The same copy for segments that have their int8 screening copy (the normal case), one wave per 32-row BLOCK: the block's
+// pieces are read as the scan reads them — two contiguous 512-byte runs per instruction, every row once — quantised with ONE
+// scale for the block, s2 = scale8[b] * 32766 / 127 (the int8 copy's block maximum: any s2 <= 32766 / max|y_i| of a row keeps
+// |y_i - Y_i / s2| <= 0.5 / s2, which is all the mid screen's bound uses; no pass for the maximum), turned row-major in LDS
+// and written as the block's Dp * 64 contiguous bytes.  mid_pack_kernel above gathers 16-byte pieces 512 bytes apart, twice per
+// row: 1.0 TB/s, 228 ms per 100M x 384 rows (profiles/r03_batch256_kernel_stats.csv).
+__global__ __launch_bounds__(64) void mid_pack_block_kernel(const float4* __restrict__ blk, const float* __restrict__ scale,
+                                                            const float* __restrict__ scale8, uint4* __restrict__ mid16,
+                                                            float* __restrict__ scale16, uint32_t first_block, uint32_t nblocks, int D4) {
+    extern __shared__ uint2 mtile[];  // [32][D4 + 2]: a row's 8-byte pieces, two of padding (rows stay 16-byte aligned)
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int LD = D4 + 2, P2 = D4 >> 1;
+    for (uint32_t b = first_block + blockIdx.x; b < nblocks; b += gridDim.x) {
+        const float sc = scale[(size_t)b * 32 + r];
+        const float s2 = scale8[b] * (32766.0f / 127.0f);  // NaN: a block without a searchable row
+        const bool searchable = sc != 0.0f && s2 == s2;
+        const float4* src = blk + (size_t)b * D4 * 32 + h * 32 + r;  // piece 2j + h of row r: src + 64 j
+        for (int j0 = 0; j0 < P2; j0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < P2) v[u] = ld_row<true>(src + (size_t)(j0 + u) * 64);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < P2) {
+                    const float y[4] = {v[u].x * sc, v[u].y * sc, v[u].z * sc, v[u].w * sc};
+                    int q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = searchable ? max(-32767, min(32767, (int)rintf(y[e] * s2))) : 0;
+                    mtile[r * LD + 2 * (j0 + u) + h] =
+                        make_uint2(((uint32_t)q[0] & 0xffffu) | ((uint32_t)q[1] << 16), ((uint32_t)q[2] & 0xffffu) | ((uint32_t)q[3] << 16));
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tile is written (one wave: nobody else touches it)
+        __builtin_amdgcn_wave_barrier();
+        uint4* dst = mid16 + (size_t)b * 32 * P2;
+        for (int i = lane; i < 32 * P2; i += 64) {
+            const int row = i / P2, pc = i - row * P2;
+            dst[i] = *(const uint4*)&mtile[row * LD + 2 * pc];
+        }
+        if (lane < 32) scale16[(size_t)b * 32 + lane] = searchable ? s2 : __builtin_nanf("");
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // the reads are done before the next block overwrites the tile
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 struct SynthShape {  // n_clusters == 0: plain i.i.d. rows, times a per-row amplitude in [amp_lo, amp_lo + amp_span) if amp_span >= 0
     uint32_t n_clusters;
     float noise, inv_sqrt_d;
@@ -2919,8 +2965,19 @@ void launch_coarse_pack8(hipStream_t st, const float4* blk, const float* scale, 
     PCV_LAUNCHED();
 }
 
-void launch_mid_pack(hipStream_t st, const float4* blk, const float* scale, uint4* mid16, float* scale16, uint32_t first_row, uint32_t nrows, int D4) {
+void launch_mid_pack(hipStream_t st, const float4* blk, const float* scale, const float* scale8, uint4* mid16, float* scale16,
+                     uint32_t first_row, uint32_t nrows, int D4) {
     if (first_row >= nrows) return;
+    if (scale8) {  // the segment has its int8 copy (and with it the blocks' maxima): block by block, every row read once
+        const uint32_t b0 = first_row / kBlockRows, nb = (nrows + kBlockRows - 1) / kBlockRows;
+        const size_t lds = (size_t)32 * (D4 + 2) * sizeof(uint2);
+        allow_dynamic_lds((const void*)mid_pack_block_kernel, lds);
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
+        const unsigned gridb = std::min<uint32_t>(nb - b0, (unsigned)current_device_cus() * per_cu);
+        mid_pack_block_kernel<<<gridb, 64, lds, st>>>(blk, scale, scale8, mid16, scale16, b0, nb, D4);
+        PCV_LAUNCHED();
+        return;
+    }
     const unsigned grid = (unsigned)std::min<uint32_t>((nrows - first_row + 3) / 4, 256u * 8 * 4);
     mid_pack_kernel<<<grid, 256, 0, st>>>(blk, scale, mid16, scale16, first_row, nrows, D4);
     PCV_LAUNCHED();

@@ -10,7 +10,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <atomic>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -171,6 +174,33 @@ struct pcv_searcher {
     bool mid_gave_way = false;               // AUTO: building it failed, or it was dropped to make room for rows: not tried again
     bool mids_present = false;               // every row of every segment is covered by a mid copy
     int mid_hot_passes = 0;                  // AUTO: passes in a row whose coarse screen let more than kMidTrigger rows per query through
+    // AUTO builds the mid copy beside the searches, on a stream of its own: the call that decides to build it queues the build
+    // and goes on without the copy, and so do the calls after it until the build's event has come (a 100M-row build is tens of
+    // milliseconds; round 3 ran it inside the deciding search call, 228 ms with the older kernel).  Whatever changes rows or
+    // copies waits for it first (settle_mid_build).
+    // The allocations of such a build are host time too (132 ms for 6 GB on the test box): a helper thread makes them and
+    // queues the kernels; it works on a list of its own (MidTask) and touches no segment — settle_mid_build joins it and hands
+    // the buffers to the segments.
+    hipStream_t side = nullptr;
+    hipEvent_t side_go = nullptr, mid_done = nullptr;
+    bool mid_building = false;
+    struct MidTask {
+        struct Item {
+            Segment* g;  // (for settle_mid_build; the helper thread does not follow it)
+            const float4* blk;
+            const float* scale;
+            const float* scale8;
+            uint32_t cap_rows, first_row, rows;
+            uint4* mid16;
+            float* scale16;
+            bool own;  // the helper thread allocated mid16 / scale16
+        };
+        std::vector<Item> items;
+        std::thread th;
+        std::atomic<bool> queued{false};  // the helper thread is through (the kernels may still run: mid_done)
+        bool joined = false, failed = false;
+    };
+    std::unique_ptr<MidTask> mid_task;
     int screen_copy = PCV_SCREEN_COPY_AUTO;  // pcv_searcher_set_screening_copy
     bool screen_copy_gave_way = false;       // AUTO: the copies were dropped to make room for rows
     int copies_kind = 0;                     // 0: not every row of every segment is covered by a screening copy; 1 bf16; 2 int8
@@ -240,7 +270,101 @@ constexpr int64_t kMidTrigger = 4096;  // coarse survivors per query and pass ab
 constexpr int64_t kMidShare = 25;      // ... or whose f32 rows (32 B per feature: 16-byte pieces in 128-byte lines) come to more than 1/25 of the bytes streamed ...
 constexpr int kMidPasses = 2;          // ... once that many passes in a row were above it
 
+// The AUTO build under way beside the searches, if any: `wait` for it, or only look whether it is done; done = its rows count.
+void settle_mid_build(pcv_searcher* s, bool wait) {
+    if (!s->mid_building) return;
+    pcv_searcher::MidTask& t = *s->mid_task;
+    if (!t.joined) {
+        if (!wait && !t.queued.load(std::memory_order_acquire)) return;
+        t.th.join();
+        t.joined = true;
+    }
+    if (!t.failed) {
+        if (wait)
+            PCV_HIP(hipEventSynchronize(s->mid_done));
+        else if (hipEventQuery(s->mid_done) != hipSuccess) {
+            (void)hipGetLastError();  // (hipErrorNotReady)
+            return;
+        }
+    }
+    s->mid_building = false;
+    if (t.failed) {  // (the helper thread has given back what it had allocated)
+        s->mid_gave_way = true;
+        s->mid_task.reset();
+        return;
+    }
+    for (auto& it : t.items) {
+        it.g->mid16 = it.mid16;
+        it.g->scale16 = it.scale16;
+        it.g->mid_rows = it.rows;
+    }
+    s->mid_task.reset();
+    s->mids_present = true;
+    for (auto& src : s->sources)
+        for (auto& g : src.segs)
+            if (g.nrows > 0 && (!g.mid16 || g.mid_rows < g.nrows)) s->mids_present = false;
+}
+
+// Queue the build of the mid copies of every segment beside the searches (AUTO): a helper thread allocates and launches on
+// the side stream, behind everything the context stream holds now.
+void start_mid_build(pcv_searcher* s) {
+    settle_mid_build(s, true);
+    if (!s->side) {
+        PCV_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        PCV_HIP(hipEventCreateWithFlags(&s->side_go, hipEventDisableTiming));
+        PCV_HIP(hipEventCreateWithFlags(&s->mid_done, hipEventDisableTiming));
+    }
+    PCV_HIP(hipEventRecord(s->side_go, s->ctx->stream));
+    PCV_HIP(hipStreamWaitEvent(s->side, s->side_go, 0));
+    s->mid_task.reset(new pcv_searcher::MidTask());
+    pcv_searcher::MidTask& t = *s->mid_task;
+    for (auto& src : s->sources)
+        for (auto& g : src.segs) {
+            if (g.nrows == 0 || (g.mid16 && g.mid_rows >= g.scaled_rows)) continue;
+            t.items.push_back({&g, g.blk, g.scale, (g.blk8 && g.copied_rows >= g.scaled_rows) ? g.scale8 : nullptr, g.cap_rows,
+                               g.mid16 ? g.mid_rows : 0u, g.scaled_rows, g.mid16, g.scale16, false});
+        }
+    const int device = s->ctx->device, D4 = s->D4, Dp = s->Dp;
+    const bool fail = s->fail_copy_alloc;
+    hipStream_t side = s->side;
+    hipEvent_t done = s->mid_done;
+    pcv_searcher::MidTask* tp = &t;
+    t.th = std::thread([tp, device, D4, Dp, fail, side, done] {
+        bool ok = hipSetDevice(device) == hipSuccess;
+        try {
+            for (auto& it : tp->items) {
+                if (!ok) break;
+                if (!it.mid16) {
+                    ok = !fail && hipMalloc((void**)&it.mid16, (size_t)it.cap_rows * Dp * 2) == hipSuccess;
+                    if (ok) {
+                        it.own = true;
+                        ok = hipMalloc((void**)&it.scale16, (size_t)it.cap_rows * sizeof(float)) == hipSuccess;
+                    }
+                    if (!ok) break;
+                }
+                launch_mid_pack(side, it.blk, it.scale, it.scale8, it.mid16, it.scale16, it.first_row, it.rows, D4);
+            }
+            if (ok) ok = hipEventRecord(done, side) == hipSuccess;
+        } catch (...) {
+            ok = false;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(side);
+            for (auto& it : tp->items)
+                if (it.own) {
+                    if (it.mid16) (void)hipFree(it.mid16);
+                    if (it.scale16) (void)hipFree(it.scale16);
+                }
+            tp->failed = true;
+        }
+        tp->queued.store(true, std::memory_order_release);
+    });
+    s->mid_building = true;  // (mids_present stays false: the passes go on without the copy until settle_mid_build sees it done)
+}
+
 void drop_mid_copies(pcv_searcher* s) {
+    settle_mid_build(s, true);
     s->mids_present = false;
     for (auto& src : s->sources)
         for (auto& g : src.segs) {
@@ -255,6 +379,7 @@ void drop_mid_copies(pcv_searcher* s) {
 // Mid copies (scan.h) of the rows that have their scale and no copy yet.  `must`: an allocation failure is an error
 // (PCV_MID_COPY_ON); otherwise it ends the attempt for good (mid_gave_way).
 void build_mid_copies(pcv_searcher* s, bool must) {
+    settle_mid_build(s, true);
     hipStream_t st = s->ctx->stream;
     for (auto& src : s->sources)
         for (auto& g : src.segs) {
@@ -282,7 +407,8 @@ void build_mid_copies(pcv_searcher* s, bool must) {
                 }
                 g.mid_rows = 0;
             }
-            launch_mid_pack(st, g.blk, g.scale, g.mid16, g.scale16, g.mid_rows, g.scaled_rows, s->D4);
+            launch_mid_pack(st, g.blk, g.scale, (g.blk8 && g.copied_rows >= g.scaled_rows) ? g.scale8 : nullptr, g.mid16, g.scale16, g.mid_rows,
+                            g.scaled_rows, s->D4);
             g.mid_rows = g.scaled_rows;
         }
     s->mids_present = true;
@@ -293,19 +419,23 @@ void build_mid_copies(pcv_searcher* s, bool must) {
 
 // AUTO mid copy: called by every search entry point in front of its passes
 void maybe_build_mid_copies(pcv_searcher* s) {
-    if (!(s->mid_copy == PCV_MID_COPY_AUTO && !s->mids_present && !s->mid_gave_way && s->mid_hot_passes >= kMidPasses)) return;
-    // (only if the memory is plainly there: the copy is a convenience, the headroom is for rows)
+    settle_mid_build(s, false);
+    if (!(s->mid_copy == PCV_MID_COPY_AUTO && !s->mids_present && !s->mid_building && !s->mid_gave_way && s->mid_hot_passes >= kMidPasses)) return;
+    // (only if the memory is plainly there: the copy is a convenience — a few per cent of a pass on Gaussian rows, a quarter on
+    // clustered ones — and the headroom is for rows, for other searchers and models of the process, for the candidate lists of
+    // an overflow rerun: a tenth of the device, at least 4 GB, stays free)
     size_t free_b = 0, total_b = 0, need = 0;
     for (const auto& src : s->sources)
         for (const auto& g : src.segs) need += (size_t)g.cap_rows * ((size_t)s->Dp * 2 + 4);
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + ((size_t)4 << 30))
-        build_mid_copies(s, false);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + std::max<size_t>((size_t)4 << 30, total_b / 10))
+        start_mid_build(s);  // beside the searches: this call and the next ones go on without it meanwhile
     else
         s->mid_gave_way = true;
     s->mid_hot_passes = 0;
 }
 
 void drop_screening_copies(pcv_searcher* s) {
+    settle_mid_build(s, true);  // (it reads the int8 copy's block scales)
     s->copies_kind = 0;
     for (auto& src : s->sources)
         for (auto& g : src.segs) {
@@ -389,6 +519,7 @@ struct Piece {
     int64_t n;
 };
 std::vector<Piece> place_rows(pcv_searcher* s, Source& src, int64_t n, bool with_ids) {
+    settle_mid_build(s, true);
     std::vector<Piece> out;
     int64_t remaining = n;
     if (!src.segs.empty()) {
@@ -514,6 +645,7 @@ void build_screening_copies(pcv_searcher* s, Source& src) {
 }
 
 void do_finalize(pcv_searcher* s) {
+    settle_mid_build(s, true);
     hipStream_t st = s->ctx->stream;
     for (auto& src : s->sources) {
         for (auto& g : src.segs) {
@@ -629,7 +761,10 @@ void ensure_pass_block(pcv_searcher* s, size_t nseg) {
 // into pinned host memory as well; the survivor counts always come back that way.  `d_flag` != nullptr
 // receives the overflow record (scan.h).
 void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSeg* segs, int nseg, int k, int kernel,
-                  pcv_hit_dev* d_out, bool download, pcv_hit_dev* d_flag, const CeilRec* ceil_host = nullptr) {
+                  pcv_hit_dev* d_out, bool download, pcv_hit_dev* d_flag, const CeilRec* ceil_host = nullptr,
+                  bool queries_on_device = false) {
+    // `queries_on_device`: queries_host is a DEVICE pointer (embeddings that never left the GPU: encode -> gather -> search of
+    // BASELINE configs[4]); the pass copies them device to device behind its parameter upload.
     const auto t_begin = std::chrono::steady_clock::now();
     hipStream_t st = s->ctx->stream;
     ensure_workspace(s);
@@ -747,7 +882,10 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     p.max_norm = s->max_norm;
 
     size_t bytes = L.off_q;
-    if (queries_host) {  // nullptr: the queries of the previous attempt are still on the device
+    const float* queries_dev = nullptr;
+    if (queries_host && queries_on_device) {
+        queries_dev = queries_host;
+    } else if (queries_host) {  // nullptr: the queries of the previous attempt are still on the device
         std::memcpy(s->pin_pass + L.off_q, queries_host, (size_t)B * s->D * sizeof(float));
         bytes += (size_t)B * s->D * sizeof(float);
     }
@@ -758,6 +896,8 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     auto launch_pass = [&](bool timed) {
         if (timed) PCV_HIP(hipEventRecord(s->ev[0], st));
         launch_upload(st, s->pin_pass, s->d_pass, bytes);
+        if (queries_dev)
+            PCV_HIP(hipMemcpyAsync(s->d_pass + L.off_q, queries_dev, (size_t)B * s->D * sizeof(float), hipMemcpyDeviceToDevice, st));
         launch_prep_seed(st, p, dp, tab[0]);
         if (timed) PCV_HIP(hipEventRecord(s->ev[1], st));
         if (kernel == PCV_KERNEL_MFMA && src_kind == 2)
@@ -788,7 +928,7 @@ void enqueue_pass(pcv_searcher* s, const float* queries_host, int B, const SelSe
     shape.seg0_scale = tab[0].scale;
     // only where queueing is a visible share of the pass: up to kGraphRows rows (a longer pass is launched plainly and
     // timed kernel by kernel, which is what the roofline figures are taken from)
-    const bool small = rows <= kGraphRows && s->use_graph && !ceil_host;
+    const bool small = rows <= kGraphRows && s->use_graph && !ceil_host && !queries_dev;
     bool replayed = false;
     if (small && s->graph_exec && shape == s->graph_shape) {
         PCV_HIP(hipEventRecord(s->ev[0], st));
@@ -1088,7 +1228,7 @@ void hits_to_outputs(int metric, int D, const pcv_hit_dev* hits, int n_queries, 
 
 // The per-shard pass of the begin/end protocol; the caller holds s->mu.
 void device_begin(pcv_searcher* s, const float* queries, int n_queries, const int64_t* source_ids, int n_sources, int k,
-                  pcv_hit_dev* out) {
+                  pcv_hit_dev* out, bool queries_on_device = false) {
     check_search_args(s, queries, n_queries, k, "search_device_begin");
     PCV_REQUIRE(!s->pending.active, "search_device_begin: the previous pass was not collected (search_device_end)");
     PCV_HIP(hipSetDevice(s->ctx->device));
@@ -1114,7 +1254,7 @@ void device_begin(pcv_searcher* s, const float* queries, int n_queries, const in
         return;
     }
     maybe_build_mid_copies(s);  // (each rank by its own statistics: the copy changes no result and no protocol)
-    enqueue_pass(s, queries, n_queries, segs.data(), (int)segs.size(), k, kernel, out, false, out + n);
+    enqueue_pass(s, queries, n_queries, segs.data(), (int)segs.size(), k, kernel, out, false, out + n, nullptr, queries_on_device);
 }
 
 }  // namespace
@@ -1158,6 +1298,16 @@ pcv_status pcv_searcher_destroy(pcv_searcher* s) {
         if (!s) return;
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
+        try {
+            settle_mid_build(s, true);
+        } catch (...) {
+        }
+        if (s->side) {
+            (void)hipStreamSynchronize(s->side);
+            (void)hipStreamDestroy(s->side);
+            (void)hipEventDestroy(s->side_go);
+            (void)hipEventDestroy(s->mid_done);
+        }
         for (auto& src : s->sources)
             for (auto& g : src.segs) free_segment(g);
         s->d_stage.release();
@@ -1288,6 +1438,8 @@ pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id) {
         if (!src) return;
         PCV_HIP(hipSetDevice(s->ctx->device));
         PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+        settle_mid_build(s, true);
+        if (!src->segs.empty()) s->screen_copy_gave_way = s->mid_gave_way = false;  // rows are given back: AUTO may try its copies again
         for (auto& g : src->segs) free_segment(g);
         src->segs.clear();
         src->next_implicit_id = 0;
@@ -1304,6 +1456,7 @@ pcv_status pcv_searcher_replace_source(pcv_searcher* s, int64_t from_source_id, 
         PCV_REQUIRE(!s->pending.active, "replace_source: a queued pass has not been collected");
         PCV_HIP(hipSetDevice(s->ctx->device));
         PCV_HIP(hipStreamSynchronize(s->ctx->stream));
+        settle_mid_build(s, true);
         std::vector<Segment> fresh;
         int64_t next_id = 0;
         for (size_t i = 0; i < s->sources.size(); ++i)
@@ -1316,6 +1469,11 @@ pcv_status pcv_searcher_replace_source(pcv_searcher* s, int64_t from_source_id, 
         Source* to = s->find_source(to_source_id);
         if (!to && !fresh.empty()) to = &s->get_or_add_source(to_source_id);
         if (to) {  // (the old rows keep their place among the sources: positions of the others do not move)
+            // The staged rebuild holds the old and the new rows of a source at once.  If AUTO gave its copies up to fit them
+            // (alloc_segment: the rows come first), the old rows going now is the room to have them again: the next finalize
+            // tries — once; another failure gives them up again.  (Without this every later search of a searcher that once
+            // rebuilt a large source on a nearly full device streamed the f32 rows, 4x the bytes, silently.)
+            if (!to->segs.empty()) s->screen_copy_gave_way = s->mid_gave_way = false;
             for (auto& g : to->segs) free_segment(g);
             to->segs = std::move(fresh);
             to->next_implicit_id = next_id;
@@ -1557,6 +1715,15 @@ pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* querie
     });
 }
 
+pcv_status pcv_searcher_search_device_begin_dq(pcv_searcher* s, const void* d_queries, int n_queries,
+                                               const int64_t* source_ids, int n_sources, int k, void* d_out) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr && d_out != nullptr, "search_device_begin_dq: NULL argument");
+        std::lock_guard<std::mutex> lk(s->mu);
+        device_begin(s, (const float*)d_queries, n_queries, source_ids, n_sources, k, (pcv_hit_dev*)d_out, true);
+    });
+}
+
 pcv_status pcv_searcher_search_device_end(pcv_searcher* s, int* out_overflowed) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr, "search_device_end: NULL argument");
@@ -1754,9 +1921,17 @@ pcv_status pcv_comm_destroy(pcv_comm* c) {
     });
 }
 
-pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float* queries, int n_queries,
-                                       const int64_t* source_ids, int n_sources, int k, int64_t* out_ids,
-                                       float* out_scores, int* out_counts) {
+pcv_status pcv_comm_all_gather(pcv_comm* c, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    return guarded([&] {
+        PCV_REQUIRE(c != nullptr && d_send != nullptr && d_recv != nullptr && bytes_per_rank > 0, "comm_all_gather: bad argument");
+        PCV_HIP(hipSetDevice(c->ctx->device));
+        rccl_check(rccl().AllGather(d_send, d_recv, bytes_per_rank, /*ncclInt8*/ 0, c->comm, c->ctx->stream), "ncclAllGather");
+    });
+}
+
+static pcv_status search_sharded_impl(pcv_searcher* s, pcv_comm* c, const float* queries, bool queries_on_device, int n_queries,
+                                      const int64_t* source_ids, int n_sources, int k, int64_t* out_ids,
+                                      float* out_scores, int* out_counts) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr && c != nullptr, "search_sharded: NULL argument");
         PCV_REQUIRE(s->ctx == c->ctx, "search_sharded: searcher and communicator live on different contexts");
@@ -1812,7 +1987,7 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
             // One pass: everything is queued back to back and the host waits once.  Whether a list
             // overflowed somewhere is part of the exchanged payload, so all ranks repeat (or not) together.
             for (int attempt = 0;; ++attempt) {
-                device_begin(s, queries + (size_t)q0 * s->D, B, source_ids, n_sources, k, c->d_local.p);
+                device_begin(s, queries + (size_t)q0 * s->D, B, source_ids, n_sources, k, c->d_local.p, queries_on_device);
                 try {
                     exchange(c->d_local.p, (size_t)B, 1);
                 } catch (...) {
@@ -1841,6 +2016,18 @@ pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float
         s->stats = total;
         hits_to_outputs(s->metric, s->D, all.data(), n_queries, k, out_ids, out_scores, out_counts);
     });
+}
+
+pcv_status pcv_searcher_search_sharded(pcv_searcher* s, pcv_comm* c, const float* queries, int n_queries,
+                                       const int64_t* source_ids, int n_sources, int k, int64_t* out_ids,
+                                       float* out_scores, int* out_counts) {
+    return search_sharded_impl(s, c, queries, false, n_queries, source_ids, n_sources, k, out_ids, out_scores, out_counts);
+}
+
+pcv_status pcv_searcher_search_sharded_dq(pcv_searcher* s, pcv_comm* c, const void* d_queries, int n_queries,
+                                          const int64_t* source_ids, int n_sources, int k, int64_t* out_ids,
+                                          float* out_scores, int* out_counts) {
+    return search_sharded_impl(s, c, (const float*)d_queries, true, n_queries, source_ids, n_sources, k, out_ids, out_scores, out_counts);
 }
 
 static pcv_status similarity(pcv_ctx* ctx, const float* a, int B, const float* m, int64_t N, int dim, float* out,

@@ -208,6 +208,16 @@ class Searcher:
             )
         )
 
+    def search_device_begin_dq(self, sources, num_results, d_queries, n_queries, d_out):
+        """The same with the queries in device memory (pcv_searcher_search_device_begin_dq): `d_queries` is the address of
+        [n_queries][dim] f32 on this searcher's device, e.g. what Model.encode_tokens_device left there."""
+        src, nsrc, _keep = _source_filter(sources)
+        _ffi.check(
+            _ffi.lib().pcv_searcher_search_device_begin_dq(
+                self._handle, C.c_void_p(d_queries), int(n_queries), src, nsrc, int(num_results), C.c_void_p(d_out)
+            )
+        )
+
     def search_device_end(self):
         """Wait for the queued pass and book its statistics; True if the pass has to be repeated (a candidate list
         overflowed, or a speculative start threshold did not hold)."""
@@ -232,6 +242,21 @@ class Searcher:
         _ffi.check(
             _ffi.lib().pcv_searcher_search_sharded(
                 self._handle, comm._handle, _ffi.f32p(q), B, src, nsrc, k, _ffi.i64p(ids), _ffi.f32p(scores),
+                _ffi.i32p(counts),
+            )
+        )
+        return ids, scores, counts
+
+    def search_sharded_dq(self, comm, sources, num_results, d_queries, n_queries):
+        """search_sharded with the queries in device memory, the same on every rank (pcv_searcher_search_sharded_dq)."""
+        B, k = int(n_queries), int(num_results)
+        src, nsrc, _keep = _source_filter(sources)
+        ids = np.full((B, k), -1, dtype=np.int64)
+        scores = np.full((B, k), np.nan, dtype=np.float32)
+        counts = np.zeros(B, dtype=np.int32)
+        _ffi.check(
+            _ffi.lib().pcv_searcher_search_sharded_dq(
+                self._handle, comm._handle, C.c_void_p(d_queries), B, src, nsrc, k, _ffi.i64p(ids), _ffi.f32p(scores),
                 _ffi.i32p(counts),
             )
         )

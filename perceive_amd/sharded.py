@@ -80,6 +80,11 @@ class NativeComm:
         dist.broadcast_object_list(box, src=0)
         return cls(ctx, dist.get_world_size(), dist.get_rank(), box[0])
 
+    def all_gather(self, d_send, d_recv, bytes_per_rank):
+        """ncclAllGather on the library's communicator and stream (pcv_comm_all_gather): device addresses; d_send may be
+        this rank's slot of d_recv."""
+        _ffi.check(_ffi.lib().pcv_comm_all_gather(self._handle, C.c_void_p(d_send), C.c_void_p(d_recv), int(bytes_per_rank)))
+
     def close(self):
         """Destroy the communicator.  It lives on the context's device and stream, so it has to go
         first; if the context is already closed the handle is dropped, not destroyed."""
@@ -181,6 +186,35 @@ class ShardedSearcher:
         local[:n].copy_(torch.from_numpy(np.ascontiguousarray(hits).view(np.uint8).reshape(-1)))
         self._all_gather(gathered[: self.world * n], local[:n])
         return merge_topk_host(self.metric, self.dim, gathered[: self.world * n].numpy(), self.world, B, k)
+
+    def search_device_queries(self, sources, num_results, d_queries, n_queries):
+        """search_vectors with the queries in DEVICE memory (address of [n_queries][dim] f32 on this rank's GPU, the same
+        values on every rank): the embeddings a data-parallel encode left on the devices and an all-gather put together
+        go into the scan without passing through host memory (BASELINE configs[4]).  One pass: n_queries <= 128."""
+        B, k = int(n_queries), int(num_results)
+        if self.comm is not None:
+            return self.searcher.search_sharded_dq(self.comm, sources, k, d_queries, B)
+        import torch
+
+        assert self.device, "device queries need the device protocol"
+        local, gathered = self._buffers(B, k)
+        if self._adopted is False:
+            if len(hip_runtimes_loaded()) == 1:
+                self.ctx.set_stream(torch.cuda.current_stream().cuda_stream, adopt=True)
+                self._adopted = True
+            else:
+                self._adopted = None
+        for _ in range(8):
+            self.searcher.search_device_begin_dq(sources, k, d_queries, B, local.data_ptr())
+            if not self._adopted:
+                self.ctx.synchronize()  # (two HIP runtimes in the process: no stream is shared, the host orders the steps)
+            self._all_gather(gathered, local)
+            ids, scores, counts, over = merge_topk(self.ctx, self.metric, self.dim, gathered.data_ptr(), self.world, B, k, flagged=True)
+            self.searcher.search_device_end()
+            if not over:
+                return ids, scores, counts
+            self.searcher.repeat_without_guess()
+        raise RuntimeError("the sharded step is still incomplete on some rank after 8 repeats (candidate lists keep overflowing)")
 
     def _local_hits_host(self, sources, q, k):
         d = self.ctx.alloc(q.shape[0] * k * HIT_BYTES)

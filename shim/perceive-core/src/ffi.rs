@@ -176,6 +176,7 @@ extern "C" {
     pub fn pcv_searcher_set_shard_offset(s: *mut pcv_searcher, first_global_pos: i64) -> c_int;
     pub fn pcv_searcher_search_device(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void, async_: c_int) -> c_int;
     pub fn pcv_searcher_search_device_begin(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void) -> c_int;
+    pub fn pcv_searcher_search_device_begin_dq(s: *mut pcv_searcher, d_queries: *const c_void, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void) -> c_int;
     pub fn pcv_searcher_search_device_end(s: *mut pcv_searcher, out_overflowed: *mut c_int) -> c_int;
     pub fn pcv_searcher_repeat_without_guess(s: *mut pcv_searcher) -> c_int;
     pub fn pcv_merge_topk(ctx: *mut pcv_ctx, metric: c_int, dim: c_int, d_lists: *const c_void, n_shards: c_int, n_queries: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;
@@ -185,6 +186,8 @@ extern "C" {
     pub fn pcv_comm_create(ctx: *mut pcv_ctx, world_size: c_int, rank: c_int, id: *const u8, out: *mut *mut pcv_comm) -> c_int;
     pub fn pcv_comm_destroy(c: *mut pcv_comm) -> c_int;
     pub fn pcv_searcher_search_sharded(s: *mut pcv_searcher, c: *mut pcv_comm, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;
+    pub fn pcv_searcher_search_sharded_dq(s: *mut pcv_searcher, c: *mut pcv_comm, d_queries: *const c_void, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;
+    pub fn pcv_comm_all_gather(c: *mut pcv_comm, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: usize) -> c_int;
     pub fn pcv_dot_product(ctx: *mut pcv_ctx, a: *const f32, B: c_int, m: *const f32, N: i64, dim: c_int, out: *mut f32) -> c_int;
     pub fn pcv_cosine_similarity(ctx: *mut pcv_ctx, a: *const f32, B: c_int, m: *const f32, N: i64, dim: c_int, out: *mut f32) -> c_int;
     pub fn pcv_searcher_last_stats(s: *mut pcv_searcher, out: *mut pcv_scan_stats) -> c_int;

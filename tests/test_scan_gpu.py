@@ -1156,6 +1156,17 @@ def test_screening_copy_gives_way_when_memory_is_short(ctx, oracle, monkeypatch)
     s.finalize()
     np.testing.assert_array_equal(s.search_vectors(None, 10, q)[0], ref)
     assert s.last_stats()["screening_copy"] == 2
+    # ... and so does the staged rebuild of a source (Searcher::rebuild_source): the old and the new rows of the source are
+    # resident at once; if AUTO gave its copies up to fit them, the old rows going is the room to have them again
+    s.set_tuning(fail_copy_alloc=True)
+    s.add_rows(3, m[:500], 5000 + np.arange(500))
+    s.finalize()
+    s.set_tuning()
+    assert s.search_vectors(None, 10, q) is not None and s.last_stats()["screening_copy"] == 0  # gave way again
+    s.rebuild_source([(2000 + i, 2, m[2000 + i]) for i in range(1000)] + [(9, 7, m[0])], 2)  # (rows of other sources are ignored)
+    got = s.search_vectors([1, 2], 10, q)[0]
+    np.testing.assert_array_equal(got, ref)
+    assert s.last_stats()["screening_copy"] == 2  # the copies are back without being asked for
     s.close()
     e = pa.Searcher(ctx, 128, "cosine")
     e.set_tuning(fail_copy_alloc=True)
@@ -1351,14 +1362,17 @@ def test_mid_copy_is_invisible_in_the_results_and_cuts_the_f32_reads(ctx, oracle
     check(ids, sc, sub)
     assert st0["screening_copy"] == 2 and st0["mid_copy"] == 0 and st0["coarse_survivors"] > 4096 * 64, st0
     s.set_mid_copy("auto")
-    for i in range(2):  # two passes above the trigger: the third call builds the copy before it searches
+    for i in range(2):  # two passes above the trigger: the third call queues the build of the copy, beside the searches
         ids, sc, _ = s.search_vectors(None, k, q)
         assert s.last_stats()["mid_copy"] == 0
         check(ids, sc, sub)
-    ids, sc, _ = s.search_vectors(None, k, q)
-    st1 = s.last_stats()
-    check(ids, sc, sub)
-    assert st1["mid_copy"] == 1 and 0 < st1["mid_survivors"] < st1["coarse_survivors"] // 8, st1
+    for i in range(200):  # ... and the calls go on without the copy until it is there
+        ids, sc, _ = s.search_vectors(None, k, q)
+        st1 = s.last_stats()
+        check(ids, sc, sub)
+        if st1["mid_copy"] == 1:
+            break
+    assert st1["mid_copy"] == 1 and 0 < st1["mid_survivors"] < st1["coarse_survivors"] // 8, (i, st1)
     # rows added afterwards join the copy at finalize (AUTO keeps what it has built)
     s.add_rows(1, rows[200_000:], np.arange(200_000, n))
     s.finalize()
@@ -1398,6 +1412,53 @@ def test_mid_copy_is_invisible_in_the_results_and_cuts_the_f32_reads(ctx, oracle
     with pytest.raises(pa.PcvError):
         u.finalize()
     u.close()
+
+
+def test_auto_mid_copy_is_built_beside_the_searches(ctx):
+    """AUTO decides inside a search call that the mid copy pays (two passes in a row with a crowd at the coarse screen).  The
+    build — a pass over every row, several times what a search takes — is queued on a stream of its own: the deciding call and
+    the calls after it take what a call without the copy takes (round 3 built it inside the deciding call: 228 ms on a
+    100M-row corpus), and once the build's event has come the passes use it.  Same hits throughout."""
+    import time
+
+    n, d, B, k = 8_000_000, 384, 64, 10
+    s = pa.Searcher(ctx, d, "cosine")
+    s.add_synthetic(1, n, 0x5EED, n_clusters=n // 20_000, noise=0.004)
+    s.finalize()
+    rng = np.random.default_rng(5)
+    probe = s.get_rows(rng.integers(0, n, B))[0]
+    q = (probe + 0.002 * rng.standard_normal(probe.shape)).astype(np.float32)
+    s.set_mid_copy("off")
+    times = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        ref = s.search_vectors(None, k, q)[0]
+        times.append(time.perf_counter() - t0)
+    base = float(np.median(times[2:]))
+    assert s.last_stats()["coarse_survivors"] > 4096 * B  # the AUTO trigger's first condition
+    s.set_mid_copy("auto")
+    calls, seen = [], None
+    for i in range(400):
+        t0 = time.perf_counter()
+        ids = s.search_vectors(None, k, q)[0]
+        calls.append(time.perf_counter() - t0)
+        np.testing.assert_array_equal(ids, ref)
+        if s.last_stats()["mid_copy"] == 1:
+            seen = i
+            break
+    assert seen is not None and seen >= 2, seen  # (calls 0 and 1 are the two hot passes; call 2 queues the build)
+    # No call waits for the build.  The deciding call pays for queueing it (a stream, a helper thread) and for the moments the
+    # helper thread's allocations hold the runtime's lock (measured: 8.9 ms against 3.3 ms here; 32 ms against 5.8 ms at 50M
+    # rows, where the build itself is ~20 ms of kernel time and the older kernel inside the call was > 110 ms); the calls
+    # while it runs share the memory system with it.
+    assert max(calls[: seen + 1]) < 4.0 * base + 1e-3, (base, calls[: seen + 1])
+    assert seen <= 8, calls
+    t0 = time.perf_counter()
+    ids = s.search_vectors(None, k, q)[0]
+    with_copy = time.perf_counter() - t0
+    np.testing.assert_array_equal(ids, ref)
+    assert with_copy < base  # what the copy is for on such rows
+    s.close()
 
 
 def test_mid_copy_on_rows_that_quantise_badly(ctx, oracle):

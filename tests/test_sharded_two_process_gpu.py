@@ -97,6 +97,74 @@ print("rank", rank, "ok", flush=True)
 """
 
 
+WORKER_E2E = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PCV_ROOT"]); sys.path.insert(0, os.path.join(os.environ["PCV_ROOT"], "tests"))
+import torch, torch.distributed as dist          # torch first: one HIP runtime for it and the library
+import oracle_ffi
+import perceive_amd as pa
+
+# BASELINE configs[4] in small, on two ranks: every rank encodes ITS half of the documents and leaves the embeddings on its
+# GPU (encode_tokens_device into its slot of the batch's buffer), an all-gather completes the buffer on every rank (staged
+# through the host over gloo here: both ranks sit on GPU 0), and the sharded search reads its queries from that DEVICE buffer
+# (search_device_begin_dq) — the embeddings never pass through host memory on the product path.
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+orc = oracle_ffi.load()
+desc = dict(vocab=500, hidden=128, layers=2, heads=4, inter=256, max_pos=64, eps=1e-12, pooling=0, normalize=1)
+ctx = pa.Context(0)
+m = pa.Model(ctx, pa.make_desc(500, 128, 2, 4, 256, 64), synthetic_seed=5)     # the same seeded weights on both ranks
+rng = np.random.default_rng(3)
+docs, L, D, k = 12, 40, 128, 10
+lens = rng.integers(5, L + 1, docs); lens[0] = L
+toks = [list(rng.integers(1, 500, int(n))) for n in lens]
+ids, mask = m.generate_token_tensors(toks)
+N = 300_000
+corpus = rng.standard_normal((N, D)).astype(np.float32)
+lo, hi = pa.shard_bounds(N, rank, world)
+s = pa.Searcher(ctx, D, "cosine")
+s.add_rows(1, corpus[lo:hi], np.arange(lo, hi) * 3 + 2)
+s.finalize()
+s.set_shard_offset(lo)
+
+d0, d1 = docs * rank // world, docs * (rank + 1) // world
+emb = torch.zeros((docs, D), dtype=torch.float32, device="cuda")               # the batch's embeddings, on the device
+m.encode_tokens_device(ids[d0:d1], mask[d0:d1], emb.data_ptr() + d0 * D * 4)   # this rank's documents into their slot
+ctx.synchronize()
+mine = emb[d0:d1].cpu()                                                         # (the exchange itself: gloo has no device all-gather)
+parts = [torch.empty((docs * (r + 1) // world - docs * r // world, D), dtype=torch.float32) for r in range(world)]
+dist.all_gather(parts, mine)
+emb.copy_(torch.cat(parts))
+torch.cuda.synchronize()
+
+def gather(gathered, local):
+    h = local.cpu()
+    out = torch.empty(gathered.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, h)
+    gathered.copy_(out)
+
+ss = pa.ShardedSearcher(dist, "cosine", D, searcher=s, ctx=ctx, device=True, all_gather=gather)
+got, sc, cnt = ss.search_device_queries(None, k, emb.data_ptr(), docs)
+
+oemb, _ = orc.encode_tokens(desc, m.state_dict(), ids, mask)                    # the oracle: all documents, whole corpus
+assert np.abs(emb.cpu().numpy() - oemb).max() < 1e-4
+opos, osc, _ = orc.topk(emb.cpu().numpy(), corpus, k)                           # ranking of the GPU's own embeddings: bit-exact ids
+assert (got == opos * 3 + 2).all() and (cnt == k).all()
+assert np.abs(sc - osc.astype(np.float32)).max() < 1e-6
+opos2, _, _ = orc.topk(oemb, corpus, k)                                         # ... and of the oracle's embeddings: the same documents
+assert (np.sort(got, 1) == np.sort(opos2 * 3 + 2, 1)).mean() > 0.98
+# the same search from host queries gives the same answer
+got_h, sc_h, _ = ss.search_vectors(None, k, emb.cpu().numpy())
+assert (got_h == got).all() and (sc_h == sc).all()
+dist.barrier()
+m.close(); s.close(); ctx.close()
+dist.destroy_process_group()
+print("rank", rank, "ok", flush=True)
+"""
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -105,9 +173,17 @@ def free_port():
     return p
 
 
+def test_two_processes_encode_gather_search_with_device_queries(tmp_path):
+    _run_two(tmp_path, WORKER_E2E)
+
+
 def test_two_processes_share_a_corpus_through_the_device_protocol(tmp_path):
+    _run_two(tmp_path, WORKER)
+
+
+def _run_two(tmp_path, worker):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER)
+    script.write_text(worker)
     env = dict(os.environ, PCV_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2",
                OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
