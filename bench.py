@@ -41,8 +41,12 @@ def parse():
                          "off = the scan streams the f32 rows themselves (1536 B/vector)")
     ap.add_argument("--cpu-rows", type=int, default=int(os.environ.get("PCV_BENCH_CPU_ROWS", 1_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--collective", default=os.environ.get("PCV_BENCH_COLLECTIVE", "torch"), choices=["torch", "native"],
-                    help="N>1 hit-list exchange: torch.distributed's RCCL group, or the library's own RCCL communicator")
+    ap.add_argument("--collective", default=os.environ.get("PCV_BENCH_COLLECTIVE", "torch"), choices=["torch", "native", "both"],
+                    help="N>1 hit-list exchange of the TIMED steps: torch.distributed's RCCL group (default), or the library's own RCCL "
+                         "communicator (native).  With torch the same steps are run once more through the native communicator AFTER the "
+                         "JSON line is out (figures on stderr as a `native_check` line and in gpurun_out/native_check.json): a failure "
+                         "there leaves the line as printed; `both` makes such a failure the exit status")
+    ap.add_argument("--no-e2e", action="store_true", help="N>1: skip the configs[4] end-to-end leg (encode -> gather -> sharded search)")
     ap.add_argument("--normalized", action="store_true", help="store unit-norm rows (MiniLM-like)")
     ap.add_argument("--clustered", action="store_true",
                     help="main leg on clustered rows (centroid + noise: ~2e4 rows within 0.01 cosine of every query's top-k)")
@@ -281,6 +285,106 @@ def e2e_leg(pa, ctx, searcher, rows, steps=5, warmup=4, batch=256, seq=256, k=10
     }
 
 
+def e2e_dist_leg(pa, ctx, dist, torch, sharded, rank, world, rehearse, rows, barrier, steps=5, warmup=3, batch=256, seq=256, k=10):
+    """BASELINE configs[4] on `world` GPUs: data-parallel encode of 256 documents x 256 tokens (f32, all-MiniLM-L6-v2 shape,
+    seeded weights), embeddings left on the devices (encode_tokens_device), one all-gather of 256 x 384 floats, then the
+    sharded exact top-10 of all 256 over the row-sharded corpus in two passes of 128 queries that read them from device memory
+    (ShardedSearcher.search_device_queries).  Returns rank 0's record (None elsewhere)."""
+    m = pa.Model(ctx, pa.minilm_l6_desc("f32"), synthetic_seed=1)
+    rng = np.random.default_rng(1)
+    ids = rng.integers(1000, 30000, (batch, seq)).astype(np.int64)
+    mask = np.ones((batch, seq), np.int64)
+    d0, d1 = batch * rank // world, batch * (rank + 1) // world
+    D = 384
+    emb = torch.zeros((batch, D), dtype=torch.float32, device="cuda")
+    even = (d1 - d0) * world == batch
+
+    def one():
+        m.encode_tokens_device(ids[d0:d1], mask[d0:d1], emb.data_ptr() + d0 * D * 4)
+        mine = emb[d0:d1].clone()
+        if rehearse:  # gloo: through the host
+            parts = [torch.empty((batch * (r + 1) // world - batch * r // world, D), dtype=torch.float32) for r in range(world)]
+            dist.all_gather(parts, mine.cpu())
+            emb.copy_(torch.cat(parts))
+        elif even:
+            dist.all_gather_into_tensor(emb, mine)
+        else:
+            parts = [torch.empty((batch * (r + 1) // world - batch * r // world, D), dtype=torch.float32, device="cuda") for r in range(world)]
+            dist.all_gather(parts, mine)
+            emb.copy_(torch.cat(parts))
+        torch.cuda.current_stream().synchronize()
+        outs = [sharded.search_device_queries(None, k, emb.data_ptr() + q0 * D * 4, min(128, batch - q0)) for q0 in range(0, batch, 128)]
+        return np.concatenate([o[0] for o in outs])
+
+    for _ in range(warmup):
+        got = one()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        got = one()
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    m.close()
+    if rank != 0:
+        return None
+    ms = 1e3 * float(el.item()) / steps
+    return {
+        "workload": f"encode batch={batch} x seq_len={seq} (MiniLM-L6 shape, f32) data-parallel over {world} GPUs + all-gather of the "
+                    f"embeddings (device) + exact top-{k} of the {batch} embeddings over {rows} x 384 row-sharded, {world} MI355X",
+        "ms_per_step": ms, "queries_per_s": batch / (ms * 1e-3), "n_gpus": world, "host_hops_of_the_embeddings": 0 if not rehearse else 1,
+        "sample_ids": [int(x) for x in got[0][:3]],
+    }
+
+
+def native_check(pa, ctx, dist, torch, searcher, queries, args, rank, world, last, barrier):
+    """The timed steps once more through the library's own RCCL communicator (pcv_searcher_search_sharded), after the JSON line
+    is out.  Reports on stderr and in gpurun_out/native_check.json; True if it ran and agreed with the torch path."""
+    rec = {"native_ok": False, "n_gpus": world}
+    comm = None
+    try:
+        comm = pa.NativeComm.from_dist(ctx, dist)
+        k = args.k
+        for i in range(args.warmup):
+            searcher.search_sharded(comm, None, k, queries[i])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            res = searcher.search_sharded(comm, None, k, queries[args.warmup + i])
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        same = bool((res[0] == last[0]).all()) and bool(np.array_equal(res[1], last[1]))
+        # the all-gather entry and the device-query form: this rank's queries gathered on the communicator, searched from device memory
+        q = np.ascontiguousarray(queries[args.warmup + args.steps - 1], np.float32)
+        per = q.nbytes
+        full = torch.zeros(world * q.size, dtype=torch.float32, device="cuda")
+        full[rank * q.size:(rank + 1) * q.size] = torch.from_numpy(q.reshape(-1)).cuda()
+        torch.cuda.synchronize()
+        comm.all_gather(full.data_ptr() + rank * per, full.data_ptr(), per)
+        res_dq = searcher.search_sharded_dq(comm, None, k, full.data_ptr(), q.shape[0])  # rank 0's slot: the same queries on every rank
+        same_dq = bool((res_dq[0] == last[0]).all())
+        rec.update({"native_ok": same and same_dq, "native_ms_per_step": 1e3 * float(el.item()) / args.steps,
+                    "native_equals_torch": same, "native_device_queries_equal": same_dq})
+    except Exception as e:  # noqa: BLE001 - reported, not raised: the line is out
+        rec["native_error"] = f"{type(e).__name__}: {e}"
+    finally:
+        try:
+            if comm is not None:
+                comm.close()
+        except Exception:
+            pass
+    if rank == 0:
+        print("native_check: " + json.dumps(rec), file=sys.stderr, flush=True)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "native_check.json"), "w") as f:
+                json.dump(rec, f)
+        except OSError:
+            pass
+    return rec["native_ok"]
+
+
 def measured_traffic(leg, kernel, required_bytes):
     """HBM bytes per launch from the committed PMC passes of this file's legs (profiles/traffic.json, written by
     tools/summarize_profiles.py; FETCH_SIZE x2 + WRITE_SIZE per the gfx950 guide): the entry of THIS leg, and only if
@@ -323,7 +427,13 @@ def main():
 
     dist = torch = None
     use_dist = world > 1 or os.environ.get("PCV_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal
+    line_out = sys.stdout
     if use_dist:
+        # stdout carries ONE JSON line.  RCCL prints a banner (version, host, library path) on stdout when its first
+        # communicator comes up: from here on file descriptor 1 is stderr, and the line goes out through a copy of the real one.
+        sys.stdout.flush()
+        line_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         # torch first: its bundled HIP runtime must be the one both it and libperceive_hip.so bind
         import torch
         import torch.distributed as dist
@@ -381,6 +491,7 @@ def main():
         # exchange of the [B][k] hit lists: torch.distributed's RCCL group (default), or the library's own
         # persistent RCCL communicator (pcv_comm_*; torch then only bootstraps the id and times the job)
         comm = pa.NativeComm.from_dist(ctx, dist) if args.collective == "native" else None
+        want_native_check = args.collective in ("torch", "both") and not rehearse  # (world 1: only under PCV_BENCH_FORCE_DIST, a rehearsal of this code)
         gather = None
         if rehearse:  # gloo has no device all-gather: stage through the host (torch copies on the current stream)
             def gather(gathered, local):
@@ -439,6 +550,12 @@ def main():
         mean_scan_ms = float(sm.item())
     else:
         mean_scan_ms = float(np.mean(scan_ms))
+
+    e2e_dist = None
+    if use_dist and world > 1 and not args.no_e2e and args.dim == 384 and not args.clustered:
+        # BASELINE configs[4] at this N: every rank encodes its share of 256 documents, the embeddings stay on the devices,
+        # one all-gather completes them on every rank, two sharded passes of 128 queries read them from device memory
+        e2e_dist = e2e_dist_leg(pa, ctx, dist, torch, sharded, rank, world, rehearse, total_rows, barrier)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -577,10 +694,17 @@ def main():
             if want("encoder_bertbase_64x256"):
                 extra["encoder_bertbase_64x256"] = encoder_leg(pa, ctx, "f32", batch=64, seq=256, shape="bert_base")
             out["extra"] = extra
+        if e2e_dist is not None:
+            out["extra"] = {"config5_end_to_end": e2e_dist}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=line_out, flush=True)
 
+    native_failed = False
+    if use_dist and comm is None and want_native_check:
+        # the library's own communicator (pcv_comm_*, ncclAllGather on its stream, no PyTorch in the data path) on the same
+        # steps, after the line above is out: what a Rust / C++ host binds.  It has never had more than one GPU to run on.
+        native_failed = not native_check(pa, ctx, dist, torch, searcher, queries, args, rank, world, last, barrier)
     if use_dist and comm is not None:
         comm.close()
     if searcher is not None:
@@ -588,6 +712,8 @@ def main():
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    if native_failed and args.collective == "both":
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":
