@@ -130,7 +130,10 @@ pcv_status pcv_searcher_clear_source(pcv_searcher* s, int64_t source_id);
  * place only once it exists): the rows of source `from_source_id` become the rows of `to_source_id`, whose old rows
  * are dropped; `from_source_id` disappears.  `from` unknown or empty: `to` is left absent (search.rs:67-69).  Build
  * the replacement under a staging id (add_* + finalize: a failure on the way leaves `to` untouched — clear the
- * staging id then), swap, finalize.  PCV_STAGING_SOURCE is the id this library's own loaders stage under. */
+ * staging id then), swap, finalize.  PCV_STAGING_SOURCE is the id this library's own loaders stage under: rows under it are
+ * not counted (pcv_searcher_num_rows / num_sources / source_ids) and a search of "every source" (source_ids = NULL) does not
+ * see them; between pcv_searcher_add_* and the next pcv_searcher_finalize every search fails (rows without scales), as after
+ * any add — a rebuild has to be serialised against searches by the caller, like Searcher::rebuild_source's &mut self. */
 #define PCV_STAGING_SOURCE INT64_MIN
 pcv_status pcv_searcher_replace_source(pcv_searcher* s, int64_t from_source_id, int64_t to_source_id);
 /* Pack pending rows into the HBM layout, compute row norms (set_searching_mode, search.rs:150). */

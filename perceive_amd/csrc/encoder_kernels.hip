@@ -552,6 +552,10 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
 // (32 x N/4 per wave and K half), so a CU still runs two waves per SIMD and the K loop has half as many barrier-separated steps.
 // The two K halves meet in LDS in the epilogue (two row-major 32 x N tiles in the staging buffers), which adds them with bias
 // and residual.  Same v_mfma_f32_32x32x2_f32 arithmetic; the sum over K is formed as two partial sums.
+// (Measured and dropped: no W value is used by two waves here — one 32-row MFMA tile per workgroup — so a form without LDS
+// staging and without barriers in the K loop suggests itself: every lane loads its operands' 16 consecutive floats straight
+// from global memory, the next step's 16 loads in flight under 48 MFMAs, as the skinny GEMM does.  2.35 ms per 32 x 256 forward
+// against 2.13 ms: 32 rows x 64 bytes per load instruction keep the address path busy four times as long as full lines do.)
 // ------------------------------------------------------------------------------------------------
 constexpr int L32M = 32, L32K = 64, L32T = L32K + 4;
 template <int CT>

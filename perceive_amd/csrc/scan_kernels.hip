@@ -215,6 +215,43 @@ __device__ __forceinline__ int ceil_class(const ScanParams& p, int q, float s) {
     return s < lo ? 0 : (s > hi ? 2 : 1);
 }
 
+// The same by a group of eight lanes (lane `sub` of 8; the eight groups of a wave offer eight different (query, score) pairs at
+// once): the drain wave of scan_mfma8_kernel's DRAIN form raises the thresholds of up to eight queries in the three round trips
+// one offer takes.  `active`: this group has an offer (all eight lanes agree); lanes of idle groups do nothing.
+__device__ __forceinline__ void offer_slot_g8(const ScanParams& p, bool active, int q, float s, int sub) {
+    const uint32_t key = f32_key(s);
+    uint32_t* sl = p.slots + (size_t)q * kMaxK;
+    for (int attempt = 0; attempt < 8 && __any(active); ++attempt) {
+        unsigned long long best = ~0ull;  // (key << 32 | slot), minimum
+        if (active)
+            for (int i = sub; i < p.k; i += 8) {
+                const unsigned long long c = ((unsigned long long)ld_relaxed(&sl[i]) << 32) | (uint32_t)i;
+                best = c < best ? c : best;
+            }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            const unsigned long long o = shfl_xor_u64(best, off);
+            best = o < best ? o : best;
+        }
+        const uint32_t mn = (uint32_t)(best >> 32), mi = (uint32_t)best;
+        if (active && key <= mn) active = false;  // k rows at or above it are there already
+        uint32_t old = 0;
+        if (active && sub == 0) old = g_atomic_cas(&sl[mi], mn, key);
+        old = (uint32_t)__shfl((int)old, (threadIdx.x & 63) & ~7);
+        if (active && old == mn) {  // the slot is ours: the new minimum is the threshold
+            uint32_t nm = 0xffffffffu;
+            for (int i = sub; i < p.k; i += 8) nm = min(nm, ld_relaxed(&sl[i]));
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) nm = min(nm, (uint32_t)__shfl_xor((int)nm, off));
+            if (sub == 0) {
+                g_atomic_max(&p.tau[q * kHot], nm);
+                g_atomic_max(&p.tau_c[q], nm);
+            }
+            active = false;
+        }
+    }
+}
+
 // A surviving (query,row) pair of the wave kernel: append to the query's candidate list and, unless the
 // row was already ranked by the seed kernel, try to raise the running k-th best.
 __device__ __noinline__ void emit_hit(const ScanParams& p, int q, int seg, uint32_t row, float s,
@@ -1629,15 +1666,10 @@ __device__ __forceinline__ void drain_survivors(const ScanParams& p, SurvRing& r
                 gst(&p.cand_s[(size_t)q * p.cand_cap + at], s32);
             }
         }
-        const bool offer = cand && cc == 0 && sub == 0 && !is_seed_block(p, si, lb) && isfinite(s32) && s32 > taun;
-        unsigned long long ob = __ballot(offer);
-        while (ob) {
-            const int osrc = __builtin_ctzll(ob);
-            ob &= ob - 1;
-            const int oq = __builtin_amdgcn_readlane(q, osrc);
-            const float os = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s32), osrc));
-            offer_slot_wave(p, oq, os, lane);
-        }
+        // the offers to the running top-k, all groups at once (one after the other by the whole wave they were three round trips
+        // each, and the thresholds of a pass rise through exactly these)
+        const bool offer = cand && cc == 0 && !is_seed_block(p, si, lb) && isfinite(s32) && s32 > taun;
+        if (__any(offer)) offer_slot_g8(p, offer, q, s32, sub);
         PCV_DCOUNT(5, __builtin_amdgcn_s_memrealtime() - ts)
         PCV_DCOUNT(6, 1)
     };
@@ -1786,10 +1818,18 @@ __device__ __forceinline__ void drain_survivors(const ScanParams& p, SurvRing& r
 // s_waitcnt vmcnt(8).  In the run-time form the compiler cannot relate `cons.ch == NCH - 2` (where the request is made) to
 // `++cons.ch == NCH` (where it is used), has to allow for the one-chunk case that asks inside the test, and ends EVERY block
 // with s_waitcnt vmcnt(0): each block then waited for the chunk requested a moment before.
+// (Measured and dropped, round 4: the thresholds through LDS for the forms WITHOUT a drain wave as well — the 128-query tile at
+// 385..1024 features — with wave 0 of the workgroup as their keeper: it fetched the side-by-side copy at every chunk step through a
+// buffer descriptor that is empty for the other waves (an out-of-range load makes no memory request, and all waves execute the same
+// instructions) and renewed U for all queries.  Same survivors as with every wave fetching for itself, 3.20 against 3.01 ms at
+// 30M x 512 / 128 queries, 8.4 against 7.0 ms at 50M x 768 while U was still read two steps before the test: there a block is
+// 16-24 KB and takes tens of microseconds, the 128-line gather per block is not what bounds it, and a keeper that is itself
+// busy in the fine screen keeps everybody's thresholds waiting.)
 template <int NT, bool NTL, int WPB, int NBUF, bool DRAIN, int NCHT>
 __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(const ScanParams* __restrict__ pp) {
     const ScanParams& p = *pp;
     constexpr uint32_t SW = DRAIN ? WPB - 1 : WPB;  // streaming waves of a workgroup
+    constexpr bool ULDS = DRAIN;                    // the test's U_q comes from LDS
     extern __shared__ uint4 lq8[];  // [NT*32][LDQ] pieces of 16 int8
     const int D4 = p.D4;
     const int Dp = D4 * 4;
@@ -1827,13 +1867,15 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     const int c = lane & 31, h = lane >> 5;
     const float nrm = (p.metric == PCV_METRIC_DOT) ? p.max_norm : 1.0f;
     const float c1 = 0.5002f * sqrtf((float)Dp8) * nrm;
-    if constexpr (DRAIN) {  // the first U of every query (the drain wave keeps them fresh from here on)
-        for (int q = threadIdx.x; q < NT * 32; q += WPB * 64) {
-            const float sqq = lsq[q];
-            const float T = (key_f32(max(ltau0[q], ld_relaxed(&p.tau_c[q]))) - (q < p.B ? 0.5f * gld(&p.margin32[q]) : 0.0f)) * sqq;
-            const float dead = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
-            lU[q] = (q < p.B) ? (sqq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead) : __builtin_inff();
-        }
+    const float dead_u = (p.metric == PCV_METRIC_DOT) ? -__builtin_inff() : __builtin_inff();
+    // U_q of the test for the running threshold `tau_key` (derivation: the epilogue below)
+    auto u_of = [&](int q, uint32_t tau_key, float e32q) -> float {
+        const float sqq = lsq[q];
+        const float T = (key_f32(max(ltau0[q], tau_key)) - e32q) * sqq;
+        return (q < p.B) ? (sqq != 0.0f ? (T - fabsf(T) * 2e-6f) - c1 : dead_u) : __builtin_inff();
+    };
+    if constexpr (ULDS) {  // the first U of every query (the drain wave keeps them fresh from here on)
+        for (int q = threadIdx.x; q < NT * 32; q += WPB * 64) lU[q] = u_of(q, ld_relaxed(&p.tau_c[q]), q < p.B ? 0.5f * gld(&p.margin32[q]) : 0.0f);
         __syncthreads();
     }
     float sq[NT], vq[NT], e32[NT];
@@ -1906,12 +1948,11 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
     // thresholds and the quantisation scale of the block being finished, requested one chunk ahead of the epilogue:
     // lane (c, h) tests rows 4h + {0..3, 8..11, 16..19, 24..27} of the block
     uint32_t tauk[NT];
-    float Uk[NT];  // DRAIN form: U_q as the drain wave last wrote it (LDS) instead of the thresholds themselves
     float sblk = 0.0f;
     auto prefetch = [&]() __attribute__((always_inline)) {  // (before the step's row loads and untouched until the epilogue: see scan_mfma_kernel)
-        if constexpr (DRAIN) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) Uk[t] = __hip_atomic_load(&lU[32 * t + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (ULDS) {
+            // (U itself is read in the epilogue, at the moment of the test: an LDS read costs the block ~100 cycles, and while the
+            // thresholds rise fast — the first blocks of a pass — a value read two chunk steps earlier let twice the rows through)
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) tauk[t] = ld_relaxed(&p.tau[(32 * t + c) * kHot]);
@@ -1930,8 +1971,16 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
         float U[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if constexpr (DRAIN) {
-                U[t] = Uk[t];
+            if constexpr (ULDS) {
+                U[t] = __hip_atomic_load(&lU[32 * t + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if PCV_EXP == 12  // experiment: is the U from LDS behind the thresholds?  (the fresh value beside it)
+                {
+                    const int q = 32 * t + c;
+                    const float Tf = (key_f32(max(tau0[t], ld_relaxed(&p.tau[q * kHot]))) - e32[t]) * sq[t];
+                    const float Uf = (q < p.B) ? (sq[t] != 0.0f ? (Tf - fabsf(Tf) * 2e-6f) - c1 : dead_u) : __builtin_inff();
+                    U[t] = fmaxf(U[t], Uf);
+                }
+#endif
                 continue;
             }
             const int q = 32 * t + c;

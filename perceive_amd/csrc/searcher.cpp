@@ -697,7 +697,9 @@ std::vector<SelSeg> select_segments(pcv_searcher* s, const int64_t* source_ids, 
     std::vector<SelSeg> out;
     const bool all = source_ids == nullptr;
     for (const auto& src : s->sources) {
-        bool sel = all;
+        // rows staged for a rebuild (PCV_STAGING_SOURCE) are nobody's rows yet: "every source" does not mean them — between the
+        // staging finalize and the swap an all-sources search would otherwise return the new rows beside the old ones
+        bool sel = all && src.id != PCV_STAGING_SOURCE;
         for (int i = 0; i < n_sources && !sel; ++i) sel = (source_ids[i] == src.id);  // search.rs:166
         if (!sel) continue;
         for (const auto& g : src.segs)
@@ -1504,7 +1506,8 @@ pcv_status pcv_searcher_num_rows(pcv_searcher* s, int64_t* out_rows) {
         PCV_REQUIRE(s != nullptr && out_rows != nullptr, "num_rows: NULL argument");
         std::lock_guard<std::mutex> lk(s->mu);
         int64_t n = 0;
-        for (auto& src : s->sources) n += src.rows();
+        for (auto& src : s->sources)
+            if (src.id != PCV_STAGING_SOURCE) n += src.rows();  // (staged rows are not the searcher's rows yet)
         *out_rows = n;
     });
 }
@@ -1523,7 +1526,9 @@ pcv_status pcv_searcher_num_sources(pcv_searcher* s, int* out_n) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr && out_n != nullptr, "num_sources: NULL argument");
         std::lock_guard<std::mutex> lk(s->mu);
-        *out_n = (int)s->sources.size();
+        int n = 0;
+        for (const auto& src : s->sources) n += src.id != PCV_STAGING_SOURCE ? 1 : 0;
+        *out_n = n;
     });
 }
 
@@ -1531,8 +1536,12 @@ pcv_status pcv_searcher_source_ids(pcv_searcher* s, int64_t* out_ids, int cap) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr && out_ids != nullptr, "source_ids: NULL argument");
         std::lock_guard<std::mutex> lk(s->mu);
-        PCV_REQUIRE(cap >= (int)s->sources.size(), "source_ids: capacity %d < %zu sources", cap, s->sources.size());
-        for (size_t i = 0; i < s->sources.size(); ++i) out_ids[i] = s->sources[i].id;
+        size_t n = 0;
+        for (const auto& src : s->sources) n += src.id != PCV_STAGING_SOURCE ? 1 : 0;
+        PCV_REQUIRE(cap >= (int)n, "source_ids: capacity %d < %zu sources", cap, n);
+        n = 0;
+        for (const auto& src : s->sources)
+            if (src.id != PCV_STAGING_SOURCE) out_ids[n++] = src.id;
     });
 }
 

@@ -171,6 +171,41 @@ def test_rebuild_of_one_source_is_atomic(ctx, oracle, tmp_path):
     s.close()
 
 
+def test_staged_rows_are_nobodys_rows_until_the_swap(ctx, oracle):
+    """Between the staging finalize and pcv_searcher_replace_source the new rows of a source are resident beside the old ones
+    (PCV_STAGING_SOURCE).  They are not counted and a search of every source does not see them — the reference swaps a finished
+    SourceSearch in one step (search.rs:57-79), so no caller ever sees both generations."""
+    rng = np.random.default_rng(8)
+    D = 32
+    old = rng.standard_normal((200, D)).astype(np.float32)
+    new = (old[:50] * 1.5).astype(np.float32)  # the replacement of source 2: scaled copies, they would tie or win under dot
+    q = rng.standard_normal((4, D)).astype(np.float32)
+    s = pa.Searcher(ctx, D, "dot")
+    s.add_rows(1, old[:100], np.arange(100))
+    s.add_rows(2, old[100:], np.arange(100, 200))
+    s.finalize()
+    before = s.search_vectors(None, 10, q)
+    s.add_rows(pa.search.STAGING_SOURCE, new, 1000 + np.arange(50))
+    s.finalize()  # staged and searchable by id, but nobody's rows yet
+    assert s.num_rows == 200 and sorted(s.source_ids) == [1, 2]
+    during = s.search_vectors(None, 10, q)
+    np.testing.assert_array_equal(during[0], before[0])
+    np.testing.assert_array_equal(during[1], before[1])
+    staged = s.search_vectors([pa.search.STAGING_SOURCE], 5, q)  # named explicitly they can be searched (the loaders do not)
+    assert (staged[0] >= 1000).all()
+    from perceive_amd import _ffi
+    _ffi.check(_ffi.lib().pcv_searcher_replace_source(s._handle, pa.search.STAGING_SOURCE, 2))
+    s.finalize()
+    assert s.num_rows == 150 and sorted(s.source_ids) == [1, 2]
+    m = np.concatenate([old[:100], new])
+    ids = np.concatenate([np.arange(100), 1000 + np.arange(50)])
+    got = s.search_vectors(None, 10, q)
+    for b in range(4):
+        oi, _ = oracle.search_vector(q[b], m, ids, np.concatenate([np.full(100, 1), np.full(50, 2)]), [1, 2], 10)
+        assert list(got[0][b]) == list(oi)
+    s.close()
+
+
 def test_replace_source_swaps_and_keeps_the_order_of_sources(ctx, oracle):
     """pcv_searcher_replace_source: `from` takes `to`'s place (global positions of the other sources do not move), an unknown
     or empty `from` leaves `to` absent (search.rs:67-69), a source cannot replace itself."""

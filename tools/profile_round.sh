@@ -42,6 +42,7 @@ legs=(
   "d768_dot_b1|--steps 10 --rows 100000000 --only d768_dot_b1"
   "config2_10m_b1|--no-extra --steps 20 --rows 10000000 --batch 1"
   "shard_12p5m_b64|--no-extra --steps 20 --rows 12500000"
+  "shard_12p5m_b256|--steps 10 --only shard_12p5m_b256"
 )
 if [ "$PART" = stats ]; then
   for l in "${legs[@]}"; do
@@ -52,6 +53,8 @@ if [ "$PART" = stats ]; then
   run prof_encoder_256x256 --kernel-trace --stats --output-format csv -d $G/prof_encoder_256x256 -o p -- $BENCH --steps 3 --rows 1000000 --only encoder_256x256
   run prof_encoder_256x256_split_precision --kernel-trace --stats --output-format csv -d $G/prof_encoder_256x256_split_precision -o p -- $BENCH --steps 3 --rows 1000000 --only encoder_256x256_split_precision
   run prof_encoder_bertbase_64x256 --kernel-trace --stats --output-format csv -d $G/prof_encoder_bertbase_64x256 -o p -- $BENCH --steps 3 --rows 1000000 --only encoder_bertbase_64x256
+  run prof_encoder_32x256 --kernel-trace --stats --output-format csv -d $G/prof_encoder_32x256 -o p -- $BENCH --steps 3 --rows 1000000 --only encoder_32x256
+  run prof_encoder_64x256 --kernel-trace --stats --output-format csv -d $G/prof_encoder_64x256 -o p -- $BENCH --steps 3 --rows 1000000 --only encoder_64x256
 else
   for l in "${legs[@]}"; do
     name=${l%%|*}; args=${l#*|}

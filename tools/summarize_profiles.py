@@ -11,7 +11,7 @@ tools/profile_round.sh) into the committed summaries under profiles/:
 PMC passes are corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes for gfx950 (FETCH_SIZE counts 64 B
 per 128 B request on wide coalesced streaming reads: x2; WRITE_SIZE exact; both in KiB).
 
-    python tools/summarize_profiles.py r03
+    python tools/summarize_profiles.py r04
 """
 import csv
 import glob
@@ -38,8 +38,9 @@ SCAN_LEGS = [
     ("d768_dot_b1", "d768_dot_b1", "d768_dot_b1"),
     ("config2_10m_b1", "config2_10m_b1", None),
     ("shard_12p5m_b64", "shard_12p5m_b64", None),
+    ("shard_12p5m_b256", "shard_12p5m_b256", "shard_12p5m_b256"),
 ]
-ENC_LEGS = ["encoder_256x256", "encoder_256x256_split_precision", "encoder_bertbase_64x256", "config5_end_to_end"]
+ENC_LEGS = ["encoder_256x256", "encoder_256x256_split_precision", "encoder_bertbase_64x256", "encoder_32x256", "encoder_64x256", "config5_end_to_end"]
 
 
 def newest(pattern):
@@ -114,7 +115,7 @@ def short(name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     os.makedirs(OUT, exist_ok=True)
     summary, traffic = {}, {}
     for leg, suffix, key in SCAN_LEGS:
