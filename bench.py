@@ -174,8 +174,19 @@ def scan_leg(pa, ctx, rows, batch, k, kernel, steps, warmup, seed=0x5EED, cluste
         queries = q.reshape(warmup + steps, batch, dim).astype(np.float32)
     else:
         queries = rng.standard_normal((warmup + steps, batch, dim)).astype(np.float32)
+    searcher.set_mid_copy("auto")
     for i in range(warmup):
         searcher.search_vectors(None, k, queries[i])
+    # AUTO decides from the passes it sees whether a mid copy pays and builds it beside the searches (a crowd at the coarse screen
+    # two passes in a row; at one query the count hovers around the trigger, so the decision can fall anywhere): the timed passes
+    # are one state or the other, not the build in between — a build under way is waited for, and a searcher that has not built
+    # one by now keeps none for this leg.
+    searcher.wait_background()
+    if not searcher.last_stats()["mid_copy"]:
+        searcher.search_vectors(None, k, queries[warmup - 1])
+        searcher.wait_background()
+        if not searcher.last_stats()["mid_copy"]:
+            searcher.set_mid_copy("off")
     ctx.synchronize()
     scan_ms, pass_ms, cands, coarse, mids, reruns, launches, spec_reruns, streamed = [], [], [], [], [], 0, 0, 0, 0
     wall = 0.0  # host time inside the search calls (query batch in host memory -> hits in host memory); reading the statistics is not part of a step
@@ -533,12 +544,24 @@ def main():
 
     for i in range(args.warmup):
         step(i, False)
+    # The searcher decides from its first passes whether a mid copy pays (two passes with a crowd at the coarse screen: the third
+    # call queues the build, beside the searches): the timed steps are the steady state, so with fewer than three warm-up steps
+    # the missing ones are made up for here (untimed, counted in `settle_passes`), and a build under way is waited for.
+    settle_passes = max(0, 3 - args.warmup)
+    for i in range(settle_passes):
+        step(i % max(args.warmup, 1), False)
+    searcher.wait_background()
+    step(0, False)  # (a pass that would use a copy finished a moment ago; in every rank alike)
+    settle_passes += 1
+    if not searcher.last_stats()["mid_copy"]:  # (no copy by now: none during the timed steps either — every rank for itself)
+        searcher.set_mid_copy("off")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    searcher.set_mid_copy("auto")
 
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
@@ -584,6 +607,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_passes": settle_passes,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": args.scaling,

@@ -216,6 +216,11 @@ pcv_status pcv_searcher_set_screening_copy(pcv_searcher* s, int mode);
  *   PCV_MID_COPY_OFF   : never built; an existing one is freed */
 enum { PCV_MID_COPY_OFF = 0, PCV_MID_COPY_AUTO = 1, PCV_MID_COPY_ON = 2 };
 pcv_status pcv_searcher_set_mid_copy(pcv_searcher* s, int mode);
+/* AUTO builds the mid copy BESIDE the searches (a stream and a helper thread of its own): the search call that decides to
+ * build it returns like any other, and so do the calls after it, without the copy, until it is complete — while it is being
+ * built they share the memory system with the build.  This call waits for such a build to finish (a benchmark that wants
+ * the steady state; nothing needs it for correctness).  Returns at once when nothing is under way. */
+pcv_status pcv_searcher_wait_background(pcv_searcher* s);
 
 /* Most hits ONE PASS over the rows ranks per query.  pcv_searcher_search takes any num_results (search.rs:157-182 has no limit;
  * the reference's callers ask for 10 and 20, perceive-cli's --num-results is user input): beyond this many it goes over the rows

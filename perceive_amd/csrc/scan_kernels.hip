@@ -456,13 +456,13 @@ __global__ __launch_bounds__(64) void mid_pack_block_kernel(const float4* __rest
         const float s2 = scale8[b] * (32766.0f / 127.0f);  // NaN: a block without a searchable row
         const bool searchable = sc != 0.0f && s2 == s2;
         const float4* src = blk + (size_t)b * D4 * 32 + h * 32 + r;  // piece 2j + h of row r: src + 64 j
-        for (int j0 = 0; j0 < P2; j0 += 8) {
-            float4 v[8];
+        for (int j0 = 0; j0 < P2; j0 += 16) {  // 16 KB of a block requested at a time (six waves a CU at 384-d: ~100 KB in flight)
+            float4 v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (j0 + u < P2) v[u] = ld_row<true>(src + (size_t)(j0 + u) * 64);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (j0 + u < P2) {
                     const float y[4] = {v[u].x * sc, v[u].y * sc, v[u].z * sc, v[u].w * sc};
                     int q[4];
@@ -2971,7 +2971,9 @@ void launch_scan_mfma8(hipStream_t st, const ScanParams& p, const ScanParams* dp
     if (NT == 8) PCV_FAIL(PCV_ERR_UNSUPPORTED, "int8 screen: %d queries in one pass need rows of at most 384 features", p.B);
     // Up to 64 queries: ONE 12-wave workgroup per CU, eleven waves stream and the twelfth works off their coarse survivors
     // (the survivor ring above).  Flag bit 28: the older form, three 4-wave workgroups per CU, every wave handling its own.
-    if (NT <= 2 && !(p.flags & (1u << 28)) && p.nseg < (1 << kRingSegBits) && lds + 68 * 1024 <= 156 * 1024) {
+    // (One to four queries keep the older form: their survivors are few, twelve streaming waves beat eleven — 10M x 768, one query:
+    // 1.16 against 1.20 ms; from eight queries on the drain form is ahead, 0.63 against 0.67 ms at 10M x 384 / 16 queries.)
+    if (NT <= 2 && p.B > 4 && !(p.flags & (1u << 28)) && p.nseg < (1 << kRingSegBits) && lds + 68 * 1024 <= 156 * 1024) {
         constexpr unsigned kW = 12;
         unsigned g12 = (unsigned)num_cus * (gm ? gm : 1u);
         g12 = std::min(g12, (p.total_blocks + (kW - 2)) / (kW - 1));

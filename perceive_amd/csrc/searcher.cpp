@@ -1639,6 +1639,15 @@ pcv_status pcv_searcher_set_mid_copy(pcv_searcher* s, int mode) {
     });
 }
 
+pcv_status pcv_searcher_wait_background(pcv_searcher* s) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "wait_background: searcher is NULL");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_HIP(hipSetDevice(s->ctx->device));
+        settle_mid_build(s, true);
+    });
+}
+
 pcv_status pcv_searcher_set_candidate_capacity(pcv_searcher* s, uint32_t n_candidates) {
     return guarded([&] {
         PCV_REQUIRE(s != nullptr, "set_candidate_capacity: searcher is NULL");

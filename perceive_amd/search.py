@@ -266,6 +266,10 @@ class Searcher:
     def set_kernel(self, kernel="auto"):
         _ffi.check(_ffi.lib().pcv_searcher_set_kernel(self._handle, _KERNELS[kernel]))
 
+    def wait_background(self):
+        """Wait for a mid copy that AUTO is building beside the searches (pcv_searcher_wait_background)."""
+        _ffi.check(_ffi.lib().pcv_searcher_wait_background(self._handle))
+
     def set_candidate_capacity(self, n_candidates):
         """Initial rows per query of a pass's candidate lists (tuning; a pass that needs more repeats itself)."""
         _ffi.check(_ffi.lib().pcv_searcher_set_candidate_capacity(self._handle, int(n_candidates)))

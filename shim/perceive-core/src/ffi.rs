@@ -172,6 +172,7 @@ extern "C" {
     pub fn pcv_searcher_set_tuning(s: *mut pcv_searcher, flags: u32) -> c_int;
     pub fn pcv_searcher_set_screening_copy(s: *mut pcv_searcher, mode: c_int) -> c_int;
     pub fn pcv_searcher_set_mid_copy(s: *mut pcv_searcher, mode: c_int) -> c_int;
+    pub fn pcv_searcher_wait_background(s: *mut pcv_searcher) -> c_int;
     pub fn pcv_searcher_search(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;
     pub fn pcv_searcher_set_shard_offset(s: *mut pcv_searcher, first_global_pos: i64) -> c_int;
     pub fn pcv_searcher_search_device(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void, async_: c_int) -> c_int;

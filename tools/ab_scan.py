@@ -53,6 +53,8 @@ def main():
             for f in flags:
                 s.set_tuning(f)
                 ids, sc, _ = s.search_vectors(None, args.k, qs[r])
+                if r < 2:
+                    s.wait_background()  # (AUTO's mid copy is built beside the searches: the timed rounds are the steady state)
                 st = s.last_stats()
                 if ref is None:
                     ref = ids

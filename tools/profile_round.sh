@@ -3,8 +3,10 @@
 # kernel each leg names has a kept kernel-trace summary, and the scan legs a FETCH_SIZE / WRITE_SIZE pass each
 # (counters in their own runs, kernel-trace only besides them).
 # Run on the GPU box, one part per call (a part takes 8-12 minutes):
-#   gpurun --timeout 1100 -- "bash tools/profile_round.sh stats"
-#   gpurun --timeout 1100 -- "bash tools/profile_round.sh pmc"
+#   gpurun --timeout 1100 -- "bash tools/profile_round.sh stats"      (the scan legs)
+#   gpurun --timeout 1100 -- "bash tools/profile_round.sh encoders"   (the encoder and end-to-end legs)
+#   gpurun --timeout 1100 -- "bash tools/profile_round.sh pmc 0 6"    (FETCH / WRITE passes of scan legs 0..5)
+#   gpurun --timeout 1100 -- "bash tools/profile_round.sh pmc 6 12"
 R=$GRAFT_REPO_ROOT
 PART=${1:-stats}
 cd /tmp && export TMPDIR=/tmp
@@ -49,6 +51,7 @@ if [ "$PART" = stats ]; then
     name=${l%%|*}; args=${l#*|}
     run prof_$name --kernel-trace --stats --output-format csv -d $G/prof_$name -o p -- $BENCH $args
   done
+elif [ "$PART" = encoders ]; then
   run prof_config5_end_to_end --kernel-trace --stats --output-format csv -d $G/prof_config5_end_to_end -o p -- $BENCH --steps 5 --only config5_end_to_end
   run prof_encoder_256x256 --kernel-trace --stats --output-format csv -d $G/prof_encoder_256x256 -o p -- $BENCH --steps 3 --rows 1000000 --only encoder_256x256
   run prof_encoder_256x256_split_precision --kernel-trace --stats --output-format csv -d $G/prof_encoder_256x256_split_precision -o p -- $BENCH --steps 3 --rows 1000000 --only encoder_256x256_split_precision
@@ -56,7 +59,8 @@ if [ "$PART" = stats ]; then
   run prof_encoder_32x256 --kernel-trace --stats --output-format csv -d $G/prof_encoder_32x256 -o p -- $BENCH --steps 3 --rows 1000000 --only encoder_32x256
   run prof_encoder_64x256 --kernel-trace --stats --output-format csv -d $G/prof_encoder_64x256 -o p -- $BENCH --steps 3 --rows 1000000 --only encoder_64x256
 else
-  for l in "${legs[@]}"; do
+  FROM=${2:-0}; TO=${3:-${#legs[@]}}
+  for l in "${legs[@]:$FROM:$((TO-FROM))}"; do
     name=${l%%|*}; args=${l#*|}
     args=${args/--steps 10/--steps 3}; args=${args/--steps 20/--steps 3}
     run pmc_fetch_$name --pmc FETCH_SIZE --kernel-trace --output-format csv -d $G/pmc_fetch_$name -o p -- $BENCH $args
