@@ -555,7 +555,9 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
 // (Measured and dropped: no W value is used by two waves here — one 32-row MFMA tile per workgroup — so a form without LDS
 // staging and without barriers in the K loop suggests itself: every lane loads its operands' 16 consecutive floats straight
 // from global memory, the next step's 16 loads in flight under 48 MFMAs, as the skinny GEMM does.  2.35 ms per 32 x 256 forward
-// against 2.13 ms: 32 rows x 64 bytes per load instruction keep the address path busy four times as long as full lines do.)
+// against 2.13 ms: 32 rows x 64 bytes per load instruction keep the address path busy four times as long as full lines do.
+// Also dropped: 32-wide K steps through two 60 KB staging buffers, the next step's operands written under this step's multiplies
+// and one barrier a step: 2.27 ms — twice the barriers for 24 multiplies per wave and step cost more than the overlap gives.)
 // ------------------------------------------------------------------------------------------------
 constexpr int L32M = 32, L32K = 64, L32T = L32K + 4;
 template <int CT>
