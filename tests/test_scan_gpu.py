@@ -329,6 +329,31 @@ def test_candidate_overflow_reruns_and_stays_exact(ctx, oracle):
         s.close()
 
 
+@pytest.mark.parametrize("B", [5, 64])
+def test_survivor_ring_when_every_row_passes_the_coarse_screen(ctx, oracle, B):
+    # The DRAIN form of the int8 scan (5..64 queries): streaming waves write coarse survivors into an LDS ring that one drain wave
+    # per CU works off.  Here nearly every (row, query) pair survives the coarse test — the rows are one vector plus noise far
+    # below the int8 margin, the queries are that vector — so every wave fills the ring at every block and has to wait for room,
+    # the candidate lists overflow and the pass is repeated with longer ones: no hang, exact hits (ties by position).
+    rng = np.random.default_rng(4)
+    N, D = 48_000, 128
+    v = rng.standard_normal(D).astype(np.float32)
+    m = (v[None, :] + 1e-4 * rng.standard_normal((N, D))).astype(np.float32)
+    m[1000:1010] = v  # ten exact copies: cosine 1, ranked by position
+    q = np.repeat(v[None, :], B, 0) + (1e-5 * rng.standard_normal((B, D))).astype(np.float32)
+    q[0] = v
+    s = build(ctx, m, kernel="mfma", screen="int8")
+    ids, scores, counts = s.search_vectors(None, 10, q)
+    st = s.last_stats()
+    opos, osc, _ = oracle.topk(q, m, 10)
+    np.testing.assert_array_equal(ids, opos)
+    assert list(ids[0]) == list(range(1000, 1010))
+    assert np.abs(scores - osc.astype(np.float32)).max() < 1e-6
+    assert st["coarse_survivors"] > 0.5 * N * B, st  # nearly every pair, at every launch
+    assert st["overflow_reruns"] >= 1, st
+    s.close()
+
+
 def test_many_sources_one_launch(ctx, oracle):
     # 11 sources -> 11 segments: one launch walks them all through the device segment table
     rng = np.random.default_rng(21)
@@ -1179,7 +1204,8 @@ def test_screening_copy_gives_way_when_memory_is_short(ctx, oracle, monkeypatch)
 
 @pytest.mark.parametrize("D,B,k", [(64, 1, 1), (100, 7, 10), (256, 33, 128), (512, 65, 10), (768, 128, 10), (1000, 5, 3), (1024, 64, 10), (384, 128, 128),
                                    (96, 100, 10), (256, 128, 10), (320, 65, 5),   # the block-holding form for 65..128 queries
-                                   (384, 256, 10), (200, 130, 7), (96, 300, 3)])   # ... and for 129..256 in one pass
+                                   (384, 256, 10), (200, 130, 7), (96, 300, 3),    # ... and for 129..256 in one pass
+                                   (640, 33, 10), (896, 64, 5), (640, 3, 4)])      # 5 / 7 chunks per block: the drain form's run-time chunk count
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
 def test_screens_agree_with_the_oracle_across_shapes(ctx, oracle, D, B, k, metric):
     """int8 / bf16 / no screening copy over widths, batch sizes and k that exercise every query-tile shape, three sources in
