@@ -22,6 +22,9 @@
 #include "scan.h"
 #include "synth.h"
 
+// Timing experiments of round 4 (tools/exp_build.sh <n> on the GPU box; results are WRONG in builds 7-9): 7 = the rows of 256 blocks over
+// and over (they come out of the L2), 8 = every block ends at its test (no survivor is handled), 9 = both, 12 = the thresholds
+// fetched by every wave beside the U from LDS (what the drain wave's lag costs in survivors).
 #ifndef PCV_EXP
 #define PCV_EXP 0
 #endif
@@ -1564,9 +1567,6 @@ __device__ __forceinline__ void drain_survivors(const ScanParams& p, SurvRing& r
 
     // one entry per lane group of eight (`on`: the group has one): everything after the coarse test
     auto work = [&](bool on, uint32_t hi, uint32_t lo) {
-#if PCV_EXP == 10  // timing experiment (wrong results): the drain wave throws the survivors away
-        return;
-#endif
 #ifdef PCV_STAMPS
         const unsigned long long ts = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1747,9 +1747,7 @@ __device__ __forceinline__ void drain_survivors(const ScanParams& p, SurvRing& r
             const bool keep = have && (float)eacc >= rhs;
             // likely: the estimate clears the threshold by less than a quarter of the margin (margin = s_blk T - rhs)
             const bool likely = keep && (float)eacc >= fmaf(0.25f, rhs, 0.75f * esb * Tq);
-#if PCV_EXP != 11
             if (have) g_atomic_add(&p.cand_cnt[eq * kHot + 32], 1u);  // statistics: coarse survivors
-#endif
             const unsigned long long wait = __ballot(keep && !likely);
             const uint32_t nw = (uint32_t)__builtin_popcountll(wait);
             PCV_DCOUNT(4, n)
@@ -2094,16 +2092,6 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
             for (int j = 0; j < 4; ++j) buf[i][j] = ld_piece<NTL>(prod.rows, lane_off + (uint32_t)j * 1024u, (uint32_t)(i % NCHT) * 4096u);
             if ((i % NCHT) == NCHT - 1 && prod.gb < p.total_blocks) enter_block(prod, prod.gb + total_waves);
         }
-#if PCV_EXP == 6
-        i32x16 dummy;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dummy[i] = 0;
-#endif
-#if PCV_EXP == 1
-        i32x4 qfix[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) qfix[t] = *(const i32x4*)&lq8[(size_t)(32 * t + c) * LDQ + h];
-#endif
         auto step = [&](auto S) __attribute__((always_inline)) -> bool {  // true: the wave's stream is over
                 constexpr int s = decltype(S)::value;
                 constexpr int ch = s % NCHT, pch = (s + NBUF - 1) % NCHT;
@@ -2124,26 +2112,8 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
                         const int pc = 2 * (ch * 4 + ks) + h;
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
-#if PCV_EXP == 1  // timing experiment (wrong results): no LDS reads in the loop
-                            const i32x4 q8 = qfix[t];
-#else
                             const i32x4 q8 = *(const i32x4*)&lq8[(size_t)(32 * t + c) * LDQ + pc];
-#endif
-#if PCV_EXP == 2  // timing experiment: half the multiplies
-                            if (t == 0) acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
-                            else asm volatile("" ::"v"(q8));
-#else
                             acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, acc[t], 0, 0, 0);
-#endif
-#if PCV_EXP == 5  // timing experiment (results unchanged): half as many LDS reads again
-                            if (t == 0) {
-                                const i32x4 extra = *(const volatile i32x4*)&lq8[(size_t)(32 + c) * LDQ + (pc ^ 1)];
-                                asm volatile("" ::"v"(extra));
-                            }
-#endif
-#if PCV_EXP == 6  // timing experiment (results unchanged): half as many multiplies again
-                            if (t == 0) dummy = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, q8, dummy, 0, 0, 0);
-#endif
                         }
                     }
                     if constexpr (ch == NCHT - 1) {
@@ -2155,12 +2125,7 @@ __global__ __launch_bounds__(WPB * 64, NT == 4 ? 2 : 3) void scan_mfma8_kernel(c
                 return false;
         };
         while (true) {
-            if (static_for_until<0, PERIOD>(step)) {
-#if PCV_EXP == 6
-                asm volatile("" ::"v"(dummy));
-#endif
-                PCV_WAVE_DONE()
-            }
+            if (static_for_until<0, PERIOD>(step)) PCV_WAVE_DONE()
         }
     }
 #define PCV_STEP(REFILL, CONS)                          \

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Timing experiments on the GPU box: rebuild scan_kernels with -DPCV_EXP=<n> (results are WRONG in these builds) and link over the library.
+# Timing experiments on the GPU box: rebuild scan_kernels with -DPCV_EXP=<n> (scan_kernels.hip lists them; results are wrong in
+# some of these builds) and link over the library in the box's scratch copy of the repository.
 #   bash tools/exp_build.sh 1   (0 restores the product build)
 set -e
 cd "$(dirname "$0")/../perceive_amd/csrc"
