@@ -2338,7 +2338,12 @@ __global__ __launch_bounds__(NH == 2 ? 256 : 768, 3) void scan_mfma8_hold_kernel
                 rhs[t] = fmaf(sblk_e, U[t], -vq[t]);
                 hot |= (float)m >= rhs[t];
             }
+#if PCV_EXP == 8 || PCV_EXP == 9
+            asm volatile("" ::"s"(__ballot(hot)));
+            if (false) {
+#else
             if (__any(hot)) {  // (one scale per block: a block that gets here has a survivor)
+#endif
                 uint32_t mask[2] = {0u, 0u};
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
