@@ -299,8 +299,8 @@ def e2e_leg(pa, ctx, searcher, rows, steps=5, warmup=4, batch=256, seq=256, k=10
 def e2e_dist_leg(pa, ctx, dist, torch, sharded, rank, world, rehearse, rows, barrier, steps=5, warmup=3, batch=256, seq=256, k=10):
     """BASELINE configs[4] on `world` GPUs: data-parallel encode of 256 documents x 256 tokens (f32, all-MiniLM-L6-v2 shape,
     seeded weights), embeddings left on the devices (encode_tokens_device), one all-gather of 256 x 384 floats, then the
-    sharded exact top-10 of all 256 over the row-sharded corpus in two passes of 128 queries that read them from device memory
-    (ShardedSearcher.search_device_queries).  Returns rank 0's record (None elsewhere)."""
+    sharded exact top-10 of all 256 over the row-sharded corpus — one pass of 256 queries if every rank keeps the int8 copy of its
+    rows, else two of 128 — reading them from device memory (ShardedSearcher.search_device_queries).  Returns rank 0's record (None elsewhere)."""
     m = pa.Model(ctx, pa.minilm_l6_desc("f32"), synthetic_seed=1)
     rng = np.random.default_rng(1)
     ids = rng.integers(1000, 30000, (batch, seq)).astype(np.int64)
@@ -324,8 +324,16 @@ def e2e_dist_leg(pa, ctx, dist, torch, sharded, rank, world, rehearse, rows, bar
             dist.all_gather(parts, mine)
             emb.copy_(torch.cat(parts))
         torch.cuda.current_stream().synchronize()
-        outs = [sharded.search_device_queries(None, k, emb.data_ptr() + q0 * D * 4, min(128, batch - q0)) for q0 in range(0, batch, 128)]
+        outs = [sharded.search_device_queries(None, k, emb.data_ptr() + q0 * D * 4, min(qpass, batch - q0)) for q0 in range(0, batch, qpass)]
         return np.concatenate([o[0] for o in outs])
+
+    # all 256 queries in one pass if every rank's searcher keeps the int8 copy of all its rows (agreed with one all-reduce: the split
+    # of a batch into passes is part of the exchange's protocol, pcv_searcher_allow_wide_sharded_pass); else two passes of 128
+    have8 = torch.tensor([1 if sharded.searcher.last_stats()["screening_copy"] == 2 else 0], dtype=torch.int32, device="cpu" if rehearse else "cuda")
+    dist.all_reduce(have8, op=dist.ReduceOp.MIN)
+    wide = bool(int(have8.item()))
+    qpass = batch if wide else 128
+    sharded.searcher.allow_wide_sharded_pass(wide)
 
     for _ in range(warmup):
         got = one()
@@ -337,6 +345,7 @@ def e2e_dist_leg(pa, ctx, dist, torch, sharded, rank, world, rehearse, rows, bar
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     m.close()
+    sharded.searcher.allow_wide_sharded_pass(False)
     if rank != 0:
         return None
     ms = 1e3 * float(el.item()) / steps
@@ -344,6 +353,7 @@ def e2e_dist_leg(pa, ctx, dist, torch, sharded, rank, world, rehearse, rows, bar
         "workload": f"encode batch={batch} x seq_len={seq} (MiniLM-L6 shape, f32) data-parallel over {world} GPUs + all-gather of the "
                     f"embeddings (device) + exact top-{k} of the {batch} embeddings over {rows} x 384 row-sharded, {world} MI355X",
         "ms_per_step": ms, "queries_per_s": batch / (ms * 1e-3), "n_gpus": world, "host_hops_of_the_embeddings": 0 if not rehearse else 1,
+        "queries_per_pass": qpass,
         "sample_ids": [int(x) for x in got[0][:3]],
     }
 

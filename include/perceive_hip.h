@@ -284,6 +284,14 @@ pcv_status pcv_searcher_search_device_begin(pcv_searcher* s, const float* querie
 pcv_status pcv_searcher_search_device_begin_dq(pcv_searcher* s, const void* d_queries, int n_queries,
                                                const int64_t* source_ids, int n_sources, int k, void* d_out);
 pcv_status pcv_searcher_search_device_end(pcv_searcher* s, int* out_overflowed);
+/* How many queries a pass takes is part of a sharded search's protocol (every rank must split a batch alike), so among ranks a pass
+ * is what every searcher can take whatever copies it holds: 128 queries.  A host that KNOWS every rank's searcher keeps the int8
+ * screening copy of all its rows (pcv_scan_stats.screening_copy == 2 on every rank, e.g. agreed with one all-reduce) may say so on
+ * every rank: a pass among ranks then takes what the int8 scan takes — 256 queries up to 384-d, the 256 embeddings of BASELINE
+ * configs[4] in one pass instead of two.  A rank for which it is not true fails pcv_searcher_search_device_begin* /
+ * pcv_searcher_search_sharded* with PCV_ERR_UNSUPPORTED before queueing anything (the other ranks' exchange would wait for it:
+ * check first). */
+pcv_status pcv_searcher_allow_wide_sharded_pass(pcv_searcher* s, int on);
 /* A step of a sharded search is about to be repeated because SOME rank's pass was incomplete (any_overflow of
  * pcv_merge_topk_flagged): the repeat on THIS rank runs without a speculative start threshold as well.  Every rank
  * keeps its own guess statistics; without this call guesses could fail on different ranks in different attempts and

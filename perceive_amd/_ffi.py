@@ -123,6 +123,7 @@ SYMBOLS = {
     "pcv_searcher_set_screening_copy": (C.c_int, [_P, C.c_int]),
     "pcv_searcher_set_mid_copy": (C.c_int, [_P, C.c_int]),
     "pcv_searcher_wait_background": (C.c_int, [_P]),
+    "pcv_searcher_allow_wide_sharded_pass": (C.c_int, [_P, C.c_int]),
     "pcv_searcher_set_candidate_capacity": (C.c_int, [_P, C.c_uint32]),
     "pcv_searcher_set_tuning": (C.c_int, [_P, C.c_uint32]),
     "pcv_searcher_search": (C.c_int, [_P, _F32P, C.c_int, _I64P, C.c_int, C.c_int, _I64P, _F32P, _INTP]),

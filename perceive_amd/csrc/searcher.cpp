@@ -204,6 +204,7 @@ struct pcv_searcher {
     int screen_copy = PCV_SCREEN_COPY_AUTO;  // pcv_searcher_set_screening_copy
     bool screen_copy_gave_way = false;       // AUTO: the copies were dropped to make room for rows
     int copies_kind = 0;                     // 0: not every row of every segment is covered by a screening copy; 1 bf16; 2 int8
+    bool wide_sharded = false;               // pcv_searcher_allow_wide_sharded_pass: the host vouches for int8 copies on every rank
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // A pass is five short launches and four event records: on small corpora its cost is the queueing.  The second time
     // a pass of the same shape comes by, its launch sequence is captured into a hipGraph and replayed from then on (what
@@ -1124,8 +1125,10 @@ int pick_kernel(const pcv_searcher* s, int B) {
 // `among_ranks`: the split must be the same on every rank of a sharded search, whatever copies each of them holds
 int pass_queries(const pcv_searcher* s, int kernel, bool among_ranks = false) {
     if (kernel == PCV_KERNEL_WAVE) return kMaxWaveQueries;
-    // every row has its int8 copy: the int8 scan's pass (256 queries up to 384-d); else what the bf16 / f32-row scans take
-    if (!among_ranks && s->copies_kind == 2 && s->Dp <= 1024)
+    // every row has its int8 copy: the int8 scan's pass (256 queries up to 384-d); else what the bf16 / f32-row scans take.
+    // Among ranks only if the host has said that this holds on EVERY rank (pcv_searcher_allow_wide_sharded_pass): the split of a
+    // batch into passes is part of the exchange's protocol.
+    if ((!among_ranks || s->wide_sharded) && s->copies_kind == 2 && s->Dp <= 1024)
         return std::min(kMfmaQueries, std::max(mfma8_pass_queries(s->Dp), mfma_pass_queries(s->Dp)));
     return mfma_pass_queries(s->Dp);
 }
@@ -1239,7 +1242,8 @@ void device_begin(pcv_searcher* s, const float* queries, int n_queries, const in
     // Only a condition every rank evaluates alike may refuse: the ranks of a sharded search must all
     // take the same protocol (the exchanged payload differs by the overflow record).
     if (n_queries > pass_queries(s, kernel, true))
-        PCV_FAIL(PCV_ERR_UNSUPPORTED, "search_device_begin: %d queries need more than one pass", n_queries);
+        PCV_FAIL(PCV_ERR_UNSUPPORTED, "search_device_begin: %d queries need more than one pass%s", n_queries,
+                 s->wide_sharded ? " (wide sharded passes were allowed, but not every row of THIS rank has its int8 screening copy)" : "");
     const size_t n = (size_t)n_queries * k;
     s->stats = pcv_scan_stats{};
     s->stats.kernel_used = kernel;
@@ -1636,6 +1640,15 @@ pcv_status pcv_searcher_set_mid_copy(pcv_searcher* s, int mode) {
         s->mid_copy = mode;
         s->mid_gave_way = false;
         s->mid_hot_passes = 0;
+    });
+}
+
+pcv_status pcv_searcher_allow_wide_sharded_pass(pcv_searcher* s, int on) {
+    return guarded([&] {
+        PCV_REQUIRE(s != nullptr, "allow_wide_sharded_pass: searcher is NULL");
+        std::lock_guard<std::mutex> lk(s->mu);
+        PCV_REQUIRE(!s->pending.active, "allow_wide_sharded_pass: a queued pass has not been collected");
+        s->wide_sharded = on != 0;
     });
 }
 

@@ -266,6 +266,11 @@ class Searcher:
     def set_kernel(self, kernel="auto"):
         _ffi.check(_ffi.lib().pcv_searcher_set_kernel(self._handle, _KERNELS[kernel]))
 
+    def allow_wide_sharded_pass(self, on=True):
+        """Every rank's searcher keeps the int8 copy of all its rows (the host has checked): a pass among ranks may take 256
+        queries (pcv_searcher_allow_wide_sharded_pass)."""
+        _ffi.check(_ffi.lib().pcv_searcher_allow_wide_sharded_pass(self._handle, 1 if on else 0))
+
     def wait_background(self):
         """Wait for a mid copy that AUTO is building beside the searches (pcv_searcher_wait_background)."""
         _ffi.check(_ffi.lib().pcv_searcher_wait_background(self._handle))

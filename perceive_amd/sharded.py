@@ -190,7 +190,8 @@ class ShardedSearcher:
     def search_device_queries(self, sources, num_results, d_queries, n_queries):
         """search_vectors with the queries in DEVICE memory (address of [n_queries][dim] f32 on this rank's GPU, the same
         values on every rank): the embeddings a data-parallel encode left on the devices and an all-gather put together
-        go into the scan without passing through host memory (BASELINE configs[4]).  One pass: n_queries <= 128."""
+        go into the scan without passing through host memory (BASELINE configs[4]).  One pass: n_queries <= 128, or 256 up to
+        384-d after Searcher.allow_wide_sharded_pass on every rank."""
         B, k = int(n_queries), int(num_results)
         if self.comm is not None:
             return self.searcher.search_sharded_dq(self.comm, sources, k, d_queries, B)

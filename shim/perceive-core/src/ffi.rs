@@ -179,6 +179,7 @@ extern "C" {
     pub fn pcv_searcher_search_device_begin(s: *mut pcv_searcher, queries: *const f32, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void) -> c_int;
     pub fn pcv_searcher_search_device_begin_dq(s: *mut pcv_searcher, d_queries: *const c_void, n_queries: c_int, source_ids: *const i64, n_sources: c_int, k: c_int, d_out: *mut c_void) -> c_int;
     pub fn pcv_searcher_search_device_end(s: *mut pcv_searcher, out_overflowed: *mut c_int) -> c_int;
+    pub fn pcv_searcher_allow_wide_sharded_pass(s: *mut pcv_searcher, on: c_int) -> c_int;
     pub fn pcv_searcher_repeat_without_guess(s: *mut pcv_searcher) -> c_int;
     pub fn pcv_merge_topk(ctx: *mut pcv_ctx, metric: c_int, dim: c_int, d_lists: *const c_void, n_shards: c_int, n_queries: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int) -> c_int;
     pub fn pcv_merge_topk_flagged(ctx: *mut pcv_ctx, metric: c_int, dim: c_int, d_lists: *const c_void, n_shards: c_int, n_queries: c_int, k: c_int, out_ids: *mut i64, out_scores: *mut f32, out_counts: *mut c_int, out_any_overflow: *mut c_int) -> c_int;

@@ -158,6 +158,22 @@ assert (np.sort(got, 1) == np.sort(opos2 * 3 + 2, 1)).mean() > 0.98
 # the same search from host queries gives the same answer
 got_h, sc_h, _ = ss.search_vectors(None, k, emb.cpu().numpy())
 assert (got_h == got).all() and (sc_h == sc).all()
+# 200 queries in ONE pass among the ranks: only after the host has said that every rank keeps the int8 copy of its rows
+q200 = torch.from_numpy(rng.standard_normal((200, D)).astype(np.float32)).cuda()
+torch.cuda.synchronize()
+try:
+    ss.search_device_queries(None, k, q200.data_ptr(), 200)
+    raise SystemExit("a 200-query pass among ranks must be refused until the host allows it")
+except pa.PcvError as e:
+    assert e.status == 3, e
+assert s.last_stats()["screening_copy"] == 2
+s.allow_wide_sharded_pass(True)
+got2, sc2, cnt2 = ss.search_device_queries(None, k, q200.data_ptr(), 200)
+o2, os2, _ = orc.topk(q200.cpu().numpy(), corpus, k)
+assert (got2 == o2 * 3 + 2).all() and (cnt2 == k).all()
+assert np.abs(sc2 - os2.astype(np.float32)).max() < 1e-6
+assert s.last_stats()["scan_launches"] == 1
+s.allow_wide_sharded_pass(False)
 dist.barrier()
 m.close(); s.close(); ctx.close()
 dist.destroy_process_group()
