@@ -33,6 +33,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // floats: the 16-lane ds_read_b128 groups then cover all 64 banks), 4 waves as 2x2, each wave
 // 2x2 MFMA tiles of 32x32.  The k index inside a 32-wide step is assigned as k = 16*(lane>>5) + s
 // for both operands, so a lane's 16 operand values are 64 contiguous bytes (4 x ds_read_b128).
+// Four workgroups per CU (round 4; three before): the operand loads go through buffer descriptors — one address register for
+// the eight loads of a step instead of sixteen — and the kernel fits 122 registers (256 x 256 tokens, same box: QKV
+// projection 463 -> 447 us, FFN up 641 -> 600 us).
 // ------------------------------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
 
@@ -179,7 +182,7 @@ __device__ __forceinline__ void load_bias2(const float* __restrict__ bias, int c
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ C, int M,
                                                        int N, int K) {
@@ -194,22 +197,22 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const float* __restric
     tile_of_block(N / BN, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // staging: thread t moves float4 (row = (t>>3) + 32*u, 16-byte column c4 = t&7), u = 0..3
+    // staging: thread t moves float4 (row = (t>>3) + 32*u, 16-byte column c4 = t&7), u = 0..3.  Through buffer descriptors with
+    // the tile's base: one address register for all eight loads of a step (the rest of the address is scalar), and the rows of
+    // A past M read as zeros
     const int srow = tid >> 3, c4 = tid & 7;
-    const float* ag[4];
-    const float* wg[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int ar = min(m0 + srow + 32 * u, M - 1);
-        ag[u] = A + (size_t)ar * K + c4 * 4;
-        wg[u] = W + (size_t)(n0 + srow + 32 * u) * K + c4 * 4;
-    }
+    const uint32_t lane_off = (uint32_t)(srow * K + c4 * 4) * 4u;
+    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * K), 0, (uint32_t)(min(M - m0, BM) * K) * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * K), 0, (uint32_t)(BN * K) * 4u, 0x00020000);
     f32x4 ra[4], rw[4];
+    auto fetch = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        ra[u] = *(const f32x4*)(ag[u]);
-        rw[u] = *(const f32x4*)(wg[u]);
-    }
+        for (int u = 0; u < 4; ++u) {
+            ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, lane_off, (uint32_t)(32 * u * K + kt * BK) * 4u, 0));
+            rw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, lane_off, (uint32_t)(32 * u * K + kt * BK) * 4u, 0));
+        }
+    };
+    fetch(0);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -228,16 +231,12 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const float* __restric
             *(f32x4*)&Ws[(srow + 32 * u) * LDT + c4 * 4] = rw[u];
         }
         __syncthreads();
-        {  // next step's global loads fly under this step's MFMAs (the last step re-reads its own
-           // tile instead of branching: a conditional load made the compiler park the staging
-           // registers in scratch)
-            const size_t koff = (size_t)min(kt + 1, nk - 1) * BK;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ra[u] = *(const f32x4*)(ag[u] + koff);
-                rw[u] = *(const f32x4*)(wg[u] + koff);
-            }
-        }
+        // next step's global loads fly under this step's MFMAs (the last step re-reads its own tile instead of branching: a
+        // conditional load made the compiler park the staging registers in scratch).  The scheduling barrier keeps them HERE:
+        // left alone, the scheduler sinks the loads below the multiplies to the top of the next step — right in front of the
+        // LDS writes that wait for them — to save their registers, and the prefetch is gone (round 4)
+        fetch(min(kt + 1, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);
         float af[2][16], bf[2][16];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -434,11 +433,21 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
     int tile = blockIdx.x;
     if (tile >= tiles) return;
 
-    const float* wg = W + (size_t)srow * K + c4 * 4;
-    const float* ag = A + (size_t)min(tile * LBM + srow, M - 1) * K + c4 * 4;
-    f32x4 ra = *(const f32x4*)ag, rw[2 * CT];
+    // operands through buffer descriptors (one address register for the seven loads of a step; rows of A past M read as zeros)
+    const uint32_t lane_off = (uint32_t)(srow * K + c4 * 4) * 4u;
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (uint32_t)(N * K) * 4u, 0x00020000);
+    auto a_rsrc = [&](int t) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)t * LBM * K), 0, (uint32_t)(min(M - t * LBM, LBM) * K) * 4u, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t ares = a_rsrc(tile);
+    f32x4 ra, rw[2 * CT];
+    auto fetch = [&](int kt) __attribute__((always_inline)) {
+        ra = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, lane_off, (uint32_t)(kt * BK) * 4u, 0));
 #pragma unroll
-    for (int u = 0; u < 2 * CT; ++u) rw[u] = *(const f32x4*)(wg + (size_t)64 * u * K);
+        for (int u = 0; u < 2 * CT; ++u)
+            rw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, lane_off, (uint32_t)(64 * u * K + kt * BK) * 4u, 0));
+    };
+    fetch(0);
     const float* ap0 = &As[(rh * 32 + i) * LDT + 16 * kk];
     const float* bp0 = &Ws[(wc * CT * 32 + i) * LDT + 16 * kk];
     float* tile_lds = lsm;
@@ -473,10 +482,8 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
         };
         for (int kt = 0; kt + 1 < nk; ++kt) {
             to_lds();
-            const size_t koff = (size_t)(kt + 1) * BK;  // the next step's operands fly under this step's MFMAs
-            ra = *(const f32x4*)(ag + koff);
-#pragma unroll
-            for (int u = 0; u < 2 * CT; ++u) rw[u] = *(const f32x4*)(wg + (size_t)64 * u * K + koff);
+            fetch(kt + 1);  // the next step's operands fly under this step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);  // (issued HERE: see gemm_f32_kernel)
             mfma_step();
         }
         to_lds();
@@ -538,98 +545,123 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
             }
         }
         // the next tile's first operands
-        ag = A + (size_t)min(min(tile + (int)gridDim.x, tiles - 1) * LBM + srow, M - 1) * K + c4 * 4;
-        ra = *(const f32x4*)ag;
-#pragma unroll
-        for (int u = 0; u < 2 * CT; ++u) rw[u] = *(const f32x4*)(wg + (size_t)64 * u * K);
+        ares = a_rsrc(min(tile + (int)gridDim.x, tiles - 1));
+        fetch(0);
     }
 }
 
 // The same fusion for FEW tokens (round 4): 8 192 tokens — one rank's share of BASELINE configs[4]'s 256 documents — are 128
 // tiles of 64 rows: half the chip ran one eight-wave workgroup per CU and the other half nothing (gemm_f32_ln8_kernel: 119 us per
 // call on average, 0.32 of the f32-MFMA peak; profiles/r04_encoder_32x256_before_kernel_stats.csv).  Here a workgroup owns 32
-// whole rows (256 tiles: every CU has one) and its eight waves split each 64-wide K step in two halves x four column quarters
-// (32 x N/4 per wave and K half), so a CU still runs two waves per SIMD and the K loop has half as many barrier-separated steps.
-// The two K halves meet in LDS in the epilogue (two row-major 32 x N tiles in the staging buffers), which adds them with bias
-// and residual.  Same v_mfma_f32_32x32x2_f32 arithmetic; the sum over K is formed as two partial sums.
-// (Measured and dropped: no W value is used by two waves here — one 32-row MFMA tile per workgroup — so a form without LDS
-// staging and without barriers in the K loop suggests itself: every lane loads its operands' 16 consecutive floats straight
-// from global memory, the next step's 16 loads in flight under 48 MFMAs, as the skinny GEMM does.  2.35 ms per 32 x 256 forward
-// against 2.13 ms: 32 rows x 64 bytes per load instruction keep the address path busy four times as long as full lines do.
-// Also dropped: 32-wide K steps through two 60 KB staging buffers, the next step's operands written under this step's multiplies
-// and one barrier a step: 2.27 ms — twice the barriers for 24 multiplies per wave and step cost more than the overlap gives.)
+// whole rows (256 tiles: every CU has one) and its eight waves are two halves of K x four column quarters (32 x N/4 per wave
+// and K half), two waves per SIMD.  The two K halves meet in LDS in the epilogue (two row-major 32 x N tiles), which adds them
+// with bias and residual.  Same v_mfma_f32_32x32x2_f32 arithmetic; the sum over K is formed as two partial sums.
+//
+// There is NO barrier in the K loop: no W value is used by two waves of this workgroup, so each wave stages its own operands —
+// its 32 x CT W rows and the 32 A rows over ITS half of K, 32 floats of them a step — through a private region of LDS (128 rows
+// x 36 floats = 18 KB per wave, 147 KB per workgroup): loads to registers a step ahead, registers to LDS, fragments back, all
+// inside one wave, where the LDS queue keeps the order.  The four waves of a K half each fetch the A rows themselves (L1 hits
+// after the first): 16 load instructions a step instead of 13.
+// What it took, 32 x 256 tokens, FFN-down call (K = 1536) / attention-output call (K = 384), same box:
+//   113 / 32.6 us  the first form: workgroup-wide staging of 64-wide K steps, two barriers a step
+//   104 / 32.8 us  wave-private staging, loads written as pointer arithmetic: the scheduler SANK the sixteen loads of the next
+//                  step below the step's 48 multiplies, right in front of the LDS writes that wait for them (it saves the staging
+//                  registers for the fragments that way) — the prefetch was gone, every step paid the whole L2 latency.  With the
+//                  loads taken out 87 us, with the multiplies taken out 42 us, with neither staging nor loads 80 us: nothing overlapped
+//    93 / 29.4 us  loads through buffer descriptors (one address register for all sixteen, scalar offsets: 174 registers
+//                  instead of 256 + spills) and a scheduling barrier between their issue and the multiplies
+// (Measured and dropped on the way: every lane loading its operands' 16 consecutive floats straight from global memory, no LDS:
+// 2.35 ms per 32 x 256 forward against 2.13 — 32 rows x 64 bytes per load instruction keep the address path busy four times as
+// long as full lines do; 32-wide K steps through two 60 KB workgroup-wide buffers, one barrier a step: 2.27 ms; starting the
+// second wave of each SIMD up to 2.7 us late so that the two would not stage at the same time: no change.)
 // ------------------------------------------------------------------------------------------------
-constexpr int L32M = 32, L32K = 64, L32T = L32K + 4;
+constexpr int L32M = 32;
 template <int CT>
 __global__ __launch_bounds__(512, 2) void gemm_f32_ln32_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                               const float* __restrict__ bias, const float* __restrict__ resid,
-                                                               const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                               float eps, float* __restrict__ C, int M, int K) {
+                                                                const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                                float eps, float* __restrict__ C, int M, int K) {
     constexpr int N = CT * 128;
     constexpr int LDR = N + 4;
-    constexpr int Q = N / 64;       // float4 per lane and row in the epilogue (16 lanes per row)
-    constexpr int WU = N / 32;      // float4 of W per thread and K step: N rows x 16 float4 over 512 threads
+    constexpr int Q = N / 64;
+    constexpr int WR = CT * 32;   // W rows of a wave
+    constexpr int PR = 32 + WR;   // rows of a wave's staging tile: A rows, then its W rows
+    constexpr int WJ = WR / 8;    // load instructions per step for W (8 rows x 128 bytes each), 4 for A
     extern __shared__ __attribute__((aligned(16))) float lsm[];
-    float* As = lsm;                // [32][L32T]
-    float* Ws = lsm + L32M * L32T;  // [N][L32T]
-    static_assert(2 * 32 * LDR <= (L32M + N) * L32T, "the epilogue's two partial tiles fit the staging buffers");
+    static_assert(2 * 32 * LDR <= 8 * PR * LDT, "the epilogue's two partial tiles fit the staging regions");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kk = lane >> 5;
     const int kh = wave & 1, wc = wave >> 1;
-    const int srow = tid >> 4, c4 = tid & 15;  // staging: float4 (row srow [+ 32u], 16-byte column c4 of the 64-wide step)
-    const int erow = tid >> 4, ej = tid & 15;  // epilogue: 16 lanes per row, float4 columns ej + 16t
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int erow = tid >> 4, ej = tid & 15;
     const int tiles = (M + L32M - 1) / L32M;
-    const int nk = K / L32K;
-    int tile = blockIdx.x;
-    if (tile >= tiles) return;
-
-    const float* wg = W + (size_t)srow * K + c4 * 4;
-    const float* ag = A + (size_t)min(tile * L32M + srow, M - 1) * K + c4 * 4;
-    f32x4 ra = *(const f32x4*)ag, rw[WU];
-#pragma unroll
-    for (int u = 0; u < WU; ++u) rw[u] = *(const f32x4*)(wg + (size_t)32 * u * K);
-    const float* ap0 = &As[i * L32T + 32 * kh + 16 * kk];
-    const float* bp0 = &Ws[(wc * CT * 32 + i) * L32T + 32 * kh + 16 * kk];
+    const int nk = K / 64;  // 32-wide steps in this wave's half of K
+    float* mine = lsm + wave * PR * LDT;
     float* tile_lds = lsm;
+    // operands through buffer descriptors with wave-uniform bases: ONE address register (the lane's offset inside an 8-row group)
+    // serves all 16 loads of a step, the rest of the address is scalar; rows past M read as zeros
+    const uint32_t lane_off = (uint32_t)(r8 * K + c8 * 4) * 4u;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int kh_u = wave_u & 1, wc_u = wave_u >> 1;
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(W + (size_t)wc_u * WR * K + kh_u * (K / 2)), 0, (uint32_t)(((WR - 1) * K + K / 2) * 4), 0x00020000);
+    float* st_a = mine + r8 * LDT + c8 * 4;
+    const float* ap0 = mine + i * LDT + 16 * kk;
+    const float* bp0 = mine + (32 + i) * LDT + 16 * kk;
 
-    for (; tile < tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int m0 = tile * L32M;
+        const int rows_here = min(M - m0, L32M);
+        const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(A + (size_t)m0 * K + kh_u * (K / 2)), 0, (uint32_t)(((rows_here - 1) * K + K / 2) * 4), 0x00020000);
+        f32x4 ra[4], rw[WJ];
+        auto fetch = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, lane_off, (uint32_t)(8 * j * K + kt * 32) * 4u, 0));
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) rw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, lane_off, (uint32_t)(8 * j * K + kt * 32) * 4u, 0));
+        };
+        fetch(0);
         f32x16 acc[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-        auto to_lds = [&]() {
-            __syncthreads();  // the previous step's fragment reads / the previous tile's row reads are done
-            *(f32x4*)&As[srow * L32T + c4 * 4] = ra;
+        auto to_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < WU; ++u) *(f32x4*)&Ws[(srow + 32 * u) * L32T + c4 * 4] = rw[u];
-            __syncthreads();
+            for (int j = 0; j < 4; ++j) *(f32x4*)(st_a + 8 * j * LDT) = ra[j];
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) *(f32x4*)(st_a + (32 + 8 * j) * LDT) = rw[j];
+            __builtin_amdgcn_wave_barrier();  // (scheduling only: one wave, and its LDS operations complete in order)
         };
-        auto mfma_step = [&]() {
+        auto mfma_step = [&]() __attribute__((always_inline)) {
+            f32x4 x[2], y[2][CT];  // fragments of four k per lane half, the next four on their way under these multiplies
+            x[0] = *(const f32x4*)ap0;
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh) {  // four k per lane half at a time
-                const f32x4 x = *(const f32x4*)(ap0 + 4 * hh);
-                f32x4 y[CT];
+            for (int c = 0; c < CT; ++c) y[0][c] = *(const f32x4*)(bp0 + c * 32 * LDT);
 #pragma unroll
-                for (int c = 0; c < CT; ++c) y[c] = *(const f32x4*)(bp0 + c * 32 * L32T + 4 * hh);
+            for (int hh = 0; hh < 4; ++hh) {
+                if (hh < 3) {
+                    x[(hh + 1) & 1] = *(const f32x4*)(ap0 + 4 * (hh + 1));
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) y[(hh + 1) & 1][c] = *(const f32x4*)(bp0 + c * 32 * LDT + 4 * (hh + 1));
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int c = 0; c < CT; ++c)
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s], y[c][s], acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[hh & 1][s], y[hh & 1][c][s], acc[c], 0, 0, 0);
             }
+            __builtin_amdgcn_wave_barrier();
         };
         for (int kt = 0; kt + 1 < nk; ++kt) {
             to_lds();
-            const size_t koff = (size_t)(kt + 1) * L32K;  // the next step's operands fly under this step's MFMAs
-            ra = *(const f32x4*)(ag + koff);
-#pragma unroll
-            for (int u = 0; u < WU; ++u) rw[u] = *(const f32x4*)(wg + (size_t)32 * u * K + koff);
+            fetch(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);  // the loads are ISSUED here: the scheduler otherwise sinks them below the multiplies
             mfma_step();
         }
         to_lds();
-        f32x4 rv[Q];  // under the last step: the residual rows of the epilogue
+        f32x4 rv[Q];
         {
             const float* rrow = resid + (size_t)min(m0 + erow, M - 1) * N;
 #pragma unroll
@@ -637,8 +669,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ln32_kernel(const float* __re
         }
         mfma_step();
 
-        // epilogue: both K halves row-major into LDS, then 16 lanes per row add them up with bias and residual
-        __syncthreads();
+        __syncthreads();  // every wave is done with its staging region: the partial tiles take their place
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -654,11 +685,6 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ln32_kernel(const float* __re
                    *(const f32x4*)(bias + col) + rv[t];
             sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
         }
-        // the next tile's first operands fly under the reductions and the stores
-        ag = A + (size_t)min(min(tile + (int)gridDim.x, tiles - 1) * L32M + srow, M - 1) * K + c4 * 4;
-        ra = *(const f32x4*)ag;
-#pragma unroll
-        for (int u = 0; u < WU; ++u) rw[u] = *(const f32x4*)(wg + (size_t)32 * u * K);
         sum += __shfl_xor(sum, 1);
         sum += __shfl_xor(sum, 2);
         sum += __shfl_xor(sum, 4);
@@ -682,6 +708,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ln32_kernel(const float* __re
                 *(f32x4*)(C + (size_t)row * N + col) = (v[t] - mean) * rstd * *(const f32x4*)(ln_w + col) + *(const f32x4*)(ln_b + col);
             }
         }
+        __syncthreads();  // the partial tiles are read: the next tile's staging may overwrite them
     }
 }
 
@@ -2071,13 +2098,19 @@ bool launch_gemm_f32_ln(hipStream_t st, const float* A, const float* W, const fl
     const dim3 grid((M + LBM - 1) / LBM);
     static const bool no32 = getenv("PCV_NO_LN32") != nullptr;  // (comparison switch)
     static const int max32 = getenv("PCV_LN32_MAX_M") ? atoi(getenv("PCV_LN32_MAX_M")) : -1;  // (tuning)
-    if (N == 384 && K % L32K == 0 && (max32 >= 0 ? M <= max32 : M < 64 * current_device_cus()) && !no32) {
-        // fewer 64-row tiles than CUs: 32-row tiles, eight waves that split K (gemm_f32_ln32_kernel)
-        const size_t lds32 = (size_t)(L32M + N) * L32T * sizeof(float);
-        allow_dynamic_lds((const void*)gemm_f32_ln32_kernel<3>, lds32);  // 113 KB of dynamic LDS: one workgroup per CU
-        const int tiles = (M + L32M - 1) / L32M;
-        gemm_f32_ln32_kernel<3><<<dim3(std::min<int>(tiles, current_device_cus())), 512, lds32, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
-        return true;
+    if (N == 384 && K % 64 == 0 && !no32) {
+        // 32-row tiles where they fill the chip better than 64-row ones: a CU's time is its number of tiles, a 32-row tile
+        // costing 0.6 of a 64-row one (half the work, at the lower reuse of W).  8 192 tokens: 1 x 0.6 against 1 (half the CUs
+        // idle); 16 384: 2 x 0.6 against 1; 24 576: 3 x 0.6 against 2 (5.06 against 5.49 ms a forward); 65 536: 8 x 0.6 against 4
+        const int cus = current_device_cus();
+        const int tiles32 = (M + L32M - 1) / L32M, tiles64 = (M + LBM - 1) / LBM;
+        const bool use32 = max32 >= 0 ? M <= max32 : 6 * ((tiles32 + cus - 1) / cus) < 10 * ((tiles64 + cus - 1) / cus);
+        if (use32) {
+            const size_t lds32 = (size_t)8 * (32 + 96) * LDT * sizeof(float);  // 147 KB of dynamic LDS: one workgroup per CU
+            allow_dynamic_lds((const void*)gemm_f32_ln32_kernel<3>, lds32);
+            gemm_f32_ln32_kernel<3><<<dim3(std::min<int>(tiles32, cus)), 512, lds32, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
+            return true;
+        }
     }
     if (N == 384) {  // persistent eight-wave form: 1 % of a 256 x 256 forward over the four-wave one
         allow_dynamic_lds((const void*)gemm_f32_ln8_kernel<3>, lds);  // 64.5 KB of dynamic LDS

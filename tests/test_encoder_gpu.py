@@ -121,11 +121,12 @@ def test_minilm_shape_synthetic_weights(ctx, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("shape", [(32, 256), (40, 200), (9, 100)])
+@pytest.mark.parametrize("shape", [(32, 256), (40, 200), (9, 100), (97, 250)])
 def test_minilm_shape_few_tokens_32_row_layernorm_tiles(ctx, oracle, shape):
-    # One rank's share of BASELINE configs[4] (32 documents x 256 tokens = 8 192 tokens) and other token counts below 64 x CUs:
-    # the projection + LayerNorm fusion runs on 32-row tiles whose eight waves split K (gemm_f32_ln32_kernel); (40, 200) ends
-    # in a partial tile, (9, 100) is a handful of tiles.  Sampled documents against the C oracle (padding invariance makes
+    # One rank's share of BASELINE configs[4] (32 documents x 256 tokens = 8 192 tokens) and other token counts that fill the
+    # chip better in 32-row tiles than in 64-row ones: the projection + LayerNorm fusion runs on 32-row tiles whose eight waves
+    # split K and stage their operands privately (gemm_f32_ln32_kernel); (40, 200) ends in a partial tile, (9, 100) is a handful
+    # of tiles, (97, 250) = 24 250 tokens are 758 tiles: three (or two) per workgroup, the last one partial.  Sampled documents against the C oracle (padding invariance makes
     # single-row oracle runs valid), and the whole batch against the 64-row form of the same fusion (PCV_NO_LN32 is read once
     # per process, so the comparison model is the all-in-one-batch run of the documents one by one).
     B, L = shape
@@ -145,9 +146,15 @@ def test_minilm_shape_few_tokens_32_row_layernorm_tiles(ctx, oracle, shape):
         oout, ohid = oracle.encode_tokens(desc, sd, ids1, mask1, want_hidden=True)
         assert np.abs(emb[i] - oout[0]).max() < TOL, i
     # the last layer's hidden states of document 0 (full length): every token row of a tile, not only the pooled vector
-    ids1, mask1 = m.generate_token_tensors([toks[0]])
-    _, ohid = oracle.encode_tokens(desc, sd, ids1, mask1, want_hidden=True)
-    assert np.abs(m.debug_hidden(6, B, L)[0] - ohid[-1][0]).max() < 5e-4
+    if B * L <= 16384:  # (hidden states are kept for debugging up to that many tokens)
+        ids1, mask1 = m.generate_token_tensors([toks[0]])
+        _, ohid = oracle.encode_tokens(desc, sd, ids1, mask1, want_hidden=True)
+        assert np.abs(m.debug_hidden(6, B, L)[0] - ohid[-1][0]).max() < 5e-4
+    else:  # more sampled documents instead, from every third of the batch (a workgroup's first, second and third tile)
+        for i in range(5, B, 13):
+            ids1, mask1 = m.generate_token_tensors([toks[i]])
+            oout, _ = oracle.encode_tokens(desc, sd, ids1, mask1)
+            assert np.abs(emb[i] - oout[0]).max() < TOL, i
     m.close()
 
 
