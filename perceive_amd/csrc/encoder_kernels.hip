@@ -422,6 +422,10 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     float* As = lsm;              // [64][LDT]
     float* Ws = lsm + LBM * LDT;  // [N][LDT]
+    // bias, LayerNorm weight and bias: in LDS behind the staging buffers.  Read from global memory in the epilogue they cost it
+    // most of its time: every `load weight, load bias, store` of the six per row half waits with vmcnt(0), and stores count in
+    // vmcnt — each store waited for the one before it to be acknowledged by memory (22-26 us per 64-row tile, round 4)
+    float* prm = lsm + (LBM + N) * LDT;  // [3][N]
     static_assert(32 * LDR <= (LBM + N) * LDT, "the epilogue's half tile fits the staging buffers");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kk = lane >> 5;
@@ -448,9 +452,15 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
             rw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, lane_off, (uint32_t)(64 * u * K + kt * BK) * 4u, 0));
     };
     fetch(0);
+    if (tid < 3 * N / 4) {
+        const float* src = tid < N / 4 ? bias : tid < N / 2 ? ln_w : ln_b;
+        *(f32x4*)(prm + 4 * tid) = *(const f32x4*)(src + 4 * (tid % (N / 4)));
+    }  // (visible after the first step's barriers)
     const float* ap0 = &As[(rh * 32 + i) * LDT + 16 * kk];
     const float* bp0 = &Ws[(wc * CT * 32 + i) * LDT + 16 * kk];
     float* tile_lds = lsm;
+    const float* trow = tile_lds + erow * LDR + 4 * ej;  // the epilogue's row piece and parameters: one address each + constant offsets
+    const float* pcol = prm + 4 * ej;
 
     for (; tile < tiles; tile += gridDim.x) {
         const int m0 = tile * LBM;
@@ -512,13 +522,14 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
 #pragma unroll
             for (int t = 0; t < Q; ++t) {
                 const int col = 4 * (ej + 16 * t);
-                v[t] = *(const f32x4*)(tile_lds + erow * LDR + col) + *(const f32x4*)(bias + col) + rv[t];
+                v[t] = *(const f32x4*)(trow + 64 * t) + *(const f32x4*)(pcol + 64 * t) + rv[t];
                 sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
             }
             if (a == 0) {  // the second half's residual rows fly under this half's arithmetic and stores
                 const float* rrow = resid + (size_t)min(row + 32, M - 1) * N;
 #pragma unroll
                 for (int t = 0; t < Q; ++t) rv[t] = *(const f32x4*)(rrow + 4 * (ej + 16 * t));
+                __builtin_amdgcn_sched_barrier(0);  // issued BEFORE this half's stores: waiting for them then leaves the stores in flight
             }
             sum += __shfl_xor(sum, 1);
             sum += __shfl_xor(sum, 2);
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_ln8_kernel(const float* __res
 #pragma unroll
                 for (int t = 0; t < Q; ++t) {
                     const int col = 4 * (ej + 16 * t);
-                    *(f32x4*)(C + (size_t)row * N + col) = (v[t] - mean) * rstd * *(const f32x4*)(ln_w + col) + *(const f32x4*)(ln_b + col);
+                    *(f32x4*)(C + (size_t)row * N + col) = (v[t] - mean) * rstd * *(const f32x4*)(pcol + N + 64 * t) + *(const f32x4*)(pcol + 2 * N + 64 * t);
                 }
             }
         }
@@ -598,6 +609,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ln32_kernel(const float* __re
     const int nk = K / 64;  // 32-wide steps in this wave's half of K
     float* mine = lsm + wave * PR * LDT;
     float* tile_lds = lsm;
+    float* prm = lsm + 8 * PR * LDT;  // bias, LayerNorm weight and bias [3][N], behind the staging regions (see gemm_f32_ln8_kernel)
+    if (tid < 3 * N / 4) {
+        const float* src = tid < N / 4 ? bias : tid < N / 2 ? ln_w : ln_b;
+        *(f32x4*)(prm + 4 * tid) = *(const f32x4*)(src + 4 * (tid % (N / 4)));
+    }  // (visible after the epilogue's first barrier)
+    const float* pcol = prm + 4 * ej;
     // operands through buffer descriptors with wave-uniform bases: ONE address register (the lane's offset inside an 8-row group)
     // serves all 16 loads of a step, the rest of the address is scalar; rows past M read as zeros
     const uint32_t lane_off = (uint32_t)(r8 * K + c8 * 4) * 4u;
@@ -682,7 +699,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ln32_kernel(const float* __re
         for (int t = 0; t < Q; ++t) {
             const int col = 4 * (ej + 16 * t);
             v[t] = (*(const f32x4*)(tile_lds + erow * LDR + col) + *(const f32x4*)(tile_lds + (32 + erow) * LDR + col)) +
-                   *(const f32x4*)(bias + col) + rv[t];
+                   *(const f32x4*)(pcol + 64 * t) + rv[t];
             sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
         }
         sum += __shfl_xor(sum, 1);
@@ -705,7 +722,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ln32_kernel(const float* __re
 #pragma unroll
             for (int t = 0; t < Q; ++t) {
                 const int col = 4 * (ej + 16 * t);
-                *(f32x4*)(C + (size_t)row * N + col) = (v[t] - mean) * rstd * *(const f32x4*)(ln_w + col) + *(const f32x4*)(ln_b + col);
+                *(f32x4*)(C + (size_t)row * N + col) = (v[t] - mean) * rstd * *(const f32x4*)(pcol + N + 64 * t) + *(const f32x4*)(pcol + 2 * N + 64 * t);
             }
         }
         __syncthreads();  // the partial tiles are read: the next tile's staging may overwrite them
@@ -2106,16 +2123,17 @@ bool launch_gemm_f32_ln(hipStream_t st, const float* A, const float* W, const fl
         const int tiles32 = (M + L32M - 1) / L32M, tiles64 = (M + LBM - 1) / LBM;
         const bool use32 = max32 >= 0 ? M <= max32 : 6 * ((tiles32 + cus - 1) / cus) < 10 * ((tiles64 + cus - 1) / cus);
         if (use32) {
-            const size_t lds32 = (size_t)8 * (32 + 96) * LDT * sizeof(float);  // 147 KB of dynamic LDS: one workgroup per CU
+            const size_t lds32 = ((size_t)8 * (32 + 96) * LDT + 3 * N) * sizeof(float);  // 152 KB of dynamic LDS: one workgroup per CU
             allow_dynamic_lds((const void*)gemm_f32_ln32_kernel<3>, lds32);
             gemm_f32_ln32_kernel<3><<<dim3(std::min<int>(tiles32, cus)), 512, lds32, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
             return true;
         }
     }
     if (N == 384) {  // persistent eight-wave form: 1 % of a 256 x 256 forward over the four-wave one
-        allow_dynamic_lds((const void*)gemm_f32_ln8_kernel<3>, lds);  // 64.5 KB of dynamic LDS
+        const size_t lds8 = lds + (size_t)3 * N * sizeof(float);  // + bias and the LayerNorm parameters
+        allow_dynamic_lds((const void*)gemm_f32_ln8_kernel<3>, lds8);  // 69 KB of dynamic LDS
         const int resident = 2 * 256;  // two workgroups per CU
-        gemm_f32_ln8_kernel<3><<<dim3(std::min<int>(grid.x, resident)), 512, lds, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
+        gemm_f32_ln8_kernel<3><<<dim3(std::min<int>(grid.x, resident)), 512, lds8, st>>>(A, W, bias, resid, ln_w, ln_b, eps, C, M, K);
         return true;
     }
     switch (N / 128) {
