@@ -11,6 +11,13 @@
 #include "encoder.h"
 #include "synth.h"
 
+// Timing experiments (tools/exp_build_enc.sh <n> on the GPU box; results are WRONG in these builds): pieces of gemm_f32_kernel
+// taken out to see what the rest costs — 10: no epilogue (one value per lane stored), 11: no operand loads in the K loop,
+// 12: no loads, no staging writes and no barriers either (fragment reads + multiplies only).  0 = the product.
+#ifndef PCV_ENC_EXP
+#define PCV_ENC_EXP 0
+#endif
+
 namespace pcv {
 namespace {
 
@@ -78,6 +85,36 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 __device__ __forceinline__ float gelu_tanh(float v) {
     const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
     return v / (1.0f + __expf(-2.0f * u));
+}
+// The same two functions on PAIRS of values: v_pk_fma_f32 / v_pk_mul_f32 do two lanes' worth per instruction, and VALU time in an
+// epilogue is matrix-pipe time (the scalar form was 990 VALU instructions per thread and 128x128 tile, 640 of them fma / mul).
+// Element for element the same operations in the same order as the scalar forms: identical results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+    const f32x2 x = v * splat2(0.70710678118654752440f);
+    const f32x2 t = __builtin_elementwise_abs(x);
+    f32x2 p = __builtin_elementwise_fma(t, splat2(0.0000430638f), splat2(0.0002765672f));
+    p = __builtin_elementwise_fma(t, p, splat2(0.0001520143f));
+    p = __builtin_elementwise_fma(t, p, splat2(0.0092705272f));
+    p = __builtin_elementwise_fma(t, p, splat2(0.0422820123f));
+    p = __builtin_elementwise_fma(t, p, splat2(0.0705230784f));
+    p = __builtin_elementwise_fma(t, p, splat2(1.0f));
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    p = p * p;
+    const f32x2 e = splat2(1.0f) - f32x2{__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
+    return (splat2(0.5f) * v) * (splat2(1.0f) + __builtin_elementwise_copysign(e, x));
+}
+template <int EPI>
+__device__ __forceinline__ f32x4 epi_act4(f32x4 v) {
+    if (EPI == EPI_BIAS_GELU) {
+        const f32x2 lo = gelu_erf2(f32x2{v.x, v.y}), hi = gelu_erf2(f32x2{v.z, v.w});
+        return f32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+    if (EPI == EPI_BIAS_GELU_TANH) return f32x4{gelu_tanh(v.x), gelu_tanh(v.y), gelu_tanh(v.z), gelu_tanh(v.w)};
+    return v;
 }
 template <int EPI>
 __device__ __forceinline__ float epi_act(float v) {
@@ -166,7 +203,7 @@ __device__ __forceinline__ void store_quarter_wide(const f32x16 (&acc)[2][2], co
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             f32x4 v = *(const f32x4*)(tile + (rq + 4 * u) * LDE + 4 * c4) + b4;
-            if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_TANH) v = f32x4{epi_act<EPI>(v.x), epi_act<EPI>(v.y), epi_act<EPI>(v.z), epi_act<EPI>(v.w)};
+            if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_TANH) v = epi_act4<EPI>(v);
             if (EPI == EPI_BIAS_RESIDUAL) v += rv[u];
             *(f32x4*)(C + (size_t)(row0 + a * 32 + rq + 4 * u) * N + col0 + 4 * c4) = v;
         }
@@ -224,6 +261,10 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
 
     const int nk = K / BK;
     for (int kt = 0; kt < nk; ++kt) {
+#if PCV_ENC_EXP == 12
+        if (kt == 0)
+#endif
+        {
         __syncthreads();  // previous step's fragment reads are done
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -231,10 +272,14 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
             *(f32x4*)&Ws[(srow + 32 * u) * LDT + c4 * 4] = rw[u];
         }
         __syncthreads();
+        }
         // next step's global loads fly under this step's MFMAs (the last step re-reads its own tile instead of branching: a
         // conditional load made the compiler park the staging registers in scratch).  The scheduling barrier keeps them HERE:
         // left alone, the scheduler sinks the loads below the multiplies to the top of the next step — right in front of the
         // LDS writes that wait for them — to save their registers, and the prefetch is gone (round 4)
+#if PCV_ENC_EXP == 11 || PCV_ENC_EXP == 12
+        if (kt == 1000)
+#endif
         fetch(min(kt + 1, nk - 1));
         __builtin_amdgcn_sched_barrier(0);
         float af[2][16], bf[2][16];
@@ -259,6 +304,19 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
     }
 
+#if PCV_ENC_EXP == 10
+    {
+        float keep = 0.0f;
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[a2][b2][r];
+        C[(size_t)(m0 + (tid >> 1)) * N + n0 + (tid & 1) * 64 + lane] = keep;
+        return;
+    }
+#endif
     if (m0 + BM <= M) {  // full tile (workgroup-uniform): wide epilogue through LDS
         __syncthreads();  // every wave is done with the last K-step's fragments
         store_quarter_wide<EPI>(acc, bias, resid, C, N, m0 + wr * 64, n0 + wc * 64, smem + wave * 32 * LDE, lane);
