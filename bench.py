@@ -649,7 +649,7 @@ def main():
             "build_s": t_build,
             "sample_result": {"ids": [int(x) for x in ids[0][:3]], "scores": [float(x) for x in scores[0][:3]]},
         }
-        if world == 1 and not args.no_extra:
+        if world == 1 and not args.no_extra and not use_dist:  # (not in the one-rank rehearsal of the N > 1 path either)
             # the other legs BASELINE.json names, measured in the same run (single GPU only)
             extra = {}
             only = only_legs
@@ -735,7 +735,7 @@ def main():
         print(json.dumps(out), file=line_out, flush=True)
 
     native_failed = False
-    if use_dist and comm is None and want_native_check:
+    if use_dist and comm is None and want_native_check and searcher is not None:
         # the library's own communicator (pcv_comm_*, ncclAllGather on its stream, no PyTorch in the data path) on the same
         # steps, after the line above is out: what a Rust / C++ host binds.  It has never had more than one GPU to run on.
         native_failed = not native_check(pa, ctx, dist, torch, searcher, queries, args, rank, world, last, barrier)
