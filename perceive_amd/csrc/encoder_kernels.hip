@@ -2378,7 +2378,8 @@ void launch_attention(hipStream_t st, const float* qkv, const float* mask_add, f
         static const bool no_persist = getenv("PCV_ATTN_NO_PERSIST") != nullptr;
         // head_dim 64 at 256 keys (BERT-base): one 139 KB workgroup per CU, 244 registers: the persistent form with the
         // next item's pieces in flight, 128 -> 117 us per call (64 x 256 tokens).  head_dim 32 (two 75 KB workgroups
-        // per CU, 128 registers: no room for pieces in flight) measured 232 us persistent against 224 us: not used.
+        // per CU, 128 registers: no room for pieces in flight) measured 232 us persistent against 224 us: not used; nor with
+        // 32-key chunks, which leave room for the pieces (128 registers, 20 B of scratch): 236 us (round 4).
         if (Lp == 256 && HD == 64 && !no_persist) {
             launch_attention_persist<64, 8, 2, 8>(st, qkv, mask_add, ctx, B, L, Lp, H, heads, lds);
             return;
