@@ -679,11 +679,14 @@ def main():
                 # the same corpus and queries' shape without the int8 copy: the scan streams the f32 rows themselves
                 # (1536 B/vector, the SURVEY 8d / north_star workload) or the bf16 copy; results are the same exact top-k
                 held = {"int8": ((args.dim + 127) // 128) * 128 + 0.125, "bf16": 2 * args.dim}  # bytes per row of a copy
+                # (a 16-bit mid copy that AUTO built during the 128- / 256-query legs goes with the int8 copy it refines: it is part
+                # of what the driver then clears in the background)
+                had_mid = bool(searcher.last_stats()["mid_copy"])
                 for mode, key in (("off", "f32_rows_b64"), ("bf16", "bf16_copy_b64")):
                     searcher.set_screening_copy(mode)
                     searcher.finalize()
                     if mode == "off":
-                        settle(total_rows * held[copy])
+                        settle(total_rows * (held[copy] + (2 * args.dim + 4 if had_mid else 0)))
                     extra[key] = scan_leg(pa, ctx, total_rows, B, k, args.kernel, es, ew, searcher=searcher, dim=args.dim, leg=key)
                 # the north_star's own workload ("coalesced HBM reads of the corpus f32 rows", >= 70 % of the HBM roofline): beside the headline
                 f = extra["f32_rows_b64"]
