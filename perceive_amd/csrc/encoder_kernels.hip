@@ -327,6 +327,105 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
     store_quarter<EPI>(acc, bv, resid, C, M, N, m0 + wr * 64, n0 + wc * 64, i, kk);
 }
 
+// The same GEMM on 128 x 96 output tiles, + bias only (the QKV projection), for grids that the 128 x 128 tiling deals unevenly:
+// at 8 192 tokens N = 1 152 gives 576 tiles — 2.25 per CU, so the call takes as long as the CUs with three — but 768 tiles of
+// 96 columns, three per CU, each 0.75 of the work (round 4).  Four waves, each 32 rows x 96 columns (1 x 3 MFMA tiles: one A
+// fragment serves three multiplies); staging, prefetch and the K loop as above; the epilogue takes the wave's tile through LDS in
+// two halves of 16 rows and stores rows as 16-byte pieces.
+constexpr int BN96 = 96, LDE96 = 100;
+__global__ __launch_bounds__(256, 4) void gemm_f32_n96_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ C, int M, int N,
+                                                              int K) {
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN96) * LDT];
+    float* As = smem;
+    float* Ws = smem + BM * LDT;
+    static_assert(4 * 16 * LDE96 <= (BM + BN96) * LDT, "epilogue tiles fit the staging buffers");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    int tile_m, tile_n;
+    tile_of_block(N / BN96, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN96;
+    const int srow = tid >> 3, c4 = tid & 7;
+    const uint32_t lane_off = (uint32_t)(srow * K + c4 * 4) * 4u;
+    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * K), 0, (uint32_t)(min(M - m0, BM) * K) * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)n0 * K), 0, (uint32_t)(BN96 * K) * 4u, 0x00020000);
+    f32x4 ra[4], rw[3];
+    auto fetch = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, lane_off, (uint32_t)(32 * u * K + kt * BK) * 4u, 0));
+#pragma unroll
+        for (int u = 0; u < 3; ++u) rw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, lane_off, (uint32_t)(32 * u * K + kt * BK) * 4u, 0));
+    };
+    fetch(0);
+    f32x16 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    const float* ap = &As[(wave * 32 + i) * LDT + 16 * kk];
+    const float* bp = &Ws[i * LDT + 16 * kk];
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(f32x4*)&As[(srow + 32 * u) * LDT + c4 * 4] = ra[u];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) *(f32x4*)&Ws[(srow + 32 * u) * LDT + c4 * 4] = rw[u];
+        __syncthreads();
+        fetch(min(kt + 1, nk - 1));
+        __builtin_amdgcn_sched_barrier(0);  // (see gemm_f32_kernel)
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            const f32x4 x = *(const f32x4*)(ap + 4 * hh);
+            f32x4 y[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) y[c] = *(const f32x4*)(bp + c * 32 * LDT + 4 * hh);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s], y[c][s], acc[c], 0, 0, 0);
+        }
+    }
+    const int row0 = m0 + wave * 32;
+    if (m0 + BM <= M) {  // full tile (workgroup-uniform)
+        __syncthreads();  // every wave is done with the last K step's fragments
+        float* T = smem + wave * 16 * LDE96;
+        const int row8 = lane >> 3, l8 = lane & 7;
+        f32x4 b4[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) b4[j] = bias ? *(const f32x4*)(bias + n0 + 4 * (l8 + 8 * j)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) T[(acc_row(8 * half + r, kk) - 16 * half) * LDE96 + c * 32 + i] = acc[c][8 * half + r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's tile is written (no other wave touches it)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int row = row8 + 8 * p;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    *(f32x4*)(C + (size_t)(row0 + 16 * half + row) * N + n0 + 4 * (l8 + 8 * j)) = *(const f32x4*)(T + row * LDE96 + 4 * (l8 + 8 * j)) + b4[j];
+            }
+            __builtin_amdgcn_wave_barrier();  // the reads are issued before the next half overwrites the tile
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int col = n0 + c * 32 + i;
+        const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + acc_row(r, kk);
+            if (row < M) C[(size_t)row * N + col] = acc[c][r] + bv;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // out = LayerNorm(A W^T + bias + resid) for N = hidden <= 384 (all-MiniLM widths): the attention-output
 // and FFN-down projections with their residual + LayerNorm in the epilogue.  A workgroup owns 64 whole rows
@@ -2212,6 +2311,17 @@ void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float
         else
             launch_skinny<4, 4>(st, A, W, bias, resid, C, M, N, K, epilogue);
         return;
+    }
+    if (epilogue == EPI_BIAS && N % BN96 == 0) {
+        // 96-column tiles where they deal the CUs a lighter worst case (a 96-column tile = 0.75 of a 128-column one; ties keep
+        // the wider tile and its better operand reuse): 8 192 x 1 152 -> 3 x 0.75 against 3, 65 536 x 1 152 -> 24 x 0.75 against 18
+        static const bool no96 = getenv("PCV_NO_N96") != nullptr;  // (comparison switch)
+        const long cus = current_device_cus(), mt = (M + BM - 1) / BM;
+        const long t128 = mt * (N / BN), t96 = mt * (N / BN96);
+        if (!no96 && N % BN == 0 && 3 * ((t96 + cus - 1) / cus) < 4 * ((t128 + cus - 1) / cus)) {
+            gemm_f32_n96_kernel<<<dim3((unsigned)t96), 256, 0, st>>>(A, W, bias, C, M, N, K);
+            return;
+        }
     }
     dim3 grid((N / BN) * ((M + BM - 1) / BM));
     switch (epilogue) {

@@ -126,7 +126,8 @@ def test_minilm_shape_few_tokens_32_row_layernorm_tiles(ctx, oracle, shape):
     # One rank's share of BASELINE configs[4] (32 documents x 256 tokens = 8 192 tokens) and other token counts that fill the
     # chip better in 32-row tiles than in 64-row ones: the projection + LayerNorm fusion runs on 32-row tiles whose eight waves
     # split K and stage their operands privately (gemm_f32_ln32_kernel); (40, 200) ends in a partial tile, (9, 100) is a handful
-    # of tiles, (97, 250) = 24 250 tokens are 758 tiles: three (or two) per workgroup, the last one partial.  Sampled documents against the C oracle (padding invariance makes
+    # of tiles, (97, 250) = 24 250 tokens are 758 tiles: three (or two) per workgroup, the last one partial.  At these token counts
+    # the QKV projection runs on 128 x 96 tiles (gemm_f32_n96_kernel; (40, 200) and (97, 250) end in a partial row tile).  Sampled documents against the C oracle (padding invariance makes
     # single-row oracle runs valid), and the whole batch against the 64-row form of the same fusion (PCV_NO_LN32 is read once
     # per process, so the comparison model is the all-in-one-batch run of the documents one by one).
     B, L = shape
