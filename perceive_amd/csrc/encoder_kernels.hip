@@ -327,12 +327,13 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
     store_quarter<EPI>(acc, bv, resid, C, M, N, m0 + wr * 64, n0 + wc * 64, i, kk);
 }
 
-// The same GEMM on 128 x 96 output tiles, + bias only (the QKV projection), for grids that the 128 x 128 tiling deals unevenly:
+// The same GEMM on 128 x 96 output tiles, + bias (+ GELU), for grids that the 128 x 128 tiling deals unevenly:
 // at 8 192 tokens N = 1 152 gives 576 tiles — 2.25 per CU, so the call takes as long as the CUs with three — but 768 tiles of
 // 96 columns, three per CU, each 0.75 of the work (round 4).  Four waves, each 32 rows x 96 columns (1 x 3 MFMA tiles: one A
 // fragment serves three multiplies); staging, prefetch and the K loop as above; the epilogue takes the wave's tile through LDS in
 // two halves of 16 rows and stores rows as 16-byte pieces.
 constexpr int BN96 = 96, LDE96 = 100;
+template <int EPI>
 __global__ __launch_bounds__(256, 4) void gemm_f32_n96_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                               const float* __restrict__ bias, float* __restrict__ C, int M, int N,
                                                               int K) {
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_n96_kernel(const float* __res
                 const int row = row8 + 8 * p;
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    *(f32x4*)(C + (size_t)(row0 + 16 * half + row) * N + n0 + 4 * (l8 + 8 * j)) = *(const f32x4*)(T + row * LDE96 + 4 * (l8 + 8 * j)) + b4[j];
+                    *(f32x4*)(C + (size_t)(row0 + 16 * half + row) * N + n0 + 4 * (l8 + 8 * j)) = epi_act4<EPI>(*(const f32x4*)(T + row * LDE96 + 4 * (l8 + 8 * j)) + b4[j]);
             }
             __builtin_amdgcn_wave_barrier();  // the reads are issued before the next half overwrites the tile
             __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_n96_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + acc_row(r, kk);
-            if (row < M) C[(size_t)row * N + col] = acc[c][r] + bv;
+            if (row < M) C[(size_t)row * N + col] = epi_act<EPI>(acc[c][r] + bv);
         }
     }
 }
@@ -2312,14 +2313,16 @@ void launch_gemm_f32(hipStream_t st, const float* A, const float* W, const float
             launch_skinny<4, 4>(st, A, W, bias, resid, C, M, N, K, epilogue);
         return;
     }
-    if (epilogue == EPI_BIAS && N % BN96 == 0) {
+    if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU) && N % BN96 == 0) {
         // 96-column tiles where they deal the CUs a lighter worst case (a 96-column tile = 0.75 of a 128-column one; ties keep
         // the wider tile and its better operand reuse): 8 192 x 1 152 -> 3 x 0.75 against 3, 65 536 x 1 152 -> 24 x 0.75 against 18
         static const bool no96 = getenv("PCV_NO_N96") != nullptr;  // (comparison switch)
         const long cus = current_device_cus(), mt = (M + BM - 1) / BM;
         const long t128 = mt * (N / BN), t96 = mt * (N / BN96);
-        if (!no96 && N % BN == 0 && 3 * ((t96 + cus - 1) / cus) < 4 * ((t128 + cus - 1) / cus)) {
-            gemm_f32_n96_kernel<<<dim3((unsigned)t96), 256, 0, st>>>(A, W, bias, C, M, N, K);
+        const long c96 = 3 * ((t96 + cus - 1) / cus), c128 = 4 * ((t128 + cus - 1) / cus);
+        if (!no96 && N % BN == 0 && c96 < c128) {  // (at ties the 96-column tiles measured 1-2 % slower: 90.6 / 89.4 us, 601 / 588 us)
+            if (epilogue == EPI_BIAS) gemm_f32_n96_kernel<EPI_BIAS><<<dim3((unsigned)t96), 256, 0, st>>>(A, W, bias, C, M, N, K);
+            else gemm_f32_n96_kernel<EPI_BIAS_GELU><<<dim3((unsigned)t96), 256, 0, st>>>(A, W, bias, C, M, N, K);
             return;
         }
     }
