@@ -1920,7 +1920,10 @@ __device__ __forceinline__ void attn_wave(float (&qf)[HD / 2], const float* next
     // P V product instead of one chain of 32 dependent MFMAs; s_setprio 1 for the younger half of the workgroup; 128-key
     // chunks: 254 us, 32-key chunks: 229 us.  With the loads, the exps, the LDS addresses and the stores all stubbed out
     // the kernel still took 218 us: the time was in workgroup turnover, see attention_persist_kernel.  Round 4, the same question
-    // asked piece by piece: 237 us as it stands, 229 without the exponentials, 214 without any per-element softmax arithmetic.  Half of the first
+    // asked piece by piece: 237 us as it stands, 229 without the exponentials, 214 without any per-element softmax arithmetic.
+    // And turnover is not it either: persistent workgroups that stream an item's keys and values through LDS in two double-buffered
+    // chunks of 128 keys (the next chunk requested into 16 registers under this chunk's multiplies, one barrier per chunk, no
+    // staging round trip in front of any item) took 230 us against 222 us on the same box (44.8 against 46.1 us at 32 x 256).  Half of the first
     // wave of workgroups started 18 us late, so that the two workgroups of a CU do not stage in step: 224 us as well.)
     f32x16 s[TPC];
     float mc;
