@@ -584,12 +584,7 @@ def main():
     else:
         mean_scan_ms = float(np.mean(scan_ms))
 
-    e2e_dist = None
-    if use_dist and world > 1 and not args.no_e2e and args.dim == 384 and not args.clustered:
-        # BASELINE configs[4] at this N: every rank encodes its share of 256 documents, the embeddings stay on the devices,
-        # one all-gather completes them on every rank, two sharded passes of 128 queries read them from device memory
-        e2e_dist = e2e_dist_leg(pa, ctx, dist, torch, sharded, rank, world, rehearse, total_rows, barrier)
-
+    final_out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         vectors_per_s = total_rows * args.steps / elapsed
@@ -731,17 +726,50 @@ def main():
             if want("encoder_bertbase_64x256"):
                 extra["encoder_bertbase_64x256"] = encoder_leg(pa, ctx, "f32", batch=64, seq=256, shape="bert_base")
             out["extra"] = extra
-        if e2e_dist is not None:
-            out["extra"] = {"config5_end_to_end": e2e_dist}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), file=line_out, flush=True)
+        final_out = out
+
+    if use_dist and world > 1 and not args.no_e2e and args.dim == 384 and not args.clustered:
+        # BASELINE configs[4] at this N: every rank encodes its share of 256 documents, the embeddings stay on the devices,
+        # one all-gather completes them on every rank, two sharded passes of 128 queries read them from device memory.  After the
+        # headline's figures are final and under a guard: this leg has not run on more than one GPU yet (gloo rehearsal only) —
+        # should it hang there, the headline's line still goes out and the job ends
+        import threading
+
+        def give_up_e2e():
+            if rank == 0:
+                final_out["extra"] = {"config5_end_to_end": {"error": "no answer within 240 s"}}
+                print(json.dumps(final_out), file=line_out, flush=True)
+            os._exit(0)
+
+        guard = threading.Timer(240.0, give_up_e2e)
+        guard.daemon = True
+        guard.start()
+        e2e_dist = e2e_dist_leg(pa, ctx, dist, torch, sharded, rank, world, rehearse, total_rows, barrier)
+        guard.cancel()
+        if rank == 0:
+            final_out["extra"] = {"config5_end_to_end": e2e_dist}
+    if rank == 0:
+        print(json.dumps(final_out), file=line_out, flush=True)
 
     native_failed = False
     if use_dist and comm is None and want_native_check and searcher is not None:
         # the library's own communicator (pcv_comm_*, ncclAllGather on its stream, no PyTorch in the data path) on the same
         # steps, after the line above is out: what a Rust / C++ host binds.  It has never had more than one GPU to run on.
+        # (a guard: this path has never run on more than one GPU; should it hang there, the line above is out and the job must
+        # still end — a timer thread ends the process with the line's status; the main thread may be inside a C call)
+        import threading
+
+        def give_up():
+            print("native_check: " + json.dumps({"native_ok": False, "n_gpus": world, "native_error": "no answer within 120 s"}), file=sys.stderr, flush=True)
+            os._exit(3 if args.collective == "both" else 0)
+
+        guard = threading.Timer(120.0, give_up)
+        guard.daemon = True
+        guard.start()
         native_failed = not native_check(pa, ctx, dist, torch, searcher, queries, args, rank, world, last, barrier)
+        guard.cancel()
     if use_dist and comm is not None:
         comm.close()
     if searcher is not None:
